@@ -1,0 +1,187 @@
+/*
+ * oxcull.h -- C ABI of the MI355X-native meshlet visibility pipeline (liboxcull.so).
+ *
+ * Drop-in boundary for the Oxylus engine's compute-path cull.  The engine has no plugin/FFI
+ * table for this path; the boundary is the two RendererInstance members
+ *
+ *   auto generate_hiz(this RendererInstance&, MainGeometryContext&) -> void;
+ *   auto cull_geometry(this RendererInstance&, CullGeometryContext&) -> void;
+ *       (Oxylus/include/Render/RendererInstance.hpp:397-398, bodies in
+ *        Oxylus/src/Render/Passes/CullGeometry.cpp:10-59 and :61-404)
+ *
+ * plus their context structs (RendererInstance.hpp:143-216).  This header is the plain-C
+ * surface under a C++ shim that keeps those names (oxylus_amd/host/RendererInstance.hpp):
+ * every vuk::Value<vuk::Buffer> becomes {device pointer, bytes}, every
+ * vuk::Value<vuk::ImageAttachment> becomes a linear mip chain in device memory.  All buffers
+ * use the reference's GPU byte layouts (Oxylus/include/Scene/SceneGPU.hpp:84-152,222-229), so a
+ * Vulkan consumer could bind the outputs unchanged.
+ *
+ * Conventions: POD structs only, no exceptions cross the ABI, every entry point returns an
+ * oxc_status.  One context per device, externally synchronised (the reference calls these from
+ * the main thread only, RenderContext.cpp:585-586).  All work is enqueued asynchronously on the
+ * caller's hipStream_t (passed as void*); the only entry points that synchronise are
+ * oxc_read_counters and oxc_reserve (when it has to grow scratch memory).
+ */
+#ifndef OXCULL_H
+#define OXCULL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OXC_ABI_VERSION 1u
+
+typedef struct oxc_ctx oxc_ctx;
+
+typedef enum oxc_status {
+  OXC_OK = 0,
+  OXC_INVALID_ARG = 1,
+  OXC_HIP_ERROR = 2,
+  OXC_RCCL_ERROR = 3,
+  OXC_OUT_OF_MEMORY = 4
+} oxc_status;
+
+/* GPU::CullFlag, SceneGPU.hpp:345-353 (spec constant 0 of every cull pipeline,
+ * CullGeometry.cpp:89,156,298,363).  HAS_FLAG(mask, a|b) in the shaders means "any of". */
+enum {
+  OXC_CULL_NONE = 0u,
+  OXC_CULL_TEST_FRUSTUM = 1u << 0,
+  OXC_CULL_SELECT_LOD = 1u << 1,
+  OXC_CULL_TEST_OCCLUSION = 1u << 2,
+  OXC_CULL_LATE_PASS = 1u << 3,
+  OXC_CULL_TEST_ALL = 7u
+};
+
+/* Which stages of cull_geometry to run (extension; 0 = all, as the reference always does).
+ * Used by the benchmark for the "frustum+cone cull only" configuration. */
+enum {
+  OXC_STAGE_MESHES = 1u << 0,    /* cull_meshes   (only honoured when init_cull_meshes) */
+  OXC_STAGE_MESHLETS = 1u << 1,  /* cull_meshlets / cull_meshlets_hiz */
+  OXC_STAGE_TRIANGLES = 1u << 2, /* cull_triangles */
+  OXC_STAGE_ALL = 7u
+};
+
+/* vuk::Value<vuk::Buffer> stand-in: device pointer + size. */
+typedef struct oxc_buffer {
+  void* dptr;
+  uint64_t bytes;
+} oxc_buffer;
+
+/* vuk::Value<vuk::ImageAttachment> stand-in for R32F / D32F images: a linear, row-major mip
+ * chain in one device allocation.  Level k is max(1,width>>k) x max(1,height>>k) floats at
+ * byte offset level_offset[k]. */
+typedef struct oxc_image {
+  void* dptr;
+  uint32_t width, height, levels, _pad;
+  uint64_t level_offset[13]; /* bytes; hiz.slang binds at most 13 mips (CullGeometry.cpp:24,36-38) */
+} oxc_image;
+
+/* GPU::CullCamera -- 96 B push constant (SceneGPU.hpp:222-229, scene.slang:196-203). */
+typedef struct oxc_cull_camera {
+  float projection_view[16]; /* glm::mat4, column-major */
+  float position[3];
+  float acceptable_lod_error;
+  float resolution[2];
+  float near_clip;
+  uint32_t mesh_instance_count;
+} oxc_cull_camera;
+
+/* The PreparedFrame buffers the cull path touches (RendererInstance.hpp:143-169; sizes from
+ * RendererInstance.cpp:1640-1732).  Caller-owned device memory. */
+typedef struct oxc_prepared_frame {
+  uint32_t mesh_instance_count;
+  uint32_t max_meshlet_instance_count;
+  oxc_buffer meshes_buffer;                           /* GPU::Mesh[]            read  */
+  oxc_buffer transforms_world_buffer;                 /* GPU::TransformWorld[]  read  */
+  oxc_buffer mesh_instances_buffer;                   /* GPU::MeshInstance[]    read; lod_index written by cull_meshes */
+  oxc_buffer meshlet_instances_buffer;                /* GPU::MeshletInstance[] written by cull_meshes, read after */
+  oxc_buffer visible_meshlet_instances_indices_buffer; /* u32[max_meshlet_instance_count] written */
+  oxc_buffer meshlet_instance_visibility_mask_buffer; /* u32[ceil(N/32)] persistent, read+written when use_hiz */
+  oxc_buffer reordered_indices_buffer;                /* u32[N*64*3] written by cull_triangles */
+} oxc_prepared_frame;
+
+/* CullGeometryContext (RendererInstance.hpp:171-197).  Field names are the reference's. */
+typedef struct oxc_cull_geometry_context {
+  uint32_t struct_size; /* sizeof(oxc_cull_geometry_context), for ABI evolution */
+  uint32_t use_hiz;     /* cull_meshlets_hiz path (two-pass occlusion) */
+  uint32_t use_hpb;     /* cull_meshlets_hpb path (VSM) -- not implemented yet: OXC_INVALID_ARG */
+  uint32_t init_cull_meshes;
+  uint32_t cull_flags;  /* OXC_CULL_* */
+  uint32_t stages;      /* OXC_STAGE_*; 0 = all */
+  oxc_cull_camera cull_camera;
+  oxc_image hiz_attachment; /* read when use_hiz */
+  /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
+   * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
+  oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */
+  oxc_buffer cull_meshlets_cmd_buffer; /* VkDispatchIndirectCommand {x, 1, 1} */
+  /* out: fresh per call (CullGeometry.cpp:125-127, 380-382) */
+  oxc_buffer cull_triangles_cmd_buffer; /* VkDispatchIndirectCommand {#visible meshlets, 1, 1} */
+  oxc_buffer draw_geometry_cmd_buffer;  /* VkDrawIndexedIndirectCommand {indexCount, 1, 0, 0, 0} */
+} oxc_cull_geometry_context;
+
+/* MainGeometryContext fields used by generate_hiz (RendererInstance.hpp:199-216). */
+typedef struct oxc_main_geometry_context {
+  uint32_t struct_size;
+  uint32_t _pad;
+  oxc_image depth_attachment; /* levels = 1; read */
+  oxc_image hiz_attachment;   /* written: all `levels` mips */
+} oxc_main_geometry_context;
+
+typedef struct oxc_counters {
+  uint32_t total_visible_meshlet_instances; /* visibility[0] */
+  uint32_t early_visible_meshlet_instances;
+  uint32_t late_visible_meshlet_instances;
+  uint32_t cull_meshlets_cmd_x;
+  uint32_t cull_triangles_cmd_x; /* meshlets emitted by this call */
+  uint32_t draw_index_count;     /* 3 * triangles emitted by this call */
+} oxc_counters;
+
+/* ---- lifetime ---- */
+uint32_t oxc_abi_version(void);
+oxc_status oxc_create(int device, oxc_ctx** out);
+void oxc_destroy(oxc_ctx* ctx);
+const char* oxc_last_error(const oxc_ctx* ctx);
+
+/* Pre-size the context's scratch memory (instance cache, survivor bitmaps, chunk counters) so
+ * that no later call allocates.  Optional: calls grow scratch on demand (with a device sync). */
+oxc_status oxc_reserve(oxc_ctx* ctx, uint32_t max_mesh_instances, uint32_t max_meshlet_instances);
+
+/* ---- the two reference entry points ---- */
+/* Replaces RendererInstance::generate_hiz (Passes/CullGeometry.cpp:10-59, passes/hiz.slang). */
+oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* context, void* hip_stream);
+
+/* Replaces RendererInstance::cull_geometry (Passes/CullGeometry.cpp:61-404; kernels
+ * passes/cull_meshes.slang, cull_meshlets.slang, cull_meshlets_hiz.slang, cull_triangles.slang).
+ * Output lists are written in ascending order (a valid outcome of the reference's
+ * atomic-ordered output, and a deterministic one). */
+oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* frame, oxc_cull_geometry_context* context,
+                             void* hip_stream);
+
+/* Harness helper: start a cull sequence from a caller-provided MeshletInstance list instead of
+ * running cull_meshes (fills context->visibility_buffer = {total,0,0} and
+ * cull_meshlets_cmd_buffer = {ceil(total/64),1,1}).  The reference always derives these from
+ * cull_meshes; the synthetic benchmark configurations start from a given list. */
+oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* context, uint32_t total,
+                                      void* hip_stream);
+
+/* Synchronising readback of the counters a context points at (bench / tests). */
+oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* context, oxc_counters* out,
+                             void* hip_stream);
+
+/* Streaming-read probe: sums `bytes` of device memory with 16 B/lane loads (the measured HBM
+ * ceiling SURVEY 8d asks to report next to the 8 TB/s spec figure). */
+oxc_status oxc_stream_read_probe(oxc_ctx* ctx, const void* dptr, uint64_t bytes, void* hip_stream);
+
+/* Test hook: decode n GPU::MeshletBounds records with the device's dequantize_half / s8/127
+ * routines into 10 floats each {center.xyz, extent.xyz, cone_axis.xyz, cone_cutoff}
+ * (scene.slang:401-435) -- lets the known-answer tests sweep all 65536 halfs and 256 s8s. */
+oxc_status oxc_debug_decode_bounds(oxc_ctx* ctx, const void* bounds_dptr, uint32_t n, float* out10_dptr,
+                                   void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OXCULL_H */

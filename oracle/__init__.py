@@ -1,0 +1,201 @@
+"""ctypes wrapper of the CPU oracle (oracle/oxcull_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by anything under oxylus_amd/.  PARITY UNPINNED (see the C header).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboxcull_oracle.so")
+
+
+def build() -> str:
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class Hiz(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32),
+                ("level_offset", C.c_uint64 * 13)]
+
+
+class Visibility(C.Structure):
+    _fields_ = [("total", C.c_uint32), ("early", C.c_uint32), ("late", C.c_uint32)]
+
+
+class MarginStats(C.Structure):
+    _fields_ = [("meshlets_near_threshold", C.c_uint64), ("triangles_near_threshold", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        l = C.CDLL(LIB_PATH)
+        vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
+        l.orc_dequantize_half.argtypes = [C.c_uint16]
+        l.orc_dequantize_half.restype = f32
+        l.orc_mul_mat4.argtypes = [vp, vp, vp]
+        l.orc_test_frustum.argtypes = [vp, vp, vp]
+        l.orc_test_cone.argtypes = [vp, f32, vp, f32, vp]
+        l.orc_project_aabb.argtypes = [vp, f32, vp, vp, vp]
+        l.orc_test_occlusion.argtypes = [vp, C.POINTER(Hiz)]
+        l.orc_occlusion_mip.argtypes = [vp, C.POINTER(Hiz)]
+        l.orc_occlusion_mip.restype = u32
+        l.orc_sample_level_min_reduction_2x2.argtypes = [C.POINTER(Hiz), f32, f32, u32]
+        l.orc_sample_level_min_reduction_2x2.restype = f32
+        l.orc_test_triangle_backface.argtypes = [vp]
+        l.orc_normal_matrix.argtypes = [vp, vp]
+        l.orc_to_world_radius.argtypes = [vp, f32]
+        l.orc_to_world_radius.restype = f32
+        l.orc_decode_bounds.argtypes = [vp, vp, vp, vp, vp]
+        l.orc_generate_hiz.argtypes = [vp, u32, u32, C.POINTER(Hiz)]
+        l.orc_generate_hiz.restype = None
+        l.orc_cull_meshes.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+        l.orc_cull_meshes.restype = u32
+        l.orc_cull_meshlets.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, vp]
+        l.orc_cull_meshlets.restype = u32
+        l.orc_cull_meshlets_mt.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32]
+        l.orc_cull_meshlets_mt.restype = u32
+        l.orc_cull_meshlets_hiz.argtypes = [vp, vp, vp, vp, vp, u32, C.POINTER(Hiz), C.POINTER(Visibility), vp, vp, vp]
+        l.orc_cull_meshlets_hiz.restype = u32
+        l.orc_cull_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp]
+        l.orc_cull_triangles.restype = u32
+        l.orc_cull_triangles_mt.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, u32]
+        l.orc_cull_triangles_mt.restype = u32
+        l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
+        l.orc_entities_update_and_cull.restype = u32
+        _lib = l
+    return _lib
+
+
+def _p(a) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(None)
+    if isinstance(a, torch.Tensor):
+        assert a.device.type == "cpu" and a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(C.addressof(a))
+
+
+def f32a(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+# ---- scalar function wrappers (KATs) ----
+def dequantize_half(h: int) -> float:
+    return lib().orc_dequantize_half(int(h) & 0xFFFF)
+
+
+def test_frustum(mvp, center, extent) -> bool:
+    return bool(lib().orc_test_frustum(_p(f32a(mvp)), _p(f32a(center)), _p(f32a(extent))))
+
+
+def test_cone(center, radius, axis, cutoff, cam) -> bool:
+    return bool(lib().orc_test_cone(_p(f32a(center)), float(radius), _p(f32a(axis)), float(cutoff), _p(f32a(cam))))
+
+
+def project_aabb(mvp, near, center, extent):
+    out = np.zeros(6, dtype=np.float32)
+    ok = lib().orc_project_aabb(_p(f32a(mvp)), float(near), _p(f32a(center)), _p(f32a(extent)), _p(out))
+    return out if ok else None
+
+
+def mul_mat4(a, b) -> np.ndarray:
+    out = np.zeros(16, dtype=np.float32)
+    lib().orc_mul_mat4(_p(f32a(a)), _p(f32a(b)), _p(out))
+    return out
+
+
+def make_hiz(data: np.ndarray, width: int, height: int, levels: int, level_offset_bytes) -> Hiz:
+    h = Hiz()
+    h.data = data.ctypes.data if isinstance(data, np.ndarray) else data.data_ptr()
+    h.width, h.height, h.levels = width, height, levels
+    for k, o in enumerate(level_offset_bytes):
+        h.level_offset[k] = o // 4
+    return h
+
+
+def test_occlusion(screen_aabb, hiz: Hiz) -> bool:
+    return bool(lib().orc_test_occlusion(_p(f32a(screen_aabb)), C.byref(hiz)))
+
+
+def occlusion_mip(screen_aabb, hiz: Hiz) -> int:
+    return int(lib().orc_occlusion_mip(_p(f32a(screen_aabb)), C.byref(hiz)))
+
+
+def triangle_backface(clip3x4) -> bool:
+    return bool(lib().orc_test_triangle_backface(_p(f32a(clip3x4))))
+
+
+def decode_bounds(bounds_i16x8: np.ndarray):
+    """bounds: int16 [n, 8] -> float32 [n, 10] {center, extent, axis, cutoff}."""
+    b = np.ascontiguousarray(bounds_i16x8)
+    n = b.shape[0]
+    out = np.zeros((n, 10), dtype=np.float32)
+    l = lib()
+    for i in range(n):
+        base = out[i:i + 1]
+        l.orc_decode_bounds(C.c_void_p(b.ctypes.data + 16 * i), C.c_void_p(base.ctypes.data), C.c_void_p(base.ctypes.data + 12),
+                            C.c_void_p(base.ctypes.data + 24), C.c_void_p(base.ctypes.data + 36))
+    return out
+
+
+# ---- kernel wrappers over a CPU `Scene` (oxylus_amd.synth.Scene on device cpu) ----
+def generate_hiz(depth: torch.Tensor, hiz_data: torch.Tensor, width: int, height: int, levels: int, level_offset_bytes) -> None:
+    assert depth.dtype == torch.float32 and depth.is_contiguous()
+    h = make_hiz(hiz_data, width, height, levels, level_offset_bytes)
+    lib().orc_generate_hiz(_p(depth), depth.shape[1], depth.shape[0], C.byref(h))
+
+
+def cull_meshes(scene, cam, cull_flags: int):
+    """Returns (meshlet_instances int32 [total,2], cmd3). Writes scene.mesh_instances lod_index."""
+    cap = scene.n_meshlet_instances
+    out = torch.zeros((max(cap, 1), 2), dtype=torch.int32)
+    cmd = np.zeros(3, dtype=np.uint32)
+    total = lib().orc_cull_meshes(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(cam), cull_flags, _p(out), _p(cmd))
+    return out[:total].clone(), cmd
+
+
+def cull_meshlets(scene, cam, meshlet_instances: torch.Tensor, nthreads: int = 1, stats: MarginStats = None) -> torch.Tensor:
+    n = meshlet_instances.shape[0]
+    out = torch.zeros(max(n, 1), dtype=torch.int32)
+    if nthreads > 1:
+        cnt = lib().orc_cull_meshlets_mt(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), n, _p(cam), _p(out), nthreads)
+    else:
+        cnt = lib().orc_cull_meshlets(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), 0, n, _p(cam), _p(out),
+                                      C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))
+    return out[:cnt].clone()
+
+
+def cull_meshlets_hiz(scene, cam, meshlet_instances: torch.Tensor, cull_flags: int, hiz: Hiz, vis: Visibility, mask: torch.Tensor,
+                      visible_out: torch.Tensor, stats: MarginStats = None) -> int:
+    return lib().orc_cull_meshlets_hiz(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(cam), cull_flags,
+                                       C.byref(hiz), C.byref(vis), _p(mask), _p(visible_out),
+                                       C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))
+
+
+def cull_triangles(scene, cam, meshlet_instances: torch.Tensor, visible: torch.Tensor, first: int, count: int, nthreads: int = 1,
+                   stats: MarginStats = None) -> torch.Tensor:
+    out = torch.zeros(max(count, 1) * 192, dtype=torch.int32)
+    if nthreads > 1:
+        n = lib().orc_cull_triangles_mt(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
+                                        _p(cam), _p(out), nthreads)
+    else:
+        n = lib().orc_cull_triangles(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
+                                     _p(cam), _p(out), C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))
+    return out[:n].clone()

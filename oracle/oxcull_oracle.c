@@ -1,0 +1,713 @@
+/*
+ * oxcull_oracle.c -- CPU oracle (plain scalar C) for the Oxylus meshlet visibility pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY -- see oxcull_oracle.h.  PARITY UNPINNED (the reference has no
+ * golden vectors for this path and cannot be built here); this is a restatement of the
+ * reference's Slang shaders with the canonical evaluation order of SURVEY.md Appendix A.0.
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/Oxylus/src/Render/Shaders unless noted).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ * Matrices are column-major (glm): element (row r, col c) = m[c*4+r].  Slang's M[i] is ROW i.
+ */
+#include "oxcull_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define M(m, r, c) ((m)[(c)*4 + (r)])
+
+/* ------------------------------------------------------------------------------------------
+ * helpers: canonical float ops
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t f2u(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+static inline float u2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float len3(const float* a) { return sqrtf(dot3(a, a)); }
+static inline float min2(float a, float b) { return fminf(a, b); }
+static inline float max2(float a, float b) { return fmaxf(a, b); }
+
+/* float -> u32 as v_cvt_u32_f32 does it: saturating, NaN -> 0. */
+static inline uint32_t cvt_u32_sat(float f) {
+  if (!(f > 0.0f)) return 0u;
+  if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+  return (uint32_t)f;
+}
+/* float -> i32 saturating, NaN -> 0 (v_cvt_i32_f32). */
+static inline int32_t cvt_i32_sat(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (int32_t)0x80000000;
+  return (int32_t)f;
+}
+
+/* |a-b| within k ulp of the larger magnitude */
+static inline int near_ulp(float a, float b, int k) {
+  float m = fmaxf(fabsf(a), fabsf(b));
+  if (m == 0.0f) return 1;
+  int e;
+  frexpf(m, &e);
+  float ulp = ldexpf(1.0f, e - 24);
+  return fabsf(a - b) <= (float)k * ulp;
+}
+
+/* mul(M, v), rows left-to-right (A.0) */
+static inline void mul_mv4(const float* m, float x, float y, float z, float w, float* out) {
+  for (int i = 0; i < 4; i++) out[i] = ((M(m, i, 0) * x + M(m, i, 1) * y) + M(m, i, 2) * z) + M(m, i, 3) * w;
+}
+/* mul(M, float4(p, 1.0)): the last product M[i][3]*1.0 is exact, so it is written as an add */
+static inline void mul_mp(const float* m, const float* p, float* out) {
+  for (int i = 0; i < 4; i++) out[i] = ((M(m, i, 0) * p[0] + M(m, i, 1) * p[1]) + M(m, i, 2) * p[2]) + M(m, i, 3);
+}
+
+/* mul(A, B) -- cull_meshlets.slang:40 `mul(camera.projection_view, transform.world)` */
+void orc_mul_mat4(const float* a, const float* b, float* out) {
+  float t[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++)
+      M(t, r, c) = ((M(a, r, 0) * M(b, 0, c) + M(a, r, 1) * M(b, 1, c)) + M(a, r, 2) * M(b, 2, c)) + M(a, r, 3) * M(b, 3, c);
+  memcpy(out, t, sizeof t);
+}
+
+/* common/math.slang:193-201 (com::dequantize_half): denormals flush to signed zero,
+ * Inf/NaN keep their class. */
+float orc_dequantize_half(uint16_t h) {
+  uint32_t s = (uint32_t)(h & 0x8000) << 16;
+  int32_t em = h & 0x7fff;
+  int32_t r = (em + (112 << 10)) << 13;
+  r = (em < (1 << 10)) ? 0 : r;
+  r += (em >= (31 << 10)) ? (112 << 23) : 0;
+  return u2f(s | (uint32_t)r);
+}
+
+/* scene.slang:401-435 MeshletBounds::get_* */
+void orc_decode_bounds(const orc_meshlet_bounds* b, float* center, float* extent, float* axis, float* cutoff) {
+  for (int i = 0; i < 3; i++) {
+    center[i] = orc_dequantize_half(b->aabb_center[i]);
+    extent[i] = orc_dequantize_half(b->aabb_extent[i]);
+  }
+  axis[0] = (float)(int32_t)b->cone_axis_xy[0] / 127.0f;
+  axis[1] = (float)(int32_t)b->cone_axis_xy[1] / 127.0f;
+  axis[2] = (float)(int32_t)b->cone_axis_z / 127.0f;
+  *cutoff = (float)(int32_t)b->cone_cutoff / 127.0f;
+}
+
+/* cull.slang:49-51 normalize_plane: all four components divided by length(xyz) */
+static inline void normalize_plane(const float* p, float* out) {
+  float l = len3(p);
+  out[0] = p[0] / l;
+  out[1] = p[1] / l;
+  out[2] = p[2] / l;
+  out[3] = p[3] / l;
+}
+
+static void frustum_planes(const float* mvp, float planes[6][4]) {
+  float r0[4], r1[4], r2[4], r3[4], t[4];
+  for (int c = 0; c < 4; c++) {
+    r0[c] = M(mvp, 0, c);
+    r1[c] = M(mvp, 1, c);
+    r2[c] = M(mvp, 2, c);
+    r3[c] = M(mvp, 3, c);
+  }
+  for (int c = 0; c < 4; c++) t[c] = r3[c] + r0[c]; /* cull.slang:60 left */
+  normalize_plane(t, planes[0]);
+  for (int c = 0; c < 4; c++) t[c] = r3[c] - r0[c]; /* :62 right */
+  normalize_plane(t, planes[1]);
+  for (int c = 0; c < 4; c++) t[c] = r3[c] + r1[c]; /* :64 bottom */
+  normalize_plane(t, planes[2]);
+  for (int c = 0; c < 4; c++) t[c] = r3[c] - r1[c]; /* :66 top */
+  normalize_plane(t, planes[3]);
+  normalize_plane(r2, planes[4]);                    /* :68 near */
+  for (int c = 0; c < 4; c++) t[c] = r3[c] - r2[c]; /* :70 far */
+  normalize_plane(t, planes[5]);
+}
+
+/* cull.slang:57-84 test_frustum.  near_out (optional): set when a plane comparison is
+ * within 4 ulp. */
+static int test_frustum_m(const float* mvp, const float* center, const float* extent, int* near_out) {
+  float planes[6][4];
+  frustum_planes(mvp, planes);
+  float h[3] = {extent[0] * 0.5f, extent[1] * 0.5f, extent[2] * 0.5f};
+  for (int i = 0; i < 6; i++) {
+    float q[3];
+    for (int k = 0; k < 3; k++) {
+      uint32_t flip = f2u(planes[i][k]) & 0x80000000u;
+      q[k] = center[k] + u2f(f2u(h[k]) ^ flip);
+    }
+    float d = dot3(q, planes[i]);
+    float rhs = -planes[i][3];
+    if (near_out && near_ulp(d, rhs, 4)) *near_out = 1;
+    if (d <= rhs) return 0;
+  }
+  return 1;
+}
+int orc_test_frustum(const float* mvp, const float* center, const float* extent) {
+  return test_frustum_m(mvp, center, extent, NULL);
+}
+
+/* cull.slang:173-175 test_cone (true => culled) */
+static int test_cone_m(const float* center, float radius, const float* axis, float cutoff, const float* cam, int* near_out) {
+  float d[3] = {center[0] - cam[0], center[1] - cam[1], center[2] - cam[2]};
+  float lhs = dot3(d, axis);
+  float rhs = cutoff * len3(d) + radius;
+  if (near_out && near_ulp(lhs, rhs, 4)) *near_out = 1;
+  return lhs >= rhs;
+}
+int orc_test_cone(const float* center, float radius, const float* axis, float cutoff, const float* cam) {
+  return test_cone_m(center, radius, axis, cutoff, cam, NULL);
+}
+
+/* scene.slang:292-299 TransformWorld::normal_matrix: cofactor matrix of the upper 3x3.
+ * basis = transpose(mat3(world)) => basis[j] (row j of the transpose) = column j of world.
+ * result = transpose(mat3(cross(b1,b2), cross(b2,b0), cross(b0,b1))) => column k = k-th cross.
+ * out9 is column-major 3x3: element (r,c) = out9[c*3+r]. */
+void orc_normal_matrix(const float* w, float* out9) {
+  float b[3][3];
+  for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) b[j][k] = M(w, k, j);
+  const int a1[3] = {1, 2, 0}, a2[3] = {2, 0, 1};
+  for (int k = 0; k < 3; k++) {
+    const float* u = b[a1[k]];
+    const float* v = b[a2[k]];
+    out9[k * 3 + 0] = u[1] * v[2] - v[1] * u[2];
+    out9[k * 3 + 1] = u[2] * v[0] - v[2] * u[0];
+    out9[k * 3 + 2] = u[0] * v[1] - v[0] * u[1];
+  }
+}
+/* mul(mat3, v) */
+static inline void mul_m3v(const float* m9, const float* v, float* out) {
+  for (int i = 0; i < 3; i++) out[i] = (m9[0 * 3 + i] * v[0] + m9[1 * 3 + i] * v[1]) + m9[2 * 3 + i] * v[2];
+}
+
+/* scene.slang:305-310 to_world_radius -- world[i].xyz is ROW i (A.4) */
+float orc_to_world_radius(const float* w, float radius) {
+  float r0[3] = {M(w, 0, 0), M(w, 0, 1), M(w, 0, 2)};
+  float r1[3] = {M(w, 1, 0), M(w, 1, 1), M(w, 1, 2)};
+  float r2[3] = {M(w, 2, 0), M(w, 2, 1), M(w, 2, 2)};
+  float sx = len3(r0), sy = len3(r1), sz = len3(r2);
+  return radius * max2(sx, max2(sy, sz));
+}
+
+/* cull.slang:12-47 project_aabb.  Returns 0 for `none`. out6 = {min.xyz, max.xyz}. */
+static int project_aabb_m(const float* mvp, float near_clip, const float* c, const float* e, float* out6, int* near_out) {
+  float SX[4], SY[4], SZ[4], P[8][4];
+  for (int i = 0; i < 4; i++) {
+    SX[i] = M(mvp, i, 0) * e[0]; /* mul(mvp,(ex,0,0,0)): the zero products vanish */
+    SY[i] = M(mvp, i, 1) * e[1];
+    SZ[i] = M(mvp, i, 2) * e[2];
+  }
+  float p0[3] = {c[0] - e[0] * 0.5f, c[1] - e[1] * 0.5f, c[2] - e[2] * 0.5f};
+  mul_mp(mvp, p0, P[0]);
+  for (int i = 0; i < 4; i++) {
+    P[1][i] = P[0][i] + SZ[i];
+    P[2][i] = P[0][i] + SY[i];
+    P[3][i] = P[2][i] + SZ[i];
+    P[4][i] = P[0][i] + SX[i];
+    P[5][i] = P[4][i] + SZ[i];
+    P[6][i] = P[4][i] + SY[i];
+    P[7][i] = P[6][i] + SZ[i];
+  }
+  float depth = P[7][3];
+  for (int k = 6; k >= 0; k--) depth = min2(P[k][3], depth);
+  if (near_out && near_ulp(depth, near_clip, 4)) *near_out = 1;
+  if (depth < near_clip) return 0;
+  float vmin[3], vmax[3];
+  for (int j = 0; j < 3; j++) {
+    float lo = P[7][j] / P[7][3];
+    float hi = lo;
+    for (int k = 6; k >= 0; k--) {
+      float d = P[k][j] / P[k][3];
+      lo = min2(d, lo);
+      hi = max2(d, hi);
+    }
+    vmin[j] = lo;
+    vmax[j] = hi;
+  }
+  out6[0] = vmin[0] * 0.5f + 0.5f;
+  out6[1] = vmin[1] * 0.5f + 0.5f;
+  out6[2] = vmin[2];
+  out6[3] = vmax[0] * 0.5f + 0.5f;
+  out6[4] = vmax[1] * 0.5f + 0.5f;
+  out6[5] = vmax[2];
+  return 1;
+}
+int orc_project_aabb(const float* mvp, float near_clip, const float* c, const float* e, float* out6) {
+  return project_aabb_m(mvp, near_clip, c, e, out6, NULL);
+}
+
+static inline uint32_t mip_dim(uint32_t d, uint32_t mip) {
+  uint32_t v = d >> mip;
+  return v ? v : 1u;
+}
+
+/* cull.slang:86-112 sample_level_min_reduction_2x2 */
+float orc_sample_level_min_reduction_2x2(const orc_hiz* hiz, float u, float v, uint32_t mip) {
+  uint32_t mw = mip_dim(hiz->width, mip), mh = mip_dim(hiz->height, mip);
+  float fw = (float)mw, fh = (float)mh;
+  int32_t maxx = (int32_t)mw - 1, maxy = (int32_t)mh - 1;
+  int32_t bx = cvt_i32_sat(floorf(u * fw - 0.5f));
+  int32_t by = cvt_i32_sat(floorf(v * fh - 0.5f));
+#define CLAMPI(x, lo, hi) ((x) < (lo) ? (lo) : ((x) > (hi) ? (hi) : (x)))
+  int32_t x0 = CLAMPI(bx, 0, maxx), y0 = CLAMPI(by, 0, maxy);
+  /* i32 add wraps on the GPU (base + i32x2(1,0)); do it in unsigned to stay defined in C */
+  int32_t bx1 = (int32_t)((uint32_t)bx + 1u), by1 = (int32_t)((uint32_t)by + 1u);
+  int32_t x1 = CLAMPI(bx1, 0, maxx), y1 = CLAMPI(by1, 0, maxy);
+  const float* lvl = hiz->data + hiz->level_offset[mip];
+  float p00 = lvl[(size_t)y0 * mw + x0];
+  float p10 = lvl[(size_t)y0 * mw + x1];
+  float p01 = lvl[(size_t)y1 * mw + x0];
+  float p11 = lvl[(size_t)y1 * mw + x1];
+  return min2(min2(p00, p10), min2(p01, p11));
+}
+
+/* ceil(log2(float(x))) clamped to [0, levels-1], in integers (A.0).  For x > 2^24 the float
+ * conversion may round to the next power of two, but levels <= 13 clamps those anyway. */
+static inline uint32_t ceil_log2_clamped(uint32_t x, uint32_t levels) {
+  uint32_t m = x <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(x - 1u);
+  uint32_t top = levels - 1u;
+  return m > top ? top : m;
+}
+
+static void occlusion_setup(const float* a, const orc_hiz* hiz, uint32_t* mip, float* u, float* v) {
+  float sw = (float)hiz->width, sh = (float)hiz->height;
+  uint32_t minx = cvt_u32_sat(max2(a[0] * sw, 0.0f));
+  uint32_t miny = cvt_u32_sat(max2(a[1] * sh, 0.0f));
+  uint32_t maxx = cvt_u32_sat(min2(a[3] * sw, sw - 1.0f));
+  uint32_t maxy = cvt_u32_sat(min2(a[4] * sh, sh - 1.0f));
+  uint32_t szx = maxx - minx, szy = maxy - miny; /* u32 wrap-around, cull.slang:127 */
+  uint32_t ms = szx > szy ? szx : szy;
+  *mip = ceil_log2_clamped(ms, hiz->levels);
+  *u = (((float)minx + (float)maxx) * 0.5f) / sw;
+  *v = (((float)miny + (float)maxy) * 0.5f) / sh;
+}
+
+uint32_t orc_occlusion_mip(const float* a, const orc_hiz* hiz) {
+  uint32_t mip;
+  float u, v;
+  occlusion_setup(a, hiz, &mip, &u, &v);
+  return mip;
+}
+
+/* cull.slang:114-135 test_occlusion (true => occluded) */
+static int test_occlusion_m(const float* a, const orc_hiz* hiz, int* near_out) {
+  uint32_t mip;
+  float u, v;
+  occlusion_setup(a, hiz, &mip, &u, &v);
+  float d = orc_sample_level_min_reduction_2x2(hiz, u, v, mip);
+  float rhs = d - 1e-7f;
+  if (near_out && near_ulp(a[5], rhs, 4)) *near_out = 1;
+  return a[5] <= rhs;
+}
+int orc_test_occlusion(const float* a, const orc_hiz* hiz) { return test_occlusion_m(a, hiz, NULL); }
+
+/* cull.slang:169-171: determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)) >= 0.0001, first-row
+ * cofactor expansion a(ei-fh) - b(di-fg) + c(dh-eg).  clip3x4: 3 rows of xyzw. */
+static int backface_m(const float* cp, int* near_out) {
+  float a = cp[0], b = cp[1], c = cp[3];
+  float d = cp[4], e = cp[5], f = cp[7];
+  float g = cp[8], h = cp[9], i = cp[11];
+  float det = (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+  if (near_out && near_ulp(det, 0.0001f, 4)) *near_out = 1;
+  return det >= 0.0001f;
+}
+int orc_test_triangle_backface(const float* cp) { return backface_m(cp, NULL); }
+
+/* ------------------------------------------------------------------------------------------
+ * HiZ -- passes/hiz.slang:42-267, host Passes/CullGeometry.cpp:10-59
+ * ---------------------------------------------------------------------------------------- */
+void orc_generate_hiz(const float* depth, uint32_t dw, uint32_t dh, orc_hiz* hiz) {
+  float* out = (float*)hiz->data;
+  uint32_t W = hiz->width, H = hiz->height;
+  uint32_t mips = hiz->levels < 13u ? hiz->levels : 13u; /* CullGeometry.cpp:24 */
+  /* hiz.slang:32-33 inv_src_extent = 1.0 / f32x2(src_extent), src_extent = HiZ extent
+   * (CullGeometry.cpp:29-31). */
+  float invx = 1.0f / (float)W, invy = 1.0f / (float)H;
+  float* m0 = out + hiz->level_offset[0];
+  for (uint32_t y = 0; y < H; y++) {
+    /* hiz.slang:92-95 load(): uv = texel*inv + inv; NEAREST clamped sample of the depth
+     * image (CullGeometry.cpp:33): texel = floor(uv * depth_dim) clamped to the image. */
+    float vv = (float)y * invy + invy;
+    int32_t sy = cvt_i32_sat(floorf(vv * (float)dh));
+    sy = CLAMPI(sy, 0, (int32_t)dh - 1);
+    for (uint32_t x = 0; x < W; x++) {
+      float uu = (float)x * invx + invx;
+      int32_t sx = cvt_i32_sat(floorf(uu * (float)dw));
+      sx = CLAMPI(sx, 0, (int32_t)dw - 1);
+      /* transform_z with mat2(1) (CullGeometry.cpp:44): z / 1 == z */
+      m0[(size_t)y * W + x] = depth[(size_t)sy * dw + sx];
+    }
+  }
+  /* hiz.slang:77-83 reduce = min over the 2x2 block of the previous mip */
+  for (uint32_t k = 1; k < mips; k++) {
+    uint32_t pw = mip_dim(W, k - 1), ph = mip_dim(H, k - 1);
+    uint32_t cw = mip_dim(W, k), ch = mip_dim(H, k);
+    const float* src = out + hiz->level_offset[k - 1];
+    float* dst = out + hiz->level_offset[k];
+    for (uint32_t y = 0; y < ch; y++)
+      for (uint32_t x = 0; x < cw; x++) {
+        uint32_t x0 = 2 * x, y0 = 2 * y;
+        uint32_t x1 = x0 + 1 < pw ? x0 + 1 : pw - 1, y1 = y0 + 1 < ph ? y0 + 1 : ph - 1;
+        float a = src[(size_t)y0 * pw + x0], b = src[(size_t)y0 * pw + x1];
+        float c = src[(size_t)y1 * pw + x0], d = src[(size_t)y1 * pw + x1];
+        dst[(size_t)y * cw + x] = min2(min2(a, b), min2(c, d));
+      }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cull_meshes -- passes/cull_meshes.slang:17-85
+ * ---------------------------------------------------------------------------------------- */
+static inline const float* xform(const float* transforms, uint32_t i) { return transforms + (size_t)i * 16; }
+
+uint32_t orc_cull_meshes(const orc_mesh* meshes, const float* transforms, orc_mesh_instance* mesh_instances,
+                         const orc_cull_camera* cam, uint32_t cull_flags, orc_meshlet_instance* out, uint32_t* cmd3) {
+  uint32_t total = 0;
+  for (uint32_t mi = 0; mi < cam->mesh_instance_count; mi++) {
+    orc_mesh_instance* inst = &mesh_instances[mi];
+    const orc_mesh* mesh = &meshes[inst->mesh_index];
+    const float* world = xform(transforms, inst->transform_index);
+    float mvp[16];
+    orc_mul_mat4(cam->projection_view, world, mvp);
+    uint32_t meshlet_count = 0, lod_index = 0;
+    const orc_mesh_lod* lods = (const orc_mesh_lod*)(uintptr_t)mesh->lods;
+    if ((cull_flags & ORC_TEST_FRUSTUM) && orc_test_frustum(mvp, mesh->aabb_center, mesh->aabb_extent)) {
+      if (cull_flags & ORC_SELECT_LOD) {
+        float c4[4], e4[4];
+        mul_mp(world, mesh->aabb_center, c4);
+        mul_mv4(world, mesh->aabb_extent[0], mesh->aabb_extent[1], mesh->aabb_extent[2], 0.0f, e4);
+        float ex = fabsf(e4[0]), ey = fabsf(e4[1]), ez = fabsf(e4[2]);
+        float rough = max2(ex, max2(ey, ez));
+        float d[3] = {c4[0] - cam->position[0], c4[1] - cam->position[1], c4[2] - cam->position[2]};
+        float dist = max2(len3(d) - 0.5f * rough, 0.0f);
+        float pixel_size_at_1m = 2.0f / max2(cam->resolution[0], cam->resolution[1]);
+        float size_at_1m = rough / dist;
+        float px = size_at_1m / pixel_size_at_1m;
+        for (uint32_t i = 1; i < mesh->lod_count; i++) {
+          float err = px * lods[i].error;
+          if (err < cam->acceptable_lod_error)
+            lod_index = i;
+          else
+            break;
+        }
+      }
+      meshlet_count = lods[lod_index].meshlet_count;
+    }
+    if (meshlet_count > 0) {
+      inst->lod_index = lod_index;
+      for (uint32_t i = 0; i < meshlet_count; i++) {
+        out[total + i].mesh_instance_index = mi;
+        out[total + i].meshlet_index = i;
+      }
+      total += meshlet_count;
+    }
+  }
+  if (cmd3) {
+    cmd3[0] = (total + 63u) / 64u; /* cull_meshes.slang:68-70 atomic_max of ceil(total/64) */
+    cmd3[1] = 1;
+    cmd3[2] = 1;
+  }
+  return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per-meshlet common part of cull_meshlets.slang:37-54 / cull_meshlets_hiz.slang:30-59
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float mvp[16];
+  float center[3], extent[3];
+  int cone_visible;
+  uint32_t mask_index;
+} meshlet_eval;
+
+static void eval_meshlet(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                         const orc_meshlet_instance* mli, const orc_cull_camera* cam, meshlet_eval* ev, int* near_out) {
+  const orc_mesh_instance* inst = &mesh_instances[mli->mesh_instance_index];
+  const float* world = xform(transforms, inst->transform_index);
+  orc_mul_mat4(cam->projection_view, world, ev->mvp);
+  const orc_mesh* mesh = &meshes[inst->mesh_index];
+  const orc_mesh_lod* lod = &((const orc_mesh_lod*)(uintptr_t)mesh->lods)[inst->lod_index];
+  const orc_meshlet_bounds* b = &((const orc_meshlet_bounds*)(uintptr_t)lod->meshlet_bounds)[mli->meshlet_index];
+  float axis[3], cutoff;
+  orc_decode_bounds(b, ev->center, ev->extent, axis, &cutoff);
+  ev->mask_index = inst->meshlet_instance_visibility_offset + mli->meshlet_index;
+
+  /* cull_meshlets.slang:49-52 */
+  float nm[9], na[3];
+  orc_normal_matrix(world, nm);
+  mul_m3v(nm, axis, na);
+  float l = len3(na);
+  float cone_axis[3] = {na[0] / l, na[1] / l, na[2] / l};
+  float wc[4];
+  mul_mp(world, ev->center, wc);
+  float h[3] = {ev->extent[0] * 0.5f, ev->extent[1] * 0.5f, ev->extent[2] * 0.5f};
+  float wr = orc_to_world_radius(world, len3(h));
+  ev->cone_visible = cutoff >= 1.0f || !test_cone_m(wc, wr, cone_axis, cutoff, cam->position, near_out);
+}
+
+uint32_t orc_cull_meshlets(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                           const orc_meshlet_instance* meshlet_instances, uint32_t begin, uint32_t end,
+                           const orc_cull_camera* cam, uint32_t* visible_out, orc_margin_stats* stats) {
+  uint32_t n = 0;
+  for (uint32_t i = begin; i < end; i++) {
+    meshlet_eval ev;
+    int nr = 0;
+    eval_meshlet(meshes, transforms, mesh_instances, &meshlet_instances[i], cam, &ev, stats ? &nr : NULL);
+    int vis = ev.cone_visible && test_frustum_m(ev.mvp, ev.center, ev.extent, stats ? &nr : NULL);
+    if (vis) visible_out[n++] = i;
+    if (stats && nr) stats->meshlets_near_threshold++;
+  }
+  return n;
+}
+
+typedef struct {
+  const orc_mesh* meshes;
+  const float* transforms;
+  const orc_mesh_instance* mesh_instances;
+  const orc_meshlet_instance* meshlet_instances;
+  const uint32_t* visible;
+  const orc_cull_camera* cam;
+  uint32_t begin, end, first;
+  uint32_t* tmp;
+  uint32_t count;
+} mt_job;
+
+static void* mt_meshlets(void* p) {
+  mt_job* j = (mt_job*)p;
+  j->count = orc_cull_meshlets(j->meshes, j->transforms, j->mesh_instances, j->meshlet_instances, j->begin, j->end, j->cam,
+                               j->tmp, NULL);
+  return NULL;
+}
+
+uint32_t orc_cull_meshlets_mt(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                              const orc_meshlet_instance* meshlet_instances, uint32_t total,
+                              const orc_cull_camera* cam, uint32_t* visible_out, uint32_t nthreads) {
+  if (nthreads <= 1) return orc_cull_meshlets(meshes, transforms, mesh_instances, meshlet_instances, 0, total, cam, visible_out, NULL);
+  mt_job* jobs = (mt_job*)calloc(nthreads, sizeof(mt_job));
+  pthread_t* th = (pthread_t*)calloc(nthreads, sizeof(pthread_t));
+  uint32_t* tmp = (uint32_t*)malloc((size_t)total * 4 + 4);
+  for (uint32_t t = 0; t < nthreads; t++) {
+    uint32_t b = (uint32_t)((uint64_t)total * t / nthreads), e = (uint32_t)((uint64_t)total * (t + 1) / nthreads);
+    jobs[t] = (mt_job){meshes, transforms, mesh_instances, meshlet_instances, NULL, cam, b, e, 0, tmp + b, 0};
+    pthread_create(&th[t], NULL, mt_meshlets, &jobs[t]);
+  }
+  uint32_t n = 0;
+  for (uint32_t t = 0; t < nthreads; t++) {
+    pthread_join(th[t], NULL);
+    memcpy(visible_out + n, jobs[t].tmp, (size_t)jobs[t].count * 4);
+    n += jobs[t].count;
+  }
+  free(tmp);
+  free(th);
+  free(jobs);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cull_meshlets_hiz -- passes/cull_meshlets_hiz.slang:19-88
+ * ---------------------------------------------------------------------------------------- */
+uint32_t orc_cull_meshlets_hiz(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                               const orc_meshlet_instance* meshlet_instances, const orc_cull_camera* cam,
+                               uint32_t cull_flags, const orc_hiz* hiz, orc_visibility* vis, uint32_t* mask,
+                               uint32_t* visible_out, orc_margin_stats* stats) {
+  const int late = (cull_flags & ORC_LATE_PASS) != 0;
+  const int occl = (cull_flags & ORC_TEST_OCCLUSION) != 0;
+  const int occl_or_late = (cull_flags & (ORC_TEST_OCCLUSION | ORC_LATE_PASS)) != 0; /* HAS_FLAG is "any of" */
+  uint32_t emitted = 0;
+  /* late pass reads early_visible non-atomically after the early pass (:73) */
+  const uint32_t early_total = vis->early_visible_meshlet_instances;
+  for (uint32_t i = 0; i < vis->total_visible_meshlet_instances; i++) {
+    meshlet_eval ev;
+    int nr = 0;
+    eval_meshlet(meshes, transforms, mesh_instances, &meshlet_instances[i], cam, &ev, stats ? &nr : NULL);
+    uint32_t word = 0, bit = 0;
+    int was_visible = 1;
+    if (occl) { /* :45-51 */
+      word = ev.mask_index / 32u;
+      bit = 1u << (ev.mask_index - word * 32u);
+      was_visible = (mask[word] & bit) != 0;
+    }
+    int visible = late ? 1 : was_visible;
+    visible = visible && ev.cone_visible;
+    visible = visible && test_frustum_m(ev.mvp, ev.center, ev.extent, stats ? &nr : NULL);
+    if (occl_or_late && visible) { /* :61-65 */
+      float sa[6];
+      if (project_aabb_m(ev.mvp, cam->near_clip, ev.center, ev.extent, sa, stats ? &nr : NULL))
+        visible = !test_occlusion_m(sa, hiz, stats ? &nr : NULL);
+    }
+    if (visible && (!late || !was_visible)) { /* :67-79 */
+      uint32_t index;
+      if (!late)
+        index = vis->early_visible_meshlet_instances++;
+      else
+        index = (vis->late_visible_meshlet_instances++) + early_total;
+      visible_out[index] = i;
+      emitted++;
+    }
+    if (occl_or_late) { /* :81-87; word/bit are 0 when TestOcclusion is off (reference behaviour) */
+      if (visible)
+        mask[word] |= bit;
+      else
+        mask[word] &= ~bit;
+    }
+    if (stats && nr) stats->meshlets_near_threshold++;
+  }
+  return emitted;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cull_triangles -- passes/cull_triangles.slang:27-90, scene.slang:336-382,478-484,
+ * visbuffer.slang:13-14
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t micro_index(const uint32_t* buf, uint32_t byte_offset) { /* scene.slang:336-342 */
+  uint32_t pack = buf[byte_offset >> 2];
+  return (pack >> ((byte_offset & 3u) * 8u)) & 0xFFu;
+}
+
+uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                            const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                            uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats) {
+  uint32_t n = 0;
+  for (uint32_t s = 0; s < count; s++) {
+    uint32_t mli_index = visible[first + s];
+    const orc_meshlet_instance* mli = &meshlet_instances[mli_index];
+    const orc_mesh_instance* inst = &mesh_instances[mli->mesh_instance_index];
+    const orc_mesh* mesh = &meshes[inst->mesh_index];
+    const orc_mesh_lod* lod = &((const orc_mesh_lod*)(uintptr_t)mesh->lods)[inst->lod_index];
+    const orc_meshlet* ml = &((const orc_meshlet*)(uintptr_t)lod->meshlets)[mli->meshlet_index];
+    float mvp[16];
+    orc_mul_mat4(cam->projection_view, xform(transforms, inst->transform_index), mvp);
+    const uint32_t* micro = (const uint32_t*)(uintptr_t)lod->local_triangle_indices;
+    const uint32_t* vidx = (const uint32_t*)(uintptr_t)lod->indirect_vertex_indices;
+    const uint16_t* pos = (const uint16_t*)(uintptr_t)mesh->vertex_positions;
+    /* one thread per triangle; the kernel has 64 threads (defines.slang:9-11) */
+    uint32_t tcount = ml->triangle_count < 64u ? ml->triangle_count : 64u;
+    for (uint32_t t = 0; t < tcount; t++) {
+      float cp[12];
+      for (int k = 0; k < 3; k++) {
+        uint32_t li = micro_index(micro, ml->local_triangle_index_offset + t * 3u + (uint32_t)k);
+        uint32_t vi = vidx[ml->indirect_vertex_index_offset + li];
+        float p[3] = {orc_dequantize_half(pos[(size_t)vi * 4 + 0]), orc_dequantize_half(pos[(size_t)vi * 4 + 1]),
+                      orc_dequantize_half(pos[(size_t)vi * 4 + 2])};
+        mul_mp(mvp, p, &cp[k * 4]);
+      }
+      int nr = 0;
+      int passed = cp[2] >= 0.0f && cp[6] >= 0.0f && cp[10] >= 0.0f;
+      passed = passed && !backface_m(cp, stats ? &nr : NULL);
+      if (stats && nr) stats->triangles_near_threshold++;
+      if (passed) {
+        uint32_t base = mli_index << 8; /* MESHLET_PRIMITIVE_BITS = 8 */
+        out[n + 0] = base | ((t * 3u + 0u) & 0xFFu);
+        out[n + 1] = base | ((t * 3u + 1u) & 0xFFu);
+        out[n + 2] = base | ((t * 3u + 2u) & 0xFFu);
+        n += 3;
+      }
+    }
+  }
+  return n;
+}
+
+static void* mt_triangles(void* p) {
+  mt_job* j = (mt_job*)p;
+  j->count = orc_cull_triangles(j->meshes, j->transforms, j->mesh_instances, j->meshlet_instances, j->visible,
+                                j->first + j->begin, j->end - j->begin, j->cam, j->tmp, NULL);
+  return NULL;
+}
+
+uint32_t orc_cull_triangles_mt(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                               const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                               uint32_t count, const orc_cull_camera* cam, uint32_t* out, uint32_t nthreads) {
+  if (nthreads <= 1) return orc_cull_triangles(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, NULL);
+  mt_job* jobs = (mt_job*)calloc(nthreads, sizeof(mt_job));
+  pthread_t* th = (pthread_t*)calloc(nthreads, sizeof(pthread_t));
+  uint32_t* tmp = (uint32_t*)malloc((size_t)count * 192 * 4 + 4);
+  for (uint32_t t = 0; t < nthreads; t++) {
+    uint32_t b = (uint32_t)((uint64_t)count * t / nthreads), e = (uint32_t)((uint64_t)count * (t + 1) / nthreads);
+    jobs[t] = (mt_job){meshes, transforms, mesh_instances, meshlet_instances, visible, cam, b, e, first, tmp + (size_t)b * 192, 0};
+    pthread_create(&th[t], NULL, mt_triangles, &jobs[t]);
+  }
+  uint32_t n = 0;
+  for (uint32_t t = 0; t < nthreads; t++) {
+    pthread_join(th[t], NULL);
+    memcpy(out + n, jobs[t].tmp, (size_t)jobs[t].count * 4);
+    n += jobs[t].count;
+  }
+  free(tmp);
+  free(th);
+  free(jobs);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Config 1 harness: ECS transform update + host AABB frustum test.
+ * Scene.cpp:1690-1711 (T*R*S chained through parents), BoundingVolume.cpp:32-53
+ * (AABB::transform), :72-88 (is_on_or_forward_plane / is_on_frustum).
+ * trs10 per entity: translation xyz, quaternion wxyz, scale xyz.  parent[i] < i or -1.
+ * planes24: 6 planes {nx,ny,nz,distance} with unit normals (Frustum.hpp:7-18).
+ * ---------------------------------------------------------------------------------------- */
+static void trs_to_mat(const float* t, float* m) {
+  float qw = t[3], qx = t[4], qy = t[5], qz = t[6];
+  /* glm::mat4_cast */
+  float qxx = qx * qx, qyy = qy * qy, qzz = qz * qz, qxz = qx * qz, qxy = qx * qy, qyz = qy * qz, qwx = qw * qx,
+        qwy = qw * qy, qwz = qw * qz;
+  float r[9];
+  r[0] = 1.0f - 2.0f * (qyy + qzz);
+  r[1] = 2.0f * (qxy + qwz);
+  r[2] = 2.0f * (qxz - qwy);
+  r[3] = 2.0f * (qxy - qwz);
+  r[4] = 1.0f - 2.0f * (qxx + qzz);
+  r[5] = 2.0f * (qyz + qwx);
+  r[6] = 2.0f * (qxz + qwy);
+  r[7] = 2.0f * (qyz - qwx);
+  r[8] = 1.0f - 2.0f * (qxx + qyy);
+  for (int c = 0; c < 3; c++) {
+    for (int rr = 0; rr < 3; rr++) M(m, rr, c) = r[c * 3 + rr] * t[7 + c];
+    M(m, 3, c) = 0.0f;
+  }
+  M(m, 0, 3) = t[0];
+  M(m, 1, 3) = t[1];
+  M(m, 2, 3) = t[2];
+  M(m, 3, 3) = 1.0f;
+}
+
+uint32_t orc_entities_update_and_cull(uint32_t n, const float* trs10, const int32_t* parent, const float* aabb6,
+                                      const float* planes24, float* world_out, uint8_t* visible_out) {
+  uint32_t nvis = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    float local[16];
+    trs_to_mat(trs10 + (size_t)i * 10, local);
+    float* w = world_out + (size_t)i * 16;
+    if (parent[i] >= 0)
+      orc_mul_mat4(world_out + (size_t)parent[i] * 16, local, w);
+    else
+      memcpy(w, local, sizeof local);
+    const float* mn = aabb6 + (size_t)i * 6;
+    const float* mx = mn + 3;
+    float c[3] = {(mx[0] + mn[0]) * 0.5f, (mx[1] + mn[1]) * 0.5f, (mx[2] + mn[2]) * 0.5f};
+    float e[3] = {(mx[0] - mn[0]) * 0.5f, (mx[1] - mn[1]) * 0.5f, (mx[2] - mn[2]) * 0.5f};
+    float nc[4];
+    mul_mp(w, c, nc);
+    float ne[3];
+    for (int r = 0; r < 3; r++)
+      ne[r] = (fabsf(M(w, r, 0)) * e[0] + fabsf(M(w, r, 1)) * e[1]) + fabsf(M(w, r, 2)) * e[2];
+    int vis = 1;
+    for (int p = 0; p < 6 && vis; p++) {
+      const float* pl = planes24 + p * 4;
+      float rr = (ne[0] * fabsf(pl[0]) + ne[1] * fabsf(pl[1])) + ne[2] * fabsf(pl[2]);
+      float dist = dot3(pl, nc) - pl[3];
+      vis = -rr <= dist;
+    }
+    visible_out[i] = (uint8_t)vis;
+    nvis += (uint32_t)vis;
+  }
+  return nvis;
+}

@@ -1,0 +1,190 @@
+/*
+ * oxcull_oracle.h -- CPU oracle for the Oxylus meshlet visibility pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (oxylus_amd/, include/) may
+ * include, link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference (oxylusengine/Oxylus) ships no golden vectors, KATs or
+ * tests for this path and its Slang->SPIR-V->Vulkan path cannot
+ * be built or run in this image (no slangc, no Vulkan ICD, no xmake, un-vendored vuk/glm).
+ * This file is therefore a restatement of the reference shaders' arithmetic with a fixed
+ * canonical IEEE-754 binary32 evaluation order: round-to-nearest,
+ * no FMA contraction (compile with -ffp-contract=off), left-to-right dot / mat*vec,
+ * correctly rounded sqrt and divide.  Output lists are emitted in ascending order (the
+ * reference's order is atomic-race dependent; compare as sorted sets against it).
+ *
+ * All struct layouts are the reference's GPU layouts (scalar layout, little endian):
+ * Oxylus/include/Scene/SceneGPU.hpp:84-152,222-229.
+ */
+#ifndef OXCULL_ORACLE_H
+#define OXCULL_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Oxylus/include/Scene/SceneGPU.hpp:84-90 */
+typedef struct {
+  uint16_t aabb_center[3];
+  int8_t cone_axis_xy[2];
+  uint16_t aabb_extent[3];
+  int8_t cone_axis_z;
+  int8_t cone_cutoff;
+} orc_meshlet_bounds; /* 16 B */
+
+/* SceneGPU.hpp:105-108 */
+typedef struct {
+  uint32_t mesh_instance_index;
+  uint32_t meshlet_index;
+} orc_meshlet_instance; /* 8 B */
+
+/* SceneGPU.hpp:110-116 */
+typedef struct {
+  uint32_t mesh_index;
+  uint32_t lod_index;
+  uint32_t material_index;
+  uint32_t transform_index;
+  uint32_t meshlet_instance_visibility_offset;
+} orc_mesh_instance; /* 20 B */
+
+/* SceneGPU.hpp:118-123 */
+typedef struct {
+  uint32_t indirect_vertex_index_offset;
+  uint32_t local_triangle_index_offset; /* BYTE offset into the u8 stream */
+  uint32_t vertex_count;
+  uint32_t triangle_count;
+} orc_meshlet; /* 16 B */
+
+/* SceneGPU.hpp:125-139 (pointers are addresses valid in the caller's address space) */
+typedef struct {
+  uint64_t indices;
+  uint64_t meshlets;
+  uint64_t meshlet_bounds;
+  uint64_t local_triangle_indices;
+  uint64_t indirect_vertex_indices;
+  uint32_t indices_count;
+  uint32_t meshlet_count;
+  uint32_t meshlet_bounds_count;
+  uint32_t local_triangle_indices_count;
+  uint32_t indirect_vertex_indices_count;
+  float error;
+} orc_mesh_lod; /* 64 B */
+
+/* SceneGPU.hpp:141-152 */
+typedef struct {
+  uint64_t vertex_positions; /* u16x4, stride 8 */
+  uint64_t vertex_normals;
+  uint64_t texture_coords;
+  uint32_t vertex_count;
+  uint32_t lod_count;
+  uint64_t lods;
+  float aabb_center[3];
+  float aabb_extent[3];
+} orc_mesh; /* 64 B */
+
+/* SceneGPU.hpp:222-229 -- 96 B push constant */
+typedef struct {
+  float projection_view[16]; /* column-major: element (r,c) at [c*4+r] */
+  float position[3];
+  float acceptable_lod_error;
+  float resolution[2];
+  float near_clip;
+  uint32_t mesh_instance_count;
+} orc_cull_camera;
+
+/* SceneGPU.hpp:97-104 */
+typedef struct {
+  uint32_t total_visible_meshlet_instances;
+  uint32_t early_visible_meshlet_instances;
+  uint32_t late_visible_meshlet_instances;
+} orc_visibility;
+
+/* Linear R32F mip chain standing in for the vuk ImageAttachment. */
+typedef struct {
+  const float* data;
+  uint32_t width, height, levels;
+  uint64_t level_offset[13]; /* in floats */
+} orc_hiz;
+
+enum {
+  ORC_TEST_FRUSTUM = 1u, /* SceneGPU.hpp:345-353 */
+  ORC_SELECT_LOD = 2u,
+  ORC_TEST_OCCLUSION = 4u,
+  ORC_LATE_PASS = 8u,
+  ORC_TEST_ALL = 7u
+};
+
+/* Decision-margin statistics ("boundary set"): elements with at least one
+ * comparison whose two sides are within 4 ulp of each other. */
+typedef struct {
+  uint64_t meshlets_near_threshold;
+  uint64_t triangles_near_threshold;
+} orc_margin_stats;
+
+/* ---- scalar functions (cull.slang, common/math.slang, scene.slang) ---- */
+float orc_dequantize_half(uint16_t h);
+void orc_mul_mat4(const float* a, const float* b, float* out);
+int orc_test_frustum(const float* mvp, const float* center, const float* extent);
+int orc_test_cone(const float* center, float radius, const float* axis, float cutoff, const float* cam);
+int orc_project_aabb(const float* mvp, float near_clip, const float* center, const float* extent, float* out6);
+int orc_test_occlusion(const float* screen_aabb6, const orc_hiz* hiz);
+uint32_t orc_occlusion_mip(const float* screen_aabb6, const orc_hiz* hiz);
+float orc_sample_level_min_reduction_2x2(const orc_hiz* hiz, float u, float v, uint32_t mip);
+int orc_test_triangle_backface(const float* clip3x4);
+void orc_normal_matrix(const float* world, float* out9);
+float orc_to_world_radius(const float* world, float radius);
+void orc_decode_bounds(const orc_meshlet_bounds* b, float* center, float* extent, float* axis, float* cutoff);
+
+/* ---- kernels ---- */
+/* passes/hiz.slang + Passes/CullGeometry.cpp:10-59.  hiz->data is written. */
+void orc_generate_hiz(const float* depth, uint32_t depth_w, uint32_t depth_h, orc_hiz* hiz);
+
+/* passes/cull_meshes.slang:17-85.  Deterministic: instances expanded in ascending
+ * mesh-instance order.  Returns total meshlet instances; writes lod_index. */
+uint32_t orc_cull_meshes(const orc_mesh* meshes, const float* transforms, orc_mesh_instance* mesh_instances,
+                         const orc_cull_camera* cam, uint32_t cull_flags, orc_meshlet_instance* meshlet_instances_out,
+                         uint32_t* cull_meshlets_cmd3);
+
+/* passes/cull_meshlets.slang:23-73 on [begin,end).  Appends to out (ascending). Returns count. */
+uint32_t orc_cull_meshlets(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                           const orc_meshlet_instance* meshlet_instances, uint32_t begin, uint32_t end,
+                           const orc_cull_camera* cam, uint32_t* visible_out, orc_margin_stats* stats);
+
+/* Same, split over nthreads contiguous ranges (pthread); output concatenated in order. */
+uint32_t orc_cull_meshlets_mt(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                              const orc_meshlet_instance* meshlet_instances, uint32_t total,
+                              const orc_cull_camera* cam, uint32_t* visible_out, uint32_t nthreads);
+
+/* passes/cull_meshlets_hiz.slang:19-88.  vis->early/late updated, mask updated in place,
+ * visible_out written at [0,early) (early pass) or [early, early+late) (late pass).
+ * Returns number emitted by this pass (= cull_triangles_cmd.x). */
+uint32_t orc_cull_meshlets_hiz(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                               const orc_meshlet_instance* meshlet_instances, const orc_cull_camera* cam,
+                               uint32_t cull_flags, const orc_hiz* hiz, orc_visibility* vis, uint32_t* mask,
+                               uint32_t* visible_out, orc_margin_stats* stats);
+
+/* passes/cull_triangles.slang:27-90 over `count` visible slots starting at slot `first`.
+ * Returns index_count (3 * passing triangles); reordered_out gets packed indices,
+ * meshlets in slot order, triangles ascending within a meshlet. */
+uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                            const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                            uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out,
+                            orc_margin_stats* stats);
+
+uint32_t orc_cull_triangles_mt(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                               const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                               uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out, uint32_t nthreads);
+
+/* Config 1 harness: Scene.cpp:1690-1740 world-matrix chain + BoundingVolume.cpp:32-88. */
+uint32_t orc_entities_update_and_cull(uint32_t n, const float* trs10 /* t3 q4 s3 */, const int32_t* parent,
+                                      const float* aabb_min_max6, const float* frustum_planes24, float* world_out16,
+                                      uint8_t* visible_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

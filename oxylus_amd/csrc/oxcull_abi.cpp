@@ -1,0 +1,394 @@
+// oxcull_abi.cpp -- host side of liboxcull.so: the C ABI declared in include/oxcull.h.
+//
+// Mirrors what RendererInstance::generate_hiz / ::cull_geometry do on the host in the reference
+// (Oxylus/src/Render/Passes/CullGeometry.cpp): pick the pipeline variant from the context flags,
+// hand out freshly initialised counter buffers, and enqueue the passes in order.  Where the
+// reference records vuk passes that run at end_frame, this enqueues HIP kernels on the caller's
+// stream; nothing here synchronises except scratch growth and oxc_read_counters.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "oxcull.h"
+#include "oxcull_kernels.hpp"
+#include "oxcull_types.hpp"
+
+using namespace oxc;
+
+namespace {
+constexpr uint32_t kSlots = 1024;  // counter-slot ring; pointers stay valid for kSlots calls
+constexpr uint32_t kMaxPackedInstances = 1u << 24;  // MESHLET_INSTANCE_ID_BITS, visbuffer.slang:9-10
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+struct oxc_ctx {
+  int device = 0;
+  uint32_t num_cus = 256;
+  std::string last_error;
+  // scratch arena
+  void* arena = nullptr;
+  uint64_t arena_bytes = 0;
+  uint32_t cap_mesh_instances = 0, cap_meshlets = 0;
+  InstCache* cache = nullptr;
+  uint32_t* mesh_counts = nullptr;
+  uint32_t* mesh_offsets = nullptr;
+  uint64_t* bits = nullptr;
+  uint32_t* m_chunk_counts = nullptr;
+  uint32_t* m_supers = nullptr;
+  uint64_t* tri_masks = nullptr;
+  uint32_t* t_chunk_counts = nullptr;
+  uint32_t* t_supers = nullptr;
+  // counter slots
+  uint32_t* slots = nullptr;
+  uint32_t slot_cursor = 0;
+  uint32_t* sink = nullptr;
+};
+
+namespace {
+
+oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hipSuccess) {
+  if (ctx) {
+    ctx->last_error = what;
+    if (e != hipSuccess) {
+      ctx->last_error += ": ";
+      ctx->last_error += hipGetErrorString(e);
+    }
+  }
+  return st;
+}
+
+#define OXC_HIP(ctx, expr)                                        \
+  do {                                                            \
+    hipError_t _e = (expr);                                       \
+    if (_e != hipSuccess) return fail(ctx, OXC_HIP_ERROR, #expr, _e); \
+  } while (0)
+
+oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets) {
+  if (mesh_instances <= ctx->cap_mesh_instances && meshlets <= ctx->cap_meshlets && ctx->arena) return OXC_OK;
+  uint32_t M = std::max(std::max(mesh_instances, ctx->cap_mesh_instances), 1u);
+  uint32_t N = std::max(std::max(meshlets, ctx->cap_meshlets), 1u);
+  const uint32_t m_chunks = cdiv(N, kMeshletChunk), t_chunks = cdiv(N, kTriChunk);
+  uint64_t off = 0;
+  auto carve = [&](uint64_t bytes) {
+    uint64_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const uint64_t o_cache = carve((uint64_t)M * sizeof(InstCache));
+  const uint64_t o_counts = carve((uint64_t)M * 4);
+  const uint64_t o_offsets = carve((uint64_t)M * 4);
+  const uint64_t o_bits = carve((uint64_t)cdiv(N, 64) * 8);
+  const uint64_t o_mcc = carve((uint64_t)m_chunks * 4);
+  const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
+  const uint64_t o_tm = carve((uint64_t)N * 8);
+  const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
+  const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4);
+  OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old arena
+  if (ctx->arena) OXC_HIP(ctx, hipFree(ctx->arena));
+  ctx->arena = nullptr;
+  hipError_t e = hipMalloc(&ctx->arena, off);
+  if (e != hipSuccess) {
+    ctx->cap_mesh_instances = ctx->cap_meshlets = 0;
+    return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(scratch arena)", e);
+  }
+  ctx->arena_bytes = off;
+  char* b = static_cast<char*>(ctx->arena);
+  ctx->cache = reinterpret_cast<InstCache*>(b + o_cache);
+  ctx->mesh_counts = reinterpret_cast<uint32_t*>(b + o_counts);
+  ctx->mesh_offsets = reinterpret_cast<uint32_t*>(b + o_offsets);
+  ctx->bits = reinterpret_cast<uint64_t*>(b + o_bits);
+  ctx->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
+  ctx->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
+  ctx->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
+  ctx->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
+  ctx->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
+  ctx->cap_mesh_instances = M;
+  ctx->cap_meshlets = N;
+  return OXC_OK;
+}
+
+uint32_t* next_slot(oxc_ctx* ctx) {
+  uint32_t* s = ctx->slots + (size_t)(ctx->slot_cursor % kSlots) * SLOT_U32S;
+  ctx->slot_cursor++;
+  return s;
+}
+
+bool image_ok(const oxc_image& im) { return im.dptr && im.width && im.height && im.levels >= 1 && im.levels <= 13; }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t oxc_abi_version(void) { return OXC_ABI_VERSION; }
+
+oxc_status oxc_create(int device, oxc_ctx** out) {
+  if (!out) return OXC_INVALID_ARG;
+  *out = nullptr;
+  oxc_ctx* ctx = new (std::nothrow) oxc_ctx();
+  if (!ctx) return OXC_OUT_OF_MEMORY;
+  ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    delete ctx;
+    return OXC_HIP_ERROR;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+  e = hipMalloc(reinterpret_cast<void**>(&ctx->slots), (size_t)kSlots * SLOT_U32S * 4 + 256);
+  if (e != hipSuccess) {
+    delete ctx;
+    return OXC_OUT_OF_MEMORY;
+  }
+  (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
+  ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
+  *out = ctx;
+  return OXC_OK;
+}
+
+void oxc_destroy(oxc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->slots) (void)hipFree(ctx->slots);
+  delete ctx;
+}
+
+const char* oxc_last_error(const oxc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+oxc_status oxc_reserve(oxc_ctx* ctx, uint32_t max_mesh_instances, uint32_t max_meshlet_instances) {
+  if (!ctx) return OXC_INVALID_ARG;
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  return ensure_capacity(ctx, max_mesh_instances, max_meshlet_instances);
+}
+
+oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* c, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!c || c->struct_size != sizeof(oxc_main_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: bad context struct");
+  const oxc_image& d = c->depth_attachment;
+  const oxc_image& h = c->hiz_attachment;
+  if (!d.dptr || !d.width || !d.height) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: depth_attachment missing");
+  if (!image_ok(h)) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: hiz_attachment missing or levels not in 1..13");
+  if (h.width > 4096 || h.height > 4096) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: hiz extent > 4096 (13 mips) unsupported");
+  HizArgs a;
+  a.depth = reinterpret_cast<const float*>(static_cast<const char*>(d.dptr) + d.level_offset[0]);
+  a.hiz = static_cast<float*>(h.dptr);
+  a.dw = d.width;
+  a.dh = d.height;
+  a.w = h.width;
+  a.h = h.height;
+  a.levels = std::min(h.levels, 13u);  // CullGeometry.cpp:24
+  for (uint32_t k = 0; k < 13; k++) {
+    if (k < a.levels && (h.level_offset[k] & 3u)) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: level offset not 4-byte aligned");
+    a.level_off[k] = k < a.levels ? (uint32_t)(h.level_offset[k] / 4) : 0u;
+  }
+  const bool tiled = (a.w % 64 == 0) && (a.h % 64 == 0);
+  if (!tiled && (uint64_t)a.w * a.h > 4096) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: extent must be a multiple of 64 or <= 4096 texels");
+  if (tiled && (h.level_offset[0] & 15u)) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: mip 0 must be 16-byte aligned");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  launch_hiz(a, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c, uint32_t total, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "seed: bad context struct");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t* slot = next_slot(ctx);
+  launch_seed_slot(slot, total, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  c->visibility_buffer = {slot + SLOT_VIS, 12};
+  c->cull_meshlets_cmd_buffer = {slot + SLOT_MESHLETS_CMD, 12};
+  return OXC_OK;
+}
+
+oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull_geometry_context* c, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!f || !c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: bad frame/context struct");
+  if (c->use_hpb) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb (cull_meshlets_hpb) is not implemented");
+  const uint32_t stages = c->stages ? c->stages : (uint32_t)OXC_STAGE_ALL;
+  const uint32_t M = f->mesh_instance_count, N = f->max_meshlet_instance_count;
+  const bool do_meshes = c->init_cull_meshes && (stages & OXC_STAGE_MESHES);
+  const bool do_meshlets = (stages & OXC_STAGE_MESHLETS) != 0;
+  const bool do_tris = (stages & OXC_STAGE_TRIANGLES) != 0;
+  if (c->cull_camera.mesh_instance_count != M) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: cull_camera.mesh_instance_count != frame.mesh_instance_count");
+  if (M && (!f->meshes_buffer.dptr || !f->transforms_world_buffer.dptr || !f->mesh_instances_buffer.dptr))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshes/transforms/mesh_instances buffer missing");
+  if (f->mesh_instances_buffer.bytes < (uint64_t)M * sizeof(GpuMeshInstance)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: mesh_instances_buffer too small");
+  if (N && (!f->meshlet_instances_buffer.dptr || f->meshlet_instances_buffer.bytes < (uint64_t)N * 8))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshlet_instances_buffer missing or < 8*N bytes");
+  if (do_meshlets && N && (!f->visible_meshlet_instances_indices_buffer.dptr || f->visible_meshlet_instances_indices_buffer.bytes < (uint64_t)N * 4))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visible_meshlet_instances_indices_buffer missing or < 4*N bytes");
+  if (do_tris && N) {
+    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * 64 * 3 * 4)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes");
+    if (N > kMaxPackedInstances) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: > 2^24 meshlet instances do not fit the packed index (visbuffer.slang:9-14)");
+  }
+  const bool occl = (c->cull_flags & OXC_CULL_TEST_OCCLUSION) != 0;
+  const bool late = (c->cull_flags & OXC_CULL_LATE_PASS) != 0;
+  if (c->use_hiz && do_meshlets) {
+    if (!image_ok(c->hiz_attachment)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz without a hiz_attachment");
+    if (occl && N && (!f->meshlet_instance_visibility_mask_buffer.dptr))
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing");
+  }
+  if (!c->init_cull_meshes && (!c->visibility_buffer.dptr || !c->cull_meshlets_cmd_buffer.dptr))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: init_cull_meshes=false needs the visibility/cull_meshlets_cmd buffers of the sequence");
+
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  oxc_status st = ensure_capacity(ctx, M, N);
+  if (st != OXC_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+
+  uint32_t* slot = next_slot(ctx);
+  uint32_t* vis;
+  uint32_t* meshlets_cmd;
+  if (c->init_cull_meshes) {
+    vis = slot + SLOT_VIS;
+    meshlets_cmd = slot + SLOT_MESHLETS_CMD;
+    c->visibility_buffer = {vis, 12};
+    c->cull_meshlets_cmd_buffer = {meshlets_cmd, 12};
+  } else {
+    vis = static_cast<uint32_t*>(c->visibility_buffer.dptr);
+    meshlets_cmd = static_cast<uint32_t*>(c->cull_meshlets_cmd_buffer.dptr);
+  }
+  uint32_t* tri_cmd = slot + SLOT_TRI_CMD;
+  uint32_t* draw_cmd = slot + SLOT_DRAW_CMD;
+  c->cull_triangles_cmd_buffer = {tri_cmd, 12};
+  c->draw_geometry_cmd_buffer = {draw_cmd, 20};
+
+  const uint32_t max_grid = ctx->num_cus * 8;
+  const uint32_t m_chunks = cdiv(std::max(N, 1u), kMeshletChunk), t_chunks = cdiv(std::max(N, 1u), kTriChunk);
+
+  // --- prepare (+ cull_meshes test): CullGeometry.cpp:69-117
+  PrepareArgs pa;
+  pa.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
+  pa.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
+  pa.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
+  pa.cache = ctx->cache;
+  pa.mesh_counts = ctx->mesh_counts;
+  pa.slot = slot;
+  pa.vis = vis;
+  pa.meshlets_cmd = meshlets_cmd;
+  pa.supers_meshlets = ctx->m_supers;
+  pa.supers_tris = ctx->t_supers;
+  pa.n_supers_meshlets = cdiv(m_chunks, kChunksPerSuper);
+  pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
+  pa.mesh_instance_count = M;
+  pa.cull_flags = c->cull_flags;
+  pa.do_cull_meshes = do_meshes ? 1u : 0u;
+  pa.init_vis = c->init_cull_meshes ? 1u : 0u;
+  pa.seed_total = 0;
+  pa.cam = c->cull_camera;
+  const uint32_t prep_threads = std::max(std::max(M, pa.n_supers_tris), 1u);
+  launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), s);
+  if (do_meshes) {
+    launch_scan_mesh_counts(ctx->mesh_counts, ctx->mesh_offsets, M, vis, meshlets_cmd, s);
+    launch_expand(ctx->mesh_counts, ctx->mesh_offsets, M, f->meshlet_instances_buffer.dptr, std::max(std::min(cdiv(M, 4), max_grid), 1u), s);
+  }
+
+  // --- meshlet stage: CullGeometry.cpp:129-335
+  if (do_meshlets) {
+    MeshletTestArgs ta;
+    std::memset(&ta, 0, sizeof ta);
+    ta.cache = ctx->cache;
+    ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
+    ta.vis = vis;
+    ta.mask = static_cast<uint32_t*>(f->meshlet_instance_visibility_mask_buffer.dptr);
+    ta.bits = ctx->bits;
+    ta.chunk_counts = ctx->m_chunk_counts;
+    ta.supers = ctx->m_supers;
+    if (c->use_hiz) {
+      const oxc_image& h = c->hiz_attachment;
+      ta.hiz_data = static_cast<const float*>(h.dptr);
+      ta.hiz_w = h.width;
+      ta.hiz_h = h.height;
+      ta.hiz_levels = h.levels;
+      for (uint32_t k = 0; k < h.levels && k < 13; k++) ta.hiz_level_off[k] = (uint32_t)(h.level_offset[k] / 4);
+    }
+    ta.near_clip = c->cull_camera.near_clip;
+    std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
+    launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
+    MeshletEmitArgs ea;
+    ea.bits = ctx->bits;
+    ea.chunk_counts = ctx->m_chunk_counts;
+    ea.supers = ctx->m_supers;
+    ea.vis = vis;
+    ea.tri_cmd = tri_cmd;
+    ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
+  }
+
+  // --- triangle stage: CullGeometry.cpp:337-403
+  if (do_tris) {
+    TriTestArgs tt;
+    tt.cache = ctx->cache;
+    tt.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
+    tt.visible = static_cast<const uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    tt.vis = vis;
+    tt.tri_cmd = tri_cmd;
+    tt.tri_masks = ctx->tri_masks;
+    tt.chunk_counts = ctx->t_chunk_counts;
+    tt.supers = ctx->t_supers;
+    launch_tris_test(tt, late, std::min(t_chunks, max_grid), s);
+    TriEmitArgs te;
+    te.tri_masks = ctx->tri_masks;
+    te.visible = tt.visible;
+    te.vis = vis;
+    te.tri_cmd = tri_cmd;
+    te.chunk_counts = ctx->t_chunk_counts;
+    te.supers = ctx->t_supers;
+    te.draw_cmd = draw_cmd;
+    te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
+    launch_tris_emit(te, late, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
+  }
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, oxc_counters* out, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!c || !out) return fail(ctx, OXC_INVALID_ARG, "read_counters: null argument");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  uint32_t vis[3] = {0, 0, 0}, mc[3] = {0, 0, 0}, tc[3] = {0, 0, 0}, dc[5] = {0, 0, 0, 0, 0};
+  if (c->visibility_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(vis, c->visibility_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
+  if (c->cull_meshlets_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(mc, c->cull_meshlets_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
+  if (c->cull_triangles_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(tc, c->cull_triangles_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
+  if (c->draw_geometry_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(dc, c->draw_geometry_cmd_buffer.dptr, 20, hipMemcpyDeviceToHost, s));
+  OXC_HIP(ctx, hipStreamSynchronize(s));
+  out->total_visible_meshlet_instances = vis[0];
+  out->early_visible_meshlet_instances = vis[1];
+  out->late_visible_meshlet_instances = vis[2];
+  out->cull_meshlets_cmd_x = mc[0];
+  out->cull_triangles_cmd_x = tc[0];
+  out->draw_index_count = dc[0];
+  return OXC_OK;
+}
+
+oxc_status oxc_stream_read_probe(oxc_ctx* ctx, const void* dptr, uint64_t bytes, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!dptr || (reinterpret_cast<uintptr_t>(dptr) & 15u)) return fail(ctx, OXC_INVALID_ARG, "stream_read_probe: pointer must be 16-byte aligned");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  launch_stream_read(dptr, bytes, ctx->sink, ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_debug_decode_bounds(oxc_ctx* ctx, const void* bounds_dptr, uint32_t n, float* out10_dptr, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!bounds_dptr || !out10_dptr) return fail(ctx, OXC_INVALID_ARG, "debug_decode_bounds: null pointer");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n) launch_debug_decode_bounds(bounds_dptr, n, out10_dptr, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+}  // extern "C"

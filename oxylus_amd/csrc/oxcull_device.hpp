@@ -1,0 +1,252 @@
+// oxcull_device.hpp -- device-side arithmetic of the cull path, written for gfx950.
+//
+// This restates the reference shaders' arithmetic (Oxylus/src/Render/Shaders/cull.slang,
+// scene.slang, common/math.slang) with the canonical IEEE-754 binary32 evaluation order of
+// no FMA contraction (the TU is compiled with -ffp-contract=off and
+// carries the pragma below), left-to-right dot / mat*vec, correctly rounded sqrt and divide
+// (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt).  It is written independently of
+// oracle/ (which is test infrastructure) -- the two must agree bit for bit, and the GPU parity
+// tests check exactly that.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#pragma clang fp contract(off)
+
+namespace oxc {
+
+#define OXC_DEV __device__ __forceinline__
+
+OXC_DEV float asf(uint32_t u) { return __builtin_bit_cast(float, u); }
+OXC_DEV uint32_t asu(float f) { return __builtin_bit_cast(uint32_t, f); }
+OXC_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+OXC_DEV uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+OXC_DEV float readlane_f(uint32_t v, int l) { return asf(readlane_u(v, l)); }
+OXC_DEV uint32_t readfirst_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+OXC_DEV float bperm_f(int src_lane, float v) {
+  return asf((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)asu(v)));
+}
+
+OXC_DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx + ay * by) + az * bz; }
+OXC_DEV float len3(float x, float y, float z) { return __builtin_sqrtf(dot3(x, y, z, x, y, z)); }
+
+// com::dequantize_half, common/math.slang:193-201 (h in the low 16 bits): denormals flush to
+// signed zero, Inf/NaN keep class and payload.
+OXC_DEV float dequantize_half(uint32_t h) {
+  uint32_t s = (h & 0x8000u) << 16;
+  int32_t em = (int32_t)(h & 0x7fffu);
+  int32_t r = (em + (112 << 10)) << 13;
+  r = (em < (1 << 10)) ? 0 : r;
+  r += (em >= (31 << 10)) ? (112 << 23) : 0;
+  return asf(s | (uint32_t)r);
+}
+
+// i32(s8) / 127.0 (scene.slang:408-418), correctly rounded.  x * (1/127) alone is wrong for 16
+// of the 256 inputs; one Markstein refinement step is exact for all 256 (checked exhaustively
+// on the CPU and by tests/test_gpu_kat.py on the device) and costs 3 VALU ops instead of a
+// ~14-op IEEE division.
+OXC_DEV float s8_over_127(int32_t x) {
+  const float r = 1.0f / 127.0f;
+  float xf = (float)x;
+  float q = xf * r;
+  float e = __builtin_fmaf(-q, 127.0f, xf);
+  return __builtin_fmaf(e, r, q);
+}
+
+// float -> u32 / i32 with v_cvt semantics (saturating, NaN -> 0), spelled out so that the
+// C++ conversion is never undefined.
+OXC_DEV uint32_t cvt_u32_sat(float f) {
+  if (!(f > 0.0f)) return 0u;
+  if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+  return (uint32_t)f;
+}
+OXC_DEV int32_t cvt_i32_sat(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (int32_t)0x80000000;
+  return (int32_t)f;
+}
+
+// Column-major 4x4 helpers: element (r,c) = m[c*4+r].
+#define OXC_M(m, r, c) ((m)[(c)*4 + (r)])
+
+OXC_DEV void mul_mat4(const float* a, const float* b, float* out) {
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      OXC_M(out, r, c) = ((OXC_M(a, r, 0) * OXC_M(b, 0, c) + OXC_M(a, r, 1) * OXC_M(b, 1, c)) + OXC_M(a, r, 2) * OXC_M(b, 2, c)) +
+                         OXC_M(a, r, 3) * OXC_M(b, 3, c);
+}
+
+// cull.slang:49-71: the six normalised planes of mvp, in the shader's order.
+OXC_DEV void frustum_planes(const float* mvp, float* pl /*24*/) {
+  float r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    r0[c] = OXC_M(mvp, 0, c);
+    r1[c] = OXC_M(mvp, 1, c);
+    r2[c] = OXC_M(mvp, 2, c);
+    r3[c] = OXC_M(mvp, 3, c);
+  }
+  float t[6][4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    t[0][c] = r3[c] + r0[c];
+    t[1][c] = r3[c] - r0[c];
+    t[2][c] = r3[c] + r1[c];
+    t[3][c] = r3[c] - r1[c];
+    t[4][c] = r2[c];
+    t[5][c] = r3[c] - r2[c];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float l = len3(t[i][0], t[i][1], t[i][2]);
+#pragma unroll
+    for (int c = 0; c < 4; c++) pl[i * 4 + c] = t[i][c] / l;
+  }
+}
+
+// cull.slang:73-83 with pre-normalised planes.
+OXC_DEV bool test_frustum_planes(const float* pl, float cx, float cy, float cz, float ex, float ey, float ez) {
+  float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
+  bool inside = true;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float nx = pl[i * 4 + 0], ny = pl[i * 4 + 1], nz = pl[i * 4 + 2], nw = pl[i * 4 + 3];
+    float qx = cx + asf(asu(hx) ^ (asu(nx) & 0x80000000u));
+    float qy = cy + asf(asu(hy) ^ (asu(ny) & 0x80000000u));
+    float qz = cz + asf(asu(hz) ^ (asu(nz) & 0x80000000u));
+    inside = inside && !(dot3(qx, qy, qz, nx, ny, nz) <= -nw);
+  }
+  return inside;
+}
+
+// scene.slang:292-299: cofactor matrix of world's upper 3x3, column-major 3x3 out.
+OXC_DEV void normal_matrix(const float* w, float* nm) {
+  float b[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) b[j][k] = OXC_M(w, k, j);
+  const int a1[3] = {1, 2, 0}, a2[3] = {2, 0, 1};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float* u = b[a1[k]];
+    const float* v = b[a2[k]];
+    nm[k * 3 + 0] = u[1] * v[2] - v[1] * u[2];
+    nm[k * 3 + 1] = u[2] * v[0] - v[2] * u[0];
+    nm[k * 3 + 2] = u[0] * v[1] - v[0] * u[1];
+  }
+}
+
+// cull_meshlets.slang:49-52 + cull.slang:173-175.  Returns cone_visible.
+// world: rows 0..2 (world[r*4+c]); nm column-major 3x3.
+OXC_DEV bool cone_visible(const float* world, const float* nm, float scale_max, float camx, float camy, float camz,
+                          float cx, float cy, float cz, float ex, float ey, float ez, float ax, float ay, float az,
+                          float cutoff) {
+  float nx = (nm[0] * ax + nm[3] * ay) + nm[6] * az;
+  float ny = (nm[1] * ax + nm[4] * ay) + nm[7] * az;
+  float nz = (nm[2] * ax + nm[5] * ay) + nm[8] * az;
+  float l = len3(nx, ny, nz);
+  float kx = nx / l, ky = ny / l, kz = nz / l;
+  float wx = ((world[0] * cx + world[1] * cy) + world[2] * cz) + world[3];
+  float wy = ((world[4] * cx + world[5] * cy) + world[6] * cz) + world[7];
+  float wz = ((world[8] * cx + world[9] * cy) + world[10] * cz) + world[11];
+  float radius = len3(ex * 0.5f, ey * 0.5f, ez * 0.5f) * scale_max;
+  float dx = wx - camx, dy = wy - camy, dz = wz - camz;
+  bool culled = dot3(dx, dy, dz, kx, ky, kz) >= cutoff * len3(dx, dy, dz) + radius;
+  return cutoff >= 1.0f || !culled;
+}
+
+struct HizView {
+  const float* data;
+  uint32_t width, height, levels;
+};
+
+OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
+  uint32_t v = d >> mip;
+  return v ? v : 1u;
+}
+
+// cull.slang:12-47 + :86-135.  Returns true when the box is occluded; `projected` false when
+// project_aabb returned none (box crosses the near plane) -- the caller keeps it visible.
+// level_off: float offsets of each mip (LDS or global).
+OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez,
+                           const HizView& hiz, const uint32_t* level_off) {
+  float SX[4], SY[4], SZ[4], P[8][4];
+  float p0x = cx - ex * 0.5f, p0y = cy - ey * 0.5f, p0z = cz - ez * 0.5f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    SX[i] = OXC_M(mvp, i, 0) * ex;
+    SY[i] = OXC_M(mvp, i, 1) * ey;
+    SZ[i] = OXC_M(mvp, i, 2) * ez;
+    P[0][i] = ((OXC_M(mvp, i, 0) * p0x + OXC_M(mvp, i, 1) * p0y) + OXC_M(mvp, i, 2) * p0z) + OXC_M(mvp, i, 3);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    P[1][i] = P[0][i] + SZ[i];
+    P[2][i] = P[0][i] + SY[i];
+    P[3][i] = P[2][i] + SZ[i];
+    P[4][i] = P[0][i] + SX[i];
+    P[5][i] = P[4][i] + SZ[i];
+    P[6][i] = P[4][i] + SY[i];
+    P[7][i] = P[6][i] + SZ[i];
+  }
+  float depth = P[7][3];
+#pragma unroll
+  for (int k = 6; k >= 0; k--) depth = fminf(P[k][3], depth);
+  if (depth < near_clip) return false;  // none -> stays visible (cull_meshlets_hiz.slang:61-65)
+
+  float vmin[3], vmax[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float lo = P[7][j] / P[7][3];
+    float hi = lo;
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+      float d = P[k][j] / P[k][3];
+      lo = fminf(d, lo);
+      hi = fmaxf(d, hi);
+    }
+    vmin[j] = lo;
+    vmax[j] = hi;
+  }
+  float minu = vmin[0] * 0.5f + 0.5f, minv = vmin[1] * 0.5f + 0.5f;
+  float maxu = vmax[0] * 0.5f + 0.5f, maxv = vmax[1] * 0.5f + 0.5f;
+  float maxz = vmax[2];
+
+  // test_occlusion, cull.slang:114-135
+  float sw = (float)hiz.width, sh = (float)hiz.height;
+  uint32_t minx = cvt_u32_sat(fmaxf(minu * sw, 0.0f));
+  uint32_t miny = cvt_u32_sat(fmaxf(minv * sh, 0.0f));
+  uint32_t maxx = cvt_u32_sat(fminf(maxu * sw, sw - 1.0f));
+  uint32_t maxy = cvt_u32_sat(fminf(maxv * sh, sh - 1.0f));
+  uint32_t szx = maxx - minx, szy = maxy - miny;  // u32 wrap-around (cull.slang:127)
+  uint32_t ms = szx > szy ? szx : szy;
+  // ceil(log2(float(ms))) in integers, clamped to [0, levels-1]
+  uint32_t mip = ms <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(ms - 1u);
+  uint32_t top = hiz.levels - 1u;
+  mip = mip > top ? top : mip;
+  float u = (((float)minx + (float)maxx) * 0.5f) / sw;
+  float v = (((float)miny + (float)maxy) * 0.5f) / sh;
+
+  // sample_level_min_reduction_2x2, cull.slang:86-112
+  uint32_t mw = mip_dim(hiz.width, mip), mh = mip_dim(hiz.height, mip);
+  int32_t mxx = (int32_t)mw - 1, mxy = (int32_t)mh - 1;
+  int32_t bx = cvt_i32_sat(floorf(u * (float)mw - 0.5f));
+  int32_t by = cvt_i32_sat(floorf(v * (float)mh - 0.5f));
+  int32_t bx1 = (int32_t)((uint32_t)bx + 1u), by1 = (int32_t)((uint32_t)by + 1u);
+  int32_t x0 = min(max(bx, 0), mxx), y0 = min(max(by, 0), mxy);
+  int32_t x1 = min(max(bx1, 0), mxx), y1 = min(max(by1, 0), mxy);
+  const float* lvl = hiz.data + level_off[mip];
+  float p00 = lvl[(size_t)y0 * mw + x0];
+  float p10 = lvl[(size_t)y0 * mw + x1];
+  float p01 = lvl[(size_t)y1 * mw + x0];
+  float p11 = lvl[(size_t)y1 * mw + x1];
+  float d = fminf(fminf(p00, p10), fminf(p01, p11));
+  return maxz <= d - 1e-7f;
+}
+
+}  // namespace oxc

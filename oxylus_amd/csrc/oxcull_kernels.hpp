@@ -1,0 +1,99 @@
+// oxcull_kernels.hpp -- kernel argument blocks and launcher prototypes shared by the kernel TU
+// (oxcull_kernels.hip) and the C-ABI host TU (oxcull_abi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "oxcull.h"
+#include "oxcull_types.hpp"
+
+namespace oxc {
+
+struct PrepareArgs {
+  const GpuMesh* meshes;
+  const float* transforms;
+  GpuMeshInstance* mesh_instances;
+  InstCache* cache;
+  uint32_t* mesh_counts;
+  uint32_t* slot;          // this call's counter slot
+  uint32_t* vis;           // {total, early, late}
+  uint32_t* meshlets_cmd;  // {x,1,1}
+  uint32_t* supers_meshlets;
+  uint32_t* supers_tris;
+  uint32_t n_supers_meshlets, n_supers_tris;
+  uint32_t mesh_instance_count;
+  uint32_t cull_flags;
+  uint32_t do_cull_meshes;
+  uint32_t init_vis;    // write vis/meshlets_cmd initial values
+  uint32_t seed_total;  // initial vis.total (0 for the reference flow)
+  oxc_cull_camera cam;
+};
+
+struct MeshletTestArgs {
+  const InstCache* cache;
+  const GpuMeshletInstance* meshlet_instances;
+  const uint32_t* vis;
+  uint32_t* mask;
+  uint64_t* bits;
+  uint32_t* chunk_counts;
+  uint32_t* supers;
+  const float* hiz_data;
+  uint32_t hiz_level_off[13];  // float offsets of each mip
+  uint32_t hiz_w, hiz_h, hiz_levels;
+  float near_clip;
+  float cam_pos[3];
+};
+
+struct MeshletEmitArgs {
+  const uint64_t* bits;
+  const uint32_t* chunk_counts;
+  const uint32_t* supers;
+  uint32_t* vis;
+  uint32_t* tri_cmd;
+  uint32_t* out;  // visible_meshlet_instances_indices
+};
+
+struct TriTestArgs {
+  const InstCache* cache;
+  const GpuMeshletInstance* meshlet_instances;
+  const uint32_t* visible;
+  const uint32_t* vis;
+  const uint32_t* tri_cmd;
+  uint64_t* tri_masks;
+  uint32_t* chunk_counts;
+  uint32_t* supers;
+};
+
+struct TriEmitArgs {
+  const uint64_t* tri_masks;
+  const uint32_t* visible;
+  const uint32_t* vis;
+  const uint32_t* tri_cmd;
+  const uint32_t* chunk_counts;
+  const uint32_t* supers;
+  uint32_t* draw_cmd;
+  uint32_t* out;  // reordered_indices
+};
+
+struct HizArgs {
+  const float* depth;
+  float* hiz;
+  uint32_t dw, dh;
+  uint32_t w, h, levels;
+  uint32_t level_off[13];  // floats
+};
+
+void launch_prepare(const PrepareArgs& a, uint32_t grid, hipStream_t s);
+void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s);
+void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, void* out, uint32_t grid, hipStream_t s);
+void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s);
+void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
+void launch_tris_test(const TriTestArgs& a, bool late, uint32_t grid, hipStream_t s);
+void launch_tris_emit(const TriEmitArgs& a, bool late, uint32_t grid, hipStream_t s);
+void launch_hiz(const HizArgs& a, hipStream_t s);
+void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
+void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
+void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
+
+}  // namespace oxc

@@ -1,0 +1,75 @@
+// oxcull_types.hpp -- device-side mirrors of the reference GPU structs and the per-instance
+// cache the kernels stream against.  Layouts: Oxylus/include/Scene/SceneGPU.hpp:84-152.
+#pragma once
+#include <cstdint>
+
+namespace oxc {
+
+struct GpuMeshletInstance {  // SceneGPU.hpp:105-108
+  uint32_t mesh_instance_index, meshlet_index;
+};
+struct GpuMeshInstance {  // SceneGPU.hpp:110-116
+  uint32_t mesh_index, lod_index, material_index, transform_index, meshlet_instance_visibility_offset;
+};
+struct GpuMeshlet {  // SceneGPU.hpp:118-123
+  uint32_t indirect_vertex_index_offset, local_triangle_index_offset, vertex_count, triangle_count;
+};
+struct GpuMeshLOD {  // SceneGPU.hpp:125-139
+  uint64_t indices, meshlets, meshlet_bounds, local_triangle_indices, indirect_vertex_indices;
+  uint32_t indices_count, meshlet_count, meshlet_bounds_count, local_triangle_indices_count,
+      indirect_vertex_indices_count;
+  float error;
+};
+struct GpuMesh {  // SceneGPU.hpp:141-152
+  uint64_t vertex_positions, vertex_normals, texture_coords;
+  uint32_t vertex_count, lod_count;
+  uint64_t lods;
+  float aabb_center[3];
+  float aabb_extent[3];
+};
+static_assert(sizeof(GpuMeshletInstance) == 8, "layout");
+static_assert(sizeof(GpuMeshInstance) == 20, "layout");
+static_assert(sizeof(GpuMeshlet) == 16, "layout");
+static_assert(sizeof(GpuMeshLOD) == 64, "layout");
+static_assert(sizeof(GpuMesh) == 64, "layout");
+
+// Everything a meshlet/triangle test needs about its mesh instance, resolved once per call by
+// k_prepare_instances instead of once per meshlet (the reference re-derives mvp/planes/normal
+// matrix in every thread and chases mesh_instance -> mesh -> lods[lod] -> pointer per meshlet,
+// cull_meshlets.slang:37-52).  Same arithmetic, same order => same bits.
+// The first 64 dwords are exactly one coalesced wave load.
+struct alignas(64) InstCache {
+  float planes[24];   // 6 normalised frustum planes of mvp (cull.slang:58-71), xyzw each
+  float mvp[16];      // projection_view * world, column-major
+  float world[12];    // rows 0..2 of world: world[r*4+c]
+  float nm[9];        // TransformWorld::normal_matrix(), column-major (scene.slang:292-299)
+  float scale_max;    // max row length of world's 3x3 (scene.slang:305-310)
+  uint32_t vis_offset;     // MeshInstance::meshlet_instance_visibility_offset
+  uint32_t meshlet_count;  // of the selected LOD
+  // dwords 64..73
+  uint64_t bounds;     // MeshLOD::meshlet_bounds
+  uint64_t meshlets;   // MeshLOD::meshlets
+  uint64_t micro;      // MeshLOD::local_triangle_indices
+  uint64_t vidx;       // MeshLOD::indirect_vertex_indices
+  uint64_t positions;  // Mesh::vertex_positions
+  uint32_t _pad[6];
+};
+static_assert(sizeof(InstCache) == 320, "layout");
+
+// Counter slot handed out per cull_geometry call (u32 indices).
+enum : uint32_t {
+  SLOT_VIS = 0,         // {total, early, late}
+  SLOT_MESHLETS_CMD = 4,  // {x,1,1}
+  SLOT_TRI_CMD = 8,     // {x,1,1}
+  SLOT_DRAW_CMD = 12,   // {indexCount, instanceCount, firstIndex, vertexOffset, firstInstance}
+  SLOT_U32S = 32        // 128 B per slot
+};
+
+// Work decomposition constants (see DESIGN.md "ordered compaction").
+constexpr uint32_t kMeshletChunk = 512;      // meshlets per block iteration of the test kernel (8 ballot words)
+constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
+constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
+constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel
+constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
+
+}  // namespace oxc

@@ -1,0 +1,168 @@
+"""ctypes binding of liboxcull.so (the C ABI in include/oxcull.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load this
+module raises, it never routes to oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboxcull.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+OXC_OK, OXC_INVALID_ARG, OXC_HIP_ERROR, OXC_RCCL_ERROR, OXC_OUT_OF_MEMORY = range(5)
+
+CULL_TEST_FRUSTUM = 1
+CULL_SELECT_LOD = 2
+CULL_TEST_OCCLUSION = 4
+CULL_LATE_PASS = 8
+CULL_TEST_ALL = 7
+
+STAGE_MESHES = 1
+STAGE_MESHLETS = 2
+STAGE_TRIANGLES = 4
+STAGE_ALL = 7
+
+
+class Buffer(C.Structure):
+    _fields_ = [("dptr", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+class Image(C.Structure):
+    _fields_ = [
+        ("dptr", C.c_void_p),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("levels", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("level_offset", C.c_uint64 * 13),
+    ]
+
+
+class CullCamera(C.Structure):
+    _fields_ = [
+        ("projection_view", C.c_float * 16),
+        ("position", C.c_float * 3),
+        ("acceptable_lod_error", C.c_float),
+        ("resolution", C.c_float * 2),
+        ("near_clip", C.c_float),
+        ("mesh_instance_count", C.c_uint32),
+    ]
+
+
+class PreparedFrame(C.Structure):
+    _fields_ = [
+        ("mesh_instance_count", C.c_uint32),
+        ("max_meshlet_instance_count", C.c_uint32),
+        ("meshes_buffer", Buffer),
+        ("transforms_world_buffer", Buffer),
+        ("mesh_instances_buffer", Buffer),
+        ("meshlet_instances_buffer", Buffer),
+        ("visible_meshlet_instances_indices_buffer", Buffer),
+        ("meshlet_instance_visibility_mask_buffer", Buffer),
+        ("reordered_indices_buffer", Buffer),
+    ]
+
+
+class CullGeometryContext(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("use_hiz", C.c_uint32),
+        ("use_hpb", C.c_uint32),
+        ("init_cull_meshes", C.c_uint32),
+        ("cull_flags", C.c_uint32),
+        ("stages", C.c_uint32),
+        ("cull_camera", CullCamera),
+        ("hiz_attachment", Image),
+        ("visibility_buffer", Buffer),
+        ("cull_meshlets_cmd_buffer", Buffer),
+        ("cull_triangles_cmd_buffer", Buffer),
+        ("draw_geometry_cmd_buffer", Buffer),
+    ]
+
+
+class MainGeometryContext(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("depth_attachment", Image),
+        ("hiz_attachment", Image),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("total_visible_meshlet_instances", C.c_uint32),
+        ("early_visible_meshlet_instances", C.c_uint32),
+        ("late_visible_meshlet_instances", C.c_uint32),
+        ("cull_meshlets_cmd_x", C.c_uint32),
+        ("cull_triangles_cmd_x", C.c_uint32),
+        ("draw_index_count", C.c_uint32),
+    ]
+
+
+# every symbol include/oxcull.h declares
+EXPORTS = [
+    "oxc_abi_version",
+    "oxc_create",
+    "oxc_destroy",
+    "oxc_last_error",
+    "oxc_reserve",
+    "oxc_generate_hiz",
+    "oxc_cull_geometry",
+    "oxc_seed_meshlet_instances",
+    "oxc_read_counters",
+    "oxc_stream_read_probe",
+    "oxc_debug_decode_bounds",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile liboxcull.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC_DIR, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC_DIR], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the cull path)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.oxc_abi_version.restype = C.c_uint32
+    lib.oxc_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.oxc_destroy.argtypes = [vp]
+    lib.oxc_destroy.restype = None
+    lib.oxc_last_error.argtypes = [vp]
+    lib.oxc_last_error.restype = C.c_char_p
+    lib.oxc_reserve.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.oxc_generate_hiz.argtypes = [vp, C.POINTER(MainGeometryContext), vp]
+    lib.oxc_cull_geometry.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(CullGeometryContext), vp]
+    lib.oxc_seed_meshlet_instances.argtypes = [vp, C.POINTER(CullGeometryContext), C.c_uint32, vp]
+    lib.oxc_read_counters.argtypes = [vp, C.POINTER(CullGeometryContext), C.POINTER(Counters), vp]
+    lib.oxc_stream_read_probe.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.oxc_debug_decode_bounds.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    for name in EXPORTS:
+        if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class OxcError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"oxcull status {status}: {msg}")
+        self.status = status

@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's RendererInstance cull entry points over the C ABI.
+
+Same names and field meaning as Oxylus/include/Render/RendererInstance.hpp:143-216,397-398:
+`RendererInstance.generate_hiz(MainGeometryContext)` and
+`RendererInstance.cull_geometry(CullGeometryContext)`.  Buffers are torch CUDA tensors (device
+memory + streams only; all compute is in liboxcull.so).  The compiled C++ shim with the same
+surface is oxylus_amd/host/RendererInstance.hpp; this Python twin exists because the test
+runner and bench driver are Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import lib as L
+from .synth import Scene, hiz_layout
+
+
+def _buf(t: Optional[torch.Tensor]) -> L.Buffer:
+    if t is None:
+        return L.Buffer(None, 0)
+    return L.Buffer(t.data_ptr(), t.numel() * t.element_size())
+
+
+@dataclass
+class ImageAttachment:
+    """Linear R32F mip chain (stand-in for vuk::ImageAttachment)."""
+    data: torch.Tensor  # float32 1-D
+    width: int
+    height: int
+    levels: int
+    level_offset: list  # bytes
+
+    @staticmethod
+    def hiz(width: int, height: int, device, levels: Optional[int] = None) -> "ImageAttachment":
+        levels, offs, total = hiz_layout(width, height, levels)
+        # vuk::clear_image(hiz, DepthZero), RendererInstance.cpp:588
+        return ImageAttachment(torch.zeros(total // 4, dtype=torch.float32, device=device), width, height, levels, offs)
+
+    @staticmethod
+    def depth(t: torch.Tensor) -> "ImageAttachment":
+        assert t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
+        return ImageAttachment(t.view(-1), t.shape[1], t.shape[0], 1, [0])
+
+    def level(self, k: int) -> torch.Tensor:
+        w, h = max(1, self.width >> k), max(1, self.height >> k)
+        o = self.level_offset[k] // 4
+        return self.data[o:o + w * h].view(h, w)
+
+    def c(self) -> L.Image:
+        im = L.Image()
+        im.dptr = self.data.data_ptr()
+        im.width, im.height, im.levels = self.width, self.height, self.levels
+        for k, o in enumerate(self.level_offset):
+            im.level_offset[k] = o
+        return im
+
+
+@dataclass
+class PreparedFrame:
+    """The PreparedFrame buffers of the cull path (RendererInstance.hpp:143-169), sized as in
+    RendererInstance::update (RendererInstance.cpp:1640-1732)."""
+    scene: Scene
+    max_meshlet_instance_count: int
+    meshlet_instances_buffer: torch.Tensor
+    visible_meshlet_instances_indices_buffer: torch.Tensor
+    meshlet_instance_visibility_mask_buffer: torch.Tensor
+    reordered_indices_buffer: Optional[torch.Tensor]
+
+    @staticmethod
+    def create(scene: Scene, with_triangles: bool = True, expand: bool = True) -> "PreparedFrame":
+        dev = scene.device
+        n = scene.n_meshlet_instances
+        mli = scene.meshlet_instances.clone() if expand else torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        vis_idx = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        # zero-filled on (re)upload of the instances, RendererInstance.cpp:1651-1665
+        mask = torch.zeros(max((n + 31) // 32, 1), dtype=torch.int32, device=dev)
+        reordered = torch.zeros(max(n, 1) * 64 * 3, dtype=torch.int32, device=dev) if with_triangles else None
+        return PreparedFrame(scene, n, mli, vis_idx, mask, reordered)
+
+    def c(self) -> L.PreparedFrame:
+        f = L.PreparedFrame()
+        s = self.scene
+        f.mesh_instance_count = s.n_mesh_instances
+        f.max_meshlet_instance_count = self.max_meshlet_instance_count
+        f.meshes_buffer = _buf(s.meshes)
+        f.transforms_world_buffer = _buf(s.transforms)
+        f.mesh_instances_buffer = _buf(s.mesh_instances)
+        f.meshlet_instances_buffer = _buf(self.meshlet_instances_buffer)
+        f.visible_meshlet_instances_indices_buffer = _buf(self.visible_meshlet_instances_indices_buffer)
+        f.meshlet_instance_visibility_mask_buffer = _buf(self.meshlet_instance_visibility_mask_buffer)
+        f.reordered_indices_buffer = _buf(self.reordered_indices_buffer)
+        return f
+
+
+@dataclass
+class CullGeometryContext:
+    """RendererInstance.hpp:171-197."""
+    use_hiz: bool = False
+    use_hpb: bool = False
+    init_cull_meshes: bool = False
+    cull_flags: int = L.CULL_TEST_ALL
+    cull_camera: Optional[L.CullCamera] = None
+    hiz_attachment: Optional[ImageAttachment] = None
+    stages: int = 0
+    _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
+
+    def c(self) -> L.CullGeometryContext:
+        c = self._c
+        c.struct_size = C.sizeof(L.CullGeometryContext)
+        c.use_hiz, c.use_hpb, c.init_cull_meshes = int(self.use_hiz), int(self.use_hpb), int(self.init_cull_meshes)
+        c.cull_flags, c.stages = self.cull_flags, self.stages
+        if self.cull_camera is not None:
+            c.cull_camera = self.cull_camera
+        if self.hiz_attachment is not None:
+            c.hiz_attachment = self.hiz_attachment.c()
+        return c
+
+
+@dataclass
+class MainGeometryContext:
+    """The fields generate_hiz uses (RendererInstance.hpp:199-216)."""
+    depth_attachment: ImageAttachment
+    hiz_attachment: ImageAttachment
+
+
+class RendererInstance:
+    """Owns one oxc_ctx on one device."""
+
+    def __init__(self, device_index: int = 0):
+        self._lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("oxylus_amd.RendererInstance needs a GPU: the cull path has no CPU fallback")
+        self.device_index = device_index
+        self._ctx = C.c_void_p()
+        st = self._lib.oxc_create(device_index, C.byref(self._ctx))
+        if st != L.OXC_OK:
+            raise L.OxcError(st, "oxc_create failed")
+        self.prepared_frame: Optional[PreparedFrame] = None
+
+    def close(self):
+        if self._ctx:
+            self._lib.oxc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != L.OXC_OK:
+            raise L.OxcError(st, self._lib.oxc_last_error(self._ctx).decode())
+
+    @staticmethod
+    def _stream(stream) -> C.c_void_p:
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return C.c_void_p(s.cuda_stream)
+
+    def reserve(self, max_mesh_instances: int, max_meshlet_instances: int):
+        self._check(self._lib.oxc_reserve(self._ctx, max_mesh_instances, max_meshlet_instances))
+
+    def generate_hiz(self, context: MainGeometryContext, stream=None):
+        c = L.MainGeometryContext()
+        c.struct_size = C.sizeof(L.MainGeometryContext)
+        c.depth_attachment = context.depth_attachment.c()
+        c.hiz_attachment = context.hiz_attachment.c()
+        self._check(self._lib.oxc_generate_hiz(self._ctx, C.byref(c), self._stream(stream)))
+
+    def cull_geometry(self, context: CullGeometryContext, stream=None):
+        assert self.prepared_frame is not None
+        f = self.prepared_frame.c()
+        self._check(self._lib.oxc_cull_geometry(self._ctx, C.byref(f), C.byref(context.c()), self._stream(stream)))
+
+    def seed_meshlet_instances(self, context: CullGeometryContext, total: int, stream=None):
+        self._check(self._lib.oxc_seed_meshlet_instances(self._ctx, C.byref(context.c()), total, self._stream(stream)))
+
+    def read_counters(self, context: CullGeometryContext, stream=None) -> L.Counters:
+        out = L.Counters()
+        self._check(self._lib.oxc_read_counters(self._ctx, C.byref(context._c), C.byref(out), self._stream(stream)))
+        return out
+
+    def stream_read_probe(self, t: torch.Tensor, stream=None):
+        self._check(self._lib.oxc_stream_read_probe(self._ctx, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), self._stream(stream)))
+
+    def debug_decode_bounds(self, bounds: torch.Tensor) -> torch.Tensor:
+        n = bounds.shape[0]
+        out = torch.empty((n, 10), dtype=torch.float32, device=bounds.device)
+        self._check(self._lib.oxc_debug_decode_bounds(self._ctx, C.c_void_p(bounds.data_ptr()), n, C.c_void_p(out.data_ptr()), self._stream(None)))
+        return out

@@ -1,0 +1,363 @@
+"""Seeded synthetic scenes in the reference's GPU byte layouts.
+
+Everything is a torch tensor so the same generator runs on the CPU (tests, oracle input) and
+directly in HBM (benchmarks at 10M+ meshlets, no PCIe upload).  `Scene.bind()` patches the
+64-bit pointer fields of GPU::Mesh / GPU::MeshLOD (SceneGPU.hpp:125-152) with the addresses of
+the tensors on whatever device they live on -- host addresses for the CPU oracle, device VAs for
+the HIP path.  Layouts: Oxylus/include/Scene/SceneGPU.hpp:84-152,222-229; producer conventions:
+Oxylus/src/Asset/AssetManager_GLTF.cpp:590-761 (extent = full box size, u16x4 positions,
+4-byte aligned micro-index runs).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+
+from .lib import CullCamera
+
+
+def _align(v: int, a: int) -> int:
+    return (v + a - 1) // a * a
+
+
+def perspective_reversed_z(fov_deg: float, aspect: float, near: float, far: float) -> torch.Tensor:
+    """glm::perspective(radians(fov), aspect, far, near) with GLM_FORCE_DEPTH_ZERO_TO_ONE, then
+    proj[1][1] *= -1 (Oxylus/src/Render/Camera.cpp:36-54).  Column-major 16 floats."""
+    t = math.tan(math.radians(fov_deg) / 2.0)
+    z_near, z_far = far, near  # swapped on purpose: reversed-Z
+    m = [[0.0] * 4 for _ in range(4)]  # m[col][row]
+    m[0][0] = 1.0 / (aspect * t)
+    m[1][1] = -(1.0 / t)
+    m[2][2] = z_far / (z_near - z_far)
+    m[2][3] = -1.0
+    m[3][2] = -(z_far * z_near) / (z_far - z_near)
+    return torch.tensor([m[c][r] for c in range(4) for r in range(4)], dtype=torch.float32)
+
+
+@dataclass
+class SceneSpec:
+    n_mesh_instances: int = 16
+    meshlets_per_mesh: int = 64  # K: LOD-0 meshlets per mesh
+    lod_count: int = 1
+    verts_per_meshlet: int = 64
+    tris_per_meshlet: int = 64
+    with_geometry: bool = True
+    ragged: bool = False       # random vertex/triangle counts per meshlet
+    share_meshes: int = 0      # >0: that many distinct meshes shared by all instances (instanced variant)
+    nonuniform_scale: bool = False
+    seed: int = 0x0A1DE5
+    scene_depth: float = 200.0  # instances fill x,y in [-D/2, D/2], z in [-D, 0.1 D]
+    resolution: int = 4096
+    fov_deg: float = 60.0
+    near: float = 0.1
+    far: float = 1000.0
+    degenerate_cone_frac: float = 0.15
+
+
+@dataclass
+class Scene:
+    spec: SceneSpec
+    device: torch.device
+    # blob arrays
+    bounds: torch.Tensor          # int16 [B, 8]    GPU::MeshletBounds
+    meshlets: torch.Tensor        # int32 [B, 4]    GPU::Meshlet
+    micro: torch.Tensor           # uint8 [..]      local_triangle_indices (u8 stream)
+    vidx: torch.Tensor            # int32 [..]      indirect_vertex_indices
+    positions: torch.Tensor       # int16 [.., 4]   u16x4 half positions
+    lods: torch.Tensor            # int64 [n_meshes*lod_count, 8]   GPU::MeshLOD
+    meshes: torch.Tensor          # int64 [n_meshes, 8]             GPU::Mesh
+    transforms: torch.Tensor      # float32 [M, 16]
+    mesh_instances: torch.Tensor  # int32 [M, 5]
+    meshlet_instances: torch.Tensor  # int32 [N, 2]  LOD-0 expansion (cull_meshes output for "all visible, LOD 0")
+    camera: Dict[str, object] = field(default_factory=dict)
+    # bookkeeping (host ints)
+    n_meshes: int = 0
+    lod_meshlet_counts: Optional[list] = None
+    _lod_tables: Optional[dict] = None
+
+    @property
+    def n_mesh_instances(self) -> int:
+        return int(self.mesh_instances.shape[0])
+
+    @property
+    def n_meshlet_instances(self) -> int:
+        return int(self.meshlet_instances.shape[0])
+
+    def cull_camera(self) -> CullCamera:
+        cam = CullCamera()
+        pv = self.camera["projection_view"]
+        for i in range(16):
+            cam.projection_view[i] = float(pv[i])
+        for i in range(3):
+            cam.position[i] = float(self.camera["position"][i])
+        cam.acceptable_lod_error = float(self.camera["acceptable_lod_error"])
+        cam.resolution[0] = float(self.camera["resolution"][0])
+        cam.resolution[1] = float(self.camera["resolution"][1])
+        cam.near_clip = float(self.camera["near_clip"])
+        cam.mesh_instance_count = self.n_mesh_instances
+        return cam
+
+    def bind(self) -> "Scene":
+        """(Re)write the pointer fields of meshes/lods for the current tensor addresses."""
+        t = self._lod_tables
+        dev = self.device
+        lods = self.lods
+        base_bounds, base_meshlets = self.bounds.data_ptr(), self.meshlets.data_ptr()
+        base_micro, base_vidx, base_pos = self.micro.data_ptr(), self.vidx.data_ptr(), self.positions.data_ptr()
+        lods[:, 0] = 0
+        lods[:, 1] = base_meshlets + t["meshlet_start"].to(dev) * 16
+        lods[:, 2] = base_bounds + t["meshlet_start"].to(dev) * 16
+        lods[:, 3] = base_micro + t["micro_start"].to(dev)
+        lods[:, 4] = base_vidx + t["vidx_start"].to(dev) * 4
+        meshes = self.meshes
+        meshes[:, 0] = base_pos + t["mesh_vertex_start"].to(dev) * 8
+        meshes[:, 1] = 0
+        meshes[:, 2] = 0
+        L = self.spec.lod_count
+        meshes[:, 4] = lods.data_ptr() + torch.arange(self.n_meshes, dtype=torch.int64, device=dev) * (64 * L)
+        return self
+
+    def to(self, device) -> "Scene":
+        device = torch.device(device)
+        kw = {}
+        for name in ("bounds", "meshlets", "micro", "vidx", "positions", "lods", "meshes", "transforms",
+                     "mesh_instances", "meshlet_instances"):
+            kw[name] = getattr(self, name).to(device).contiguous().clone()
+        s = Scene(spec=self.spec, device=device, camera=self.camera, n_meshes=self.n_meshes,
+                  lod_meshlet_counts=self.lod_meshlet_counts, _lod_tables=self._lod_tables, **kw)
+        return s.bind()
+
+    def clone(self) -> "Scene":
+        return self.to(self.device)
+
+    def algorithmic_bytes_meshlet_stage(self, visible_fraction: float) -> float:
+        """8 B MeshletInstance + 16 B MeshletBounds read, 4*v B written, per-mesh
+        tables (20+64+64+64 B) amortised over K meshlets."""
+        return 24.0 + 212.0 / max(1, self.spec.meshlets_per_mesh) + 4.0 * visible_fraction
+
+
+def _f16_bits(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16).view(torch.int16)
+
+
+def _quat_to_mat(q: torch.Tensor) -> torch.Tensor:
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    r = torch.empty((q.shape[0], 3, 3), dtype=torch.float32, device=q.device)
+    r[:, 0, 0] = 1 - 2 * (y * y + z * z)
+    r[:, 0, 1] = 2 * (x * y - w * z)
+    r[:, 0, 2] = 2 * (x * z + w * y)
+    r[:, 1, 0] = 2 * (x * y + w * z)
+    r[:, 1, 1] = 1 - 2 * (x * x + z * z)
+    r[:, 1, 2] = 2 * (y * z - w * x)
+    r[:, 2, 0] = 2 * (x * z - w * y)
+    r[:, 2, 1] = 2 * (y * z + w * x)
+    r[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return r
+
+
+def make_scene(spec: SceneSpec, device="cpu") -> Scene:
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(spec.seed)
+
+    def rand(*shape):
+        return torch.rand(*shape, generator=g, device=dev, dtype=torch.float32)
+
+    M, K, L = spec.n_mesh_instances, spec.meshlets_per_mesh, spec.lod_count
+    V, T = spec.verts_per_meshlet, spec.tris_per_meshlet
+    n_meshes = spec.share_meshes if spec.share_meshes > 0 else M
+    lod_counts = [max(1, K >> i) for i in range(L)]
+    per_mesh_meshlets = sum(lod_counts)
+    B = n_meshes * per_mesh_meshlets
+    mesh_half = 2.0  # meshlet centres uniform in [-2,2]^3 (mesh-local metres)
+
+    # ---- meshlet bounds (all meshes, all lods; layout: mesh-major, then lod, then meshlet) ----
+    centre = (rand(B, 3) * 2 - 1) * mesh_half
+    extent = torch.exp(rand(B, 3) * math.log(10.0) + math.log(0.05))  # log-uniform 0.05..0.5
+    axis = torch.randn(B, 3, generator=g, device=dev, dtype=torch.float32)
+    axis = axis / axis.norm(dim=1, keepdim=True).clamp_min(1e-6)
+    axis_s8 = torch.round(axis * 127).clamp(-127, 127).to(torch.int32)
+    cutoff_s8 = torch.randint(-64, 128, (B,), generator=g, device=dev, dtype=torch.int32)
+    cutoff_s8 = torch.where(rand(B) < spec.degenerate_cone_frac, torch.full_like(cutoff_s8, 127), cutoff_s8)
+    bounds = torch.empty((B, 8), dtype=torch.int16, device=dev)
+    bounds[:, 0:3] = _f16_bits(centre)
+    bounds[:, 4:7] = _f16_bits(extent)
+    bounds[:, 3] = ((axis_s8[:, 0] & 0xFF) | ((axis_s8[:, 1] & 0xFF) << 8)).to(torch.int16)
+    bounds[:, 7] = ((axis_s8[:, 2] & 0xFF) | ((cutoff_s8 & 0xFF) << 8)).to(torch.int16)
+
+    # ---- meshlet geometry ----
+    lod_index_of = torch.arange(n_meshes * L, device=dev, dtype=torch.int64)
+    lod_of = lod_index_of % L
+    lod_cnt = torch.tensor(lod_counts, dtype=torch.int64, device=dev)[lod_of]          # meshlets per (mesh,lod)
+    meshlet_start = torch.cumsum(lod_cnt, 0) - lod_cnt                                  # first meshlet of (mesh,lod)
+    if spec.with_geometry:
+        if spec.ragged:
+            vcount = torch.randint(3, V + 1, (B,), generator=g, device=dev, dtype=torch.int64)
+            tcount = torch.randint(1, T + 1, (B,), generator=g, device=dev, dtype=torch.int64)
+        else:
+            vcount = torch.full((B,), V, dtype=torch.int64, device=dev)
+            tcount = torch.full((B,), T, dtype=torch.int64, device=dev)
+        tbytes = (tcount * 3 + 3) // 4 * 4
+        # offsets are relative to the (mesh,lod) arrays
+        vstart_g = torch.cumsum(vcount, 0) - vcount
+        tstart_g = torch.cumsum(tbytes, 0) - tbytes
+        owner = torch.repeat_interleave(torch.arange(n_meshes * L, device=dev), lod_cnt)  # (mesh,lod) of each meshlet
+        lod_vstart = vstart_g[meshlet_start]      # vertex start of each (mesh,lod)
+        lod_tstart = tstart_g[meshlet_start]
+        meshlets = torch.empty((B, 4), dtype=torch.int32, device=dev)
+        meshlets[:, 0] = (vstart_g - lod_vstart[owner]).to(torch.int32)
+        meshlets[:, 1] = (tstart_g - lod_tstart[owner]).to(torch.int32)
+        meshlets[:, 2] = vcount.to(torch.int32)
+        meshlets[:, 3] = tcount.to(torch.int32)
+        total_v = int(vcount.sum().item())
+        total_tb = int(tbytes.sum().item())
+        # vertex positions: uniform inside the meshlet's AABB
+        vert_owner = torch.repeat_interleave(torch.arange(B, device=dev), vcount)
+        positions = torch.zeros((total_v, 4), dtype=torch.int16, device=dev)
+        step = 1 << 24
+        for s in range(0, total_v, step):
+            o = vert_owner[s:s + step]
+            p = centre[o] + (rand(o.shape[0], 3) - 0.5) * extent[o]
+            positions[s:s + step, 0:3] = _f16_bits(p)
+        # indirect vertex indices: index into the mesh's vertex array
+        mesh_of_lod = lod_index_of // L
+        mesh_vertex_start = lod_vstart[torch.arange(n_meshes, device=dev) * L]
+        vidx = (torch.arange(total_v, device=dev, dtype=torch.int64) - mesh_vertex_start[mesh_of_lod[owner[vert_owner]]]).to(torch.int32)
+        # micro indices: random corners < vertex_count
+        micro = torch.zeros((total_tb,), dtype=torch.uint8, device=dev)
+        byte_owner = torch.repeat_interleave(torch.arange(B, device=dev), tbytes)
+        for s in range(0, total_tb, step):
+            o = byte_owner[s:s + step]
+            micro[s:s + step] = (rand(o.shape[0]) * vcount[o].to(torch.float32)).to(torch.int64).clamp_(max=255).to(torch.uint8)
+        micro = torch.minimum(micro, (vcount[byte_owner] - 1).to(torch.uint8))
+        vidx_start = lod_vstart
+        micro_start = lod_tstart
+        del vert_owner, byte_owner
+    else:
+        meshlets = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+        positions = torch.zeros((1, 4), dtype=torch.int16, device=dev)
+        vidx = torch.zeros((1,), dtype=torch.int32, device=dev)
+        micro = torch.zeros((4,), dtype=torch.uint8, device=dev)
+        vidx_start = torch.zeros(n_meshes * L, dtype=torch.int64, device=dev)
+        micro_start = torch.zeros(n_meshes * L, dtype=torch.int64, device=dev)
+        mesh_vertex_start = torch.zeros(n_meshes, dtype=torch.int64, device=dev)
+        total_v, total_tb = 0, 0
+
+    # ---- GPU::MeshLOD / GPU::Mesh tables (pointers filled by bind()) ----
+    lods = torch.zeros((n_meshes * L, 8), dtype=torch.int64, device=dev)
+    lods32 = lods.view(torch.int32)  # [.., 16]
+    lods32[:, 10] = 0                                  # indices_count
+    lods32[:, 11] = lod_cnt.to(torch.int32)            # meshlet_count
+    lods32[:, 12] = lod_cnt.to(torch.int32)            # meshlet_bounds_count
+    lods32[:, 13] = 0
+    lods32[:, 14] = 0
+    lodf = lod_of.to(torch.float32)
+    err = torch.where(lod_of > 0, 0.004 * torch.pow(torch.full_like(lodf, 2.0), lodf), torch.zeros_like(lodf))
+    lods32[:, 15] = err.to(torch.float32).view(torch.int32)
+    meshes = torch.zeros((n_meshes, 8), dtype=torch.int64, device=dev)
+    meshes32 = meshes.view(torch.int32)
+    mesh_nverts = torch.zeros(n_meshes, dtype=torch.int64, device=dev)
+    meshes32[:, 6] = mesh_nverts.to(torch.int32)
+    meshes32[:, 7] = L
+    mb_centre = torch.zeros((n_meshes, 3), dtype=torch.float32, device=dev)
+    mb_extent = torch.full((n_meshes, 3), 2 * mesh_half + 0.5, dtype=torch.float32, device=dev)
+    meshes32[:, 10:13] = mb_centre.view(torch.int32)
+    meshes32[:, 13:16] = mb_extent.view(torch.int32)
+
+    # ---- instances ----
+    D = spec.scene_depth
+    n_side = max(1, int(math.ceil(M ** (1.0 / 3.0))))
+    ids = torch.arange(M, device=dev, dtype=torch.int64)
+    gx, gy, gz = ids % n_side, (ids // n_side) % n_side, ids // (n_side * n_side)
+    cell = torch.stack([gx, gy, gz], 1).to(torch.float32)
+    jitter = rand(M, 3)
+    u = (cell + jitter) / float(n_side)
+    pos = torch.stack([(u[:, 0] - 0.5) * D, (u[:, 1] - 0.5) * D, -D + u[:, 2] * 1.1 * D], 1)
+    q = torch.randn(M, 4, generator=g, device=dev, dtype=torch.float32)
+    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-6)
+    R = _quat_to_mat(q)
+    if spec.nonuniform_scale:
+        S = 0.5 + 1.5 * rand(M, 3)
+    else:
+        S = (0.5 + 1.5 * rand(M, 1)).expand(M, 3)
+    RS = R * S[:, None, :]
+    world = torch.zeros((M, 4, 4), dtype=torch.float32, device=dev)  # [m, col, row]
+    world[:, 0:3, 0:3] = RS.transpose(1, 2)
+    world[:, 3, 0:3] = pos
+    world[:, 3, 3] = 1.0
+    transforms = world.reshape(M, 16).contiguous()
+
+    mesh_index = (ids % n_meshes)
+    mesh_instances = torch.zeros((M, 5), dtype=torch.int32, device=dev)
+    mesh_instances[:, 0] = mesh_index.to(torch.int32)
+    mesh_instances[:, 1] = 0
+    mesh_instances[:, 2] = 0
+    mesh_instances[:, 3] = ids.to(torch.int32)
+    mesh_instances[:, 4] = (ids * K).to(torch.int32)  # running sum of LOD-0 meshlet counts (Scene.cpp:1248-1260)
+    n_total = M * K
+    mi = torch.arange(n_total, device=dev, dtype=torch.int64)
+    meshlet_instances = torch.stack([(mi // K).to(torch.int32), (mi % K).to(torch.int32)], 1).contiguous()
+
+    proj = perspective_reversed_z(spec.fov_deg, 1.0, spec.near, spec.far)
+    camera = {
+        "projection_view": proj.tolist(),  # view = identity: camera at the origin looking down -Z
+        "position": [0.0, 0.0, 0.0],
+        "acceptable_lod_error": 2.0,
+        "resolution": [float(spec.resolution), float(spec.resolution)],
+        "near_clip": spec.near,
+    }
+    tables = {
+        "meshlet_start": meshlet_start.cpu(),
+        "vidx_start": vidx_start.cpu(),
+        "micro_start": micro_start.cpu(),
+        "mesh_vertex_start": mesh_vertex_start.cpu(),
+    }
+    scene = Scene(spec=spec, device=dev, bounds=bounds, meshlets=meshlets, micro=micro, vidx=vidx, positions=positions,
+                  lods=lods, meshes=meshes, transforms=transforms, mesh_instances=mesh_instances,
+                  meshlet_instances=meshlet_instances, camera=camera, n_meshes=n_meshes,
+                  lod_meshlet_counts=lod_counts, _lod_tables=tables)
+    return scene.bind()
+
+
+# ---------------------------------------------------------------------------------------------
+# HiZ helpers
+# ---------------------------------------------------------------------------------------------
+def hiz_extent_for(depth_w: int, depth_h: int):
+    """RendererInstance.cpp:573-577: bit_ceil((dim + 1) >> 1) per axis."""
+    def bit_ceil(v):
+        return 1 << max(0, (v - 1).bit_length())
+    return bit_ceil((depth_w + 1) >> 1), bit_ceil((depth_h + 1) >> 1)
+
+
+def hiz_layout(w: int, h: int, levels: Optional[int] = None):
+    """Level count min(floor(log2(max(w,h)))+1, 13) (RendererInstance.cpp:585, Texture.hpp:144-146)
+    and a packed linear layout: byte offset of each level (256-byte aligned), total bytes."""
+    if levels is None:
+        levels = min(int(math.floor(math.log2(max(w, h)))) + 1, 13)
+    offs, off = [], 0
+    for k in range(levels):
+        offs.append(off)
+        off = _align(off + max(1, w >> k) * max(1, h >> k) * 4, 256)
+    return levels, offs, off
+
+
+def make_depth(w: int, h: int, n_quads: int = 64, seed: int = 1, device="cpu", near: float = 0.1) -> torch.Tensor:
+    """Synthetic reversed-Z depth: far (0) background plus random screen-space quads at random
+    view distances of 15..150 m (depth ~ near/dist), nearest wins."""
+    dev = torch.device(device)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+    for _ in range(n_quads):
+        cx, cy = torch.rand(2, generator=g).tolist()
+        sx, sy = (0.03 + 0.22 * torch.rand(2, generator=g)).tolist()
+        dist = 15.0 + 135.0 * float(torch.rand(1, generator=g))
+        z = near / dist
+        x0, x1 = int(max(0, (cx - sx / 2) * w)), int(min(w, (cx + sx / 2) * w))
+        y0, y1 = int(max(0, (cy - sy / 2) * h)), int(min(h, (cy + sy / 2) * h))
+        if x1 > x0 and y1 > y0:
+            depth[y0:y1, x0:x1] = torch.clamp(depth[y0:y1, x0:x1], min=z)
+    return depth

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle
+
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def renderer():
+    """One RendererInstance (oxc_ctx) on cuda:0 for the whole GPU session."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oxylus_amd.renderer import RendererInstance
+
+    r = RendererInstance(0)
+    yield r
+    r.close()

@@ -1,0 +1,43 @@
+"""The C-ABI library loads and exports every symbol include/oxcull.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+from oxylus_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "oxcull.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oxc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(L.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    L.build()
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"liboxcull.so does not export {name}"
+    assert lib.oxc_abi_version() == 1
+
+
+def test_struct_sizes_match_reference_layouts():
+    # GPU::CullCamera is a 96-byte push constant (SceneGPU.hpp:222-229)
+    assert ctypes.sizeof(L.CullCamera) == 96
+    assert ctypes.sizeof(L.Buffer) == 16
+    assert ctypes.sizeof(L.Image) == 24 + 13 * 8
+    assert ctypes.sizeof(L.Counters) == 24
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "oxylus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in src and "oxcull_oracle" not in src, f"{f} references the oracle"

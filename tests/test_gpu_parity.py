@@ -1,0 +1,190 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same seeded scenes.
+
+Bit-exact bar: counts equal, visibility-mask bytes equal, HiZ pyramid bytes equal, and -- because
+both sides emit in ascending order -- visible-meshlet and packed-triangle index arrays
+byte-identical WITHOUT sorting.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oxylus_amd import lib as L
+from oxylus_amd.renderer import ImageAttachment, MainGeometryContext
+from oxylus_amd.synth import SceneSpec, make_depth, make_scene
+
+from util import assert_same, gpu_frame, oracle_frame, oracle_hiz
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(spec):
+    cpu = make_scene(spec, "cpu")
+    return cpu, cpu.to("cuda")
+
+
+@pytest.mark.parametrize(
+    "spec",
+    [
+        SceneSpec(n_mesh_instances=64, meshlets_per_mesh=256),
+        SceneSpec(n_mesh_instances=27, meshlets_per_mesh=100, seed=7),          # waves straddle instances
+        SceneSpec(n_mesh_instances=200, meshlets_per_mesh=3, seed=9),           # many instances per wave
+        SceneSpec(n_mesh_instances=8, meshlets_per_mesh=1000, seed=11, nonuniform_scale=True),
+        SceneSpec(n_mesh_instances=5, meshlets_per_mesh=513, seed=13, ragged=True),
+        SceneSpec(n_mesh_instances=1, meshlets_per_mesh=1, seed=15),
+        SceneSpec(n_mesh_instances=64, meshlets_per_mesh=64, seed=17, share_meshes=4),
+    ],
+    ids=["64x256", "27x100", "200x3", "8x1000-nonuniform", "5x513-ragged", "1x1", "instanced"],
+)
+def test_cull_meshlets_and_triangles(renderer, oracle_lib, spec):
+    cpu, gpu = _pair(spec)
+    want = oracle_frame(cpu)
+    got = gpu_frame(renderer, gpu)
+    assert_same(want, got, ["total", "visible", "indices"])
+    assert len(want["visible"]) > 0 or spec.n_mesh_instances == 1
+
+
+def test_cull_meshes_lod_select_and_expansion(renderer, oracle_lib):
+    spec = SceneSpec(n_mesh_instances=300, meshlets_per_mesh=96, lod_count=4, seed=21)
+    cpu, gpu = _pair(spec)
+    want = oracle_frame(cpu, run_cull_meshes=True)
+    got = gpu_frame(renderer, gpu, run_cull_meshes=True)
+    assert_same(want, got, ["total", "cull_meshlets_cmd_x", "lod_index", "meshlet_instances", "visible", "indices"])
+    assert len(set(want["lod_index"].tolist())) > 1, "scene should exercise several LODs"
+
+
+def test_cull_meshes_frustum_only_flags(renderer, oracle_lib):
+    spec = SceneSpec(n_mesh_instances=100, meshlets_per_mesh=40, lod_count=3, seed=23)
+    cpu, gpu = _pair(spec)
+    want = oracle_frame(cpu, cull_flags=L.CULL_TEST_FRUSTUM, run_cull_meshes=True)
+    got = gpu_frame(renderer, gpu, cull_flags=L.CULL_TEST_FRUSTUM, run_cull_meshes=True)
+    assert_same(want, got, ["total", "lod_index", "meshlet_instances", "visible", "indices"])
+    assert (want["lod_index"] == 0).all()
+
+
+@pytest.mark.parametrize("size,depth_scale", [(64, 2), (256, 2), (1024, 2), (256, 1), (128, 3), (32, 2), (8, 2)])
+def test_generate_hiz(renderer, oracle_lib, size, depth_scale):
+    depth = make_depth(size * depth_scale, size * depth_scale, 24, seed=size)
+    depth += torch.rand(depth.shape, generator=torch.Generator().manual_seed(size)) * 1e-4  # no flat areas
+    want, levels, offs = oracle_hiz(depth, size, size)
+    hiz = ImageAttachment.hiz(size, size, "cuda")
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth.cuda()), hiz))
+    got = hiz.data.cpu()
+    for k in range(levels):
+        w = max(1, size >> k)
+        a = want[offs[k] // 4: offs[k] // 4 + w * w].numpy().view(np.uint32)
+        b = got[offs[k] // 4: offs[k] // 4 + w * w].numpy().view(np.uint32)
+        assert np.array_equal(a, b), f"mip {k}: {(a != b).sum()} texels differ"
+
+
+def test_generate_hiz_non_square(renderer, oracle_lib):
+    w, h = 512, 256
+    depth = torch.rand((2 * h, 2 * w), generator=torch.Generator().manual_seed(5))
+    from oxylus_amd.synth import hiz_layout
+    import oracle
+
+    levels, offs, total = hiz_layout(w, h)
+    want = torch.zeros(total // 4)
+    oracle.generate_hiz(depth, want, w, h, levels, offs)
+    hiz = ImageAttachment.hiz(w, h, "cuda")
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth.cuda()), hiz))
+    assert np.array_equal(want.numpy().view(np.uint32), hiz.data.cpu().numpy().view(np.uint32))
+
+
+def _hiz_pair(size, seed):
+    depth = make_depth(2 * size, 2 * size, 48, seed=seed)
+    data, levels, offs = oracle_hiz(depth, size, size)
+    att = ImageAttachment.hiz(size, size, "cuda")
+    att.data.copy_(data.cuda())
+    return {"data": data, "w": size, "h": size, "levels": levels, "offs": offs}, att
+
+
+@pytest.mark.parametrize(
+    "spec,size",
+    [
+        (SceneSpec(n_mesh_instances=64, meshlets_per_mesh=256, seed=31), 256),
+        (SceneSpec(n_mesh_instances=27, meshlets_per_mesh=100, seed=33), 512),
+        (SceneSpec(n_mesh_instances=150, meshlets_per_mesh=7, seed=35, ragged=True), 128),
+    ],
+    ids=["64x256", "27x100", "150x7"],
+)
+def test_two_pass_occlusion_first_frame(renderer, oracle_lib, spec, size):
+    """Frame 0: mask all zero => early emits nothing, late emits everything unoccluded."""
+    cpu, gpu = _pair(spec)
+    hz_cpu, hz_gpu = _hiz_pair(size, spec.seed)
+    mask = torch.zeros((cpu.n_meshlet_instances + 31) // 32, dtype=torch.int32)
+    want = oracle_frame(cpu, use_hiz=True, hiz=hz_cpu, mask=mask, two_pass=True)
+    got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hz_gpu, mask=mask, two_pass=True)
+    assert_same(want, got, ["early", "late", "early_visible", "late_visible", "early_indices", "late_indices", "mask"])
+    assert want["early"] == 0 and want["late"] > 0
+
+
+def test_two_pass_occlusion_random_prior_mask(renderer, oracle_lib):
+    """Config 3 restatement: given HiZ + given prior-visibility mask -> early + late pass."""
+    spec = SceneSpec(n_mesh_instances=40, meshlets_per_mesh=333, seed=41)
+    cpu, gpu = _pair(spec)
+    hz_cpu, hz_gpu = _hiz_pair(512, 41)
+    g = torch.Generator().manual_seed(41)
+    words = (cpu.n_meshlet_instances + 31) // 32
+    bits = (torch.rand((words, 32), generator=g) < 0.3).to(torch.int64)
+    mask = (bits << torch.arange(32)).sum(1).to(torch.int32)
+    want = oracle_frame(cpu, use_hiz=True, hiz=hz_cpu, mask=mask, two_pass=True)
+    got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hz_gpu, mask=mask, two_pass=True)
+    assert_same(want, got, ["early", "late", "early_visible", "late_visible", "early_indices", "late_indices", "mask"])
+    assert want["early"] > 0 and want["late"] > 0
+
+
+def test_two_pass_static_scene_second_frame(renderer, oracle_lib):
+    """Frame 1 with frame 0's mask: early U late == frame-0 visible set (static scene)."""
+    spec = SceneSpec(n_mesh_instances=32, meshlets_per_mesh=200, seed=43)
+    cpu, gpu = _pair(spec)
+    hz_cpu, hz_gpu = _hiz_pair(256, 43)
+    mask0 = torch.zeros((cpu.n_meshlet_instances + 31) // 32, dtype=torch.int32)
+    f0 = gpu_frame(renderer, gpu, use_hiz=True, hiz=hz_gpu, mask=mask0, two_pass=True)
+    f1 = gpu_frame(renderer, gpu, use_hiz=True, hiz=hz_gpu, mask=torch.from_numpy(f0["mask"]), two_pass=True)
+    assert f1["late"] == 0
+    assert np.array_equal(np.sort(f0["late_visible"]), np.sort(f1["early_visible"]))
+    assert np.array_equal(f0["mask"], f1["mask"])
+    w1 = oracle_frame(cpu, use_hiz=True, hiz=hz_cpu, mask=torch.from_numpy(f0["mask"]), two_pass=True)
+    assert_same(w1, f1, ["early", "late", "early_visible", "early_indices", "mask"])
+
+
+def test_hiz_path_without_occlusion_flag(renderer, oracle_lib):
+    spec = SceneSpec(n_mesh_instances=16, meshlets_per_mesh=128, seed=47)
+    cpu, gpu = _pair(spec)
+    hz_cpu, hz_gpu = _hiz_pair(128, 47)
+    mask = torch.full(((cpu.n_meshlet_instances + 31) // 32,), 0x5A5A5A5A, dtype=torch.int32)
+    want = oracle_frame(cpu, cull_flags=L.CULL_TEST_FRUSTUM, use_hiz=True, hiz=hz_cpu, mask=mask)
+    got = gpu_frame(renderer, gpu, cull_flags=L.CULL_TEST_FRUSTUM, use_hiz=True, hiz=hz_gpu, mask=mask)
+    assert_same(want, got, ["early", "early_visible", "early_indices", "mask"])
+
+
+def test_empty_scene_and_zero_visible(renderer, oracle_lib):
+    spec = SceneSpec(n_mesh_instances=4, meshlets_per_mesh=64, seed=51)
+    cpu, gpu = _pair(spec)
+    # camera looking away: nothing survives the frustum
+    for s in (cpu, gpu):
+        s.transforms[:, 14] = 5000.0
+    want = oracle_frame(cpu)
+    got = gpu_frame(renderer, gpu)
+    assert len(want["visible"]) == 0
+    assert_same(want, got, ["visible", "indices"])
+
+
+def test_decode_known_answers_all_halfs_and_s8(renderer, oracle_lib):
+    """Appendix B.1: every u16 through dequantize_half, every s8 through /127, device vs oracle."""
+    import oracle
+
+    h = torch.arange(65536, dtype=torch.int32)
+    b = torch.zeros((65536, 8), dtype=torch.int32)
+    b[:, 0] = h
+    b[:, 1] = (h * 7 + 3) & 0xFFFF
+    b[:, 2] = 65535 - h
+    b[:, 4] = (h * 13) & 0xFFFF
+    b[:, 5] = h ^ 0x8000
+    b[:, 6] = (h + 0x7C00) & 0xFFFF
+    b[:, 3] = h & 0xFFFF          # cone_axis_xy sweep both bytes
+    b[:, 7] = (h * 257) & 0xFFFF  # cone_axis_z / cutoff
+    b16 = b.to(torch.int16).contiguous()
+    got = renderer.debug_decode_bounds(b16.cuda()).cpu().numpy()
+    want = oracle.decode_bounds(b16.numpy())
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))

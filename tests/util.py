@@ -1,0 +1,112 @@
+"""Shared helpers of the parity tests: run one configuration through the CPU oracle and through
+the HIP path (via the C ABI) on the same seeded scene and return comparable results."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import oracle
+from oxylus_amd import lib as L
+from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame
+from oxylus_amd.synth import hiz_layout
+
+
+def oracle_hiz(depth_cpu: torch.Tensor, w: int, h: int, levels=None):
+    levels, offs, total = hiz_layout(w, h, levels)
+    data = torch.zeros(total // 4, dtype=torch.float32)
+    oracle.generate_hiz(depth_cpu, data, w, h, levels, offs)
+    return data, levels, offs
+
+
+def oracle_frame(scene_cpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hiz=None, mask=None, run_cull_meshes=False,
+                 two_pass=False, with_triangles=True):
+    """Runs the reference sequence on the CPU oracle.  Returns a dict of numpy arrays."""
+    cam = scene_cpu.cull_camera()
+    res = {}
+    if run_cull_meshes:
+        mli, cmd = oracle.cull_meshes(scene_cpu, cam, cull_flags)
+        res["cull_meshlets_cmd_x"] = int(cmd[0])
+        res["lod_index"] = scene_cpu.mesh_instances[:, 1].numpy().copy()
+    else:
+        mli = scene_cpu.meshlet_instances
+    res["meshlet_instances"] = mli.numpy().copy()
+    n = mli.shape[0]
+    res["total"] = n
+    if not use_hiz:
+        vis = oracle.cull_meshlets(scene_cpu, cam, mli)
+        res["visible"] = vis.numpy().copy()
+        if with_triangles:
+            res["indices"] = oracle.cull_triangles(scene_cpu, cam, mli, vis, 0, vis.numel()).numpy().copy()
+        return res
+    hz = oracle.make_hiz(hiz["data"], hiz["w"], hiz["h"], hiz["levels"], hiz["offs"])
+    v = oracle.Visibility(n, 0, 0)
+    out = torch.zeros(max(n, 1), dtype=torch.int32)
+    mask = mask.clone()
+    passes = [cull_flags, cull_flags | L.CULL_LATE_PASS] if two_pass else [cull_flags]
+    for i, flags in enumerate(passes):
+        tag = "late" if (flags & L.CULL_LATE_PASS) else "early"
+        emitted = oracle.cull_meshlets_hiz(scene_cpu, cam, mli, flags, hz, v, mask, out)
+        first = v.early if (flags & L.CULL_LATE_PASS) else 0
+        res[f"{tag}_emitted"] = emitted
+        res[f"{tag}_visible"] = out[first:first + emitted].numpy().copy()
+        if with_triangles:
+            res[f"{tag}_indices"] = oracle.cull_triangles(scene_cpu, cam, mli, out, first, emitted).numpy().copy()
+    res["early"], res["late"] = v.early, v.late
+    res["mask"] = mask.numpy().copy()
+    return res
+
+
+def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hiz: ImageAttachment = None, mask=None,
+              run_cull_meshes=False, two_pass=False, with_triangles=True):
+    """Same sequence through liboxcull.so.  Returns numpy arrays in the layout of oracle_frame."""
+    frame = PreparedFrame.create(scene_gpu, with_triangles=with_triangles, expand=not run_cull_meshes)
+    if mask is not None:
+        frame.meshlet_instance_visibility_mask_buffer.copy_(mask.to(scene_gpu.device))
+    renderer.prepared_frame = frame
+    cam = scene_gpu.cull_camera()
+    stages = L.STAGE_ALL if with_triangles else (L.STAGE_MESHES | L.STAGE_MESHLETS)
+    ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=run_cull_meshes, cull_flags=cull_flags, cull_camera=cam,
+                              hiz_attachment=hiz, stages=stages)
+    res = {}
+    if not run_cull_meshes:
+        renderer.seed_meshlet_instances(ctx, scene_gpu.n_meshlet_instances)
+    passes = [cull_flags, cull_flags | L.CULL_LATE_PASS] if (use_hiz and two_pass) else [cull_flags]
+    for i, flags in enumerate(passes):
+        ctx.cull_flags = flags
+        if i > 0:
+            ctx.init_cull_meshes = False
+        renderer.cull_geometry(ctx)
+        c = renderer.read_counters(ctx)
+        late = bool(flags & L.CULL_LATE_PASS)
+        tag = ("late" if late else "early") if use_hiz else None
+        first = c.early_visible_meshlet_instances if (use_hiz and late) else 0
+        emitted = c.cull_triangles_cmd_x
+        vis = frame.visible_meshlet_instances_indices_buffer[first:first + emitted].cpu().numpy().copy()
+        idx = frame.reordered_indices_buffer[:c.draw_index_count].cpu().numpy().copy() if with_triangles else None
+        if use_hiz:
+            res[f"{tag}_emitted"] = emitted
+            res[f"{tag}_visible"] = vis
+            if with_triangles:
+                res[f"{tag}_indices"] = idx
+        else:
+            res["visible"] = vis
+            if with_triangles:
+                res["indices"] = idx
+        res["total"] = c.total_visible_meshlet_instances
+        res["cull_meshlets_cmd_x"] = c.cull_meshlets_cmd_x
+        res["early"], res["late"] = c.early_visible_meshlet_instances, c.late_visible_meshlet_instances
+    res["meshlet_instances"] = frame.meshlet_instances_buffer[:res["total"]].cpu().numpy().copy()
+    res["lod_index"] = scene_gpu.mesh_instances[:, 1].cpu().numpy().copy()
+    res["mask"] = frame.meshlet_instance_visibility_mask_buffer.cpu().numpy().copy()
+    return res
+
+
+def assert_same(a: dict, b: dict, keys):
+    for k in keys:
+        x, y = a[k], b[k]
+        if isinstance(x, np.ndarray) or isinstance(y, np.ndarray):
+            x, y = np.asarray(x), np.asarray(y)
+            assert x.shape == y.shape, f"{k}: shape {x.shape} vs {y.shape}"
+            assert np.array_equal(x, y), f"{k}: {int((x != y).sum())} of {x.size} elements differ"
+        else:
+            assert x == y, f"{k}: {x} vs {y}"
