@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""bench.py -- meshlets/s culled on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one RendererInstance::cull_geometry pass over one batch of synthetic input that is
+already resident in HBM.  Default workload = BASELINE.json configs[1]: 1M meshlets (1000 mesh
+instances x 1000 meshlets), one reversed-Z perspective camera, frustum + cone cull + ordered
+compaction (stages = cull_meshlets only).  The 24 MB working set would sit in the 256 MB Infinity
+Cache, so steps rotate over COPIES independent copies of the scene (>= 1 GB) to stay HBM-bound
+(SURVEY.md 8d).  `--workload config3` times the full pipeline (HiZ build + two-pass occlusion +
+triangle cull) on 10M meshlets instead; it is reported in the same format but is not the
+default line.
+
+Extra objects on the line: "roofline" (dominant kernel: algorithmic bytes / HIP-event kernel
+time vs the 8 TB/s HBM peak) and "cpu_baseline" (the scalar C oracle over the same arrays on
+the host cores; a reported baseline, not the target).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from oxylus_amd import lib as L  # noqa: E402
+from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame, RendererInstance  # noqa: E402
+from oxylus_amd.synth import SceneSpec, make_depth, make_scene  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=960)
+    ap.add_argument("--warmup", type=int, default=96)
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3"])
+    ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
+    ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    return ap.parse_args()
+
+
+class Step:
+    """One pre-marshalled cull_geometry call (C structs built once; the hot loop only calls into
+    liboxcull.so)."""
+
+    def __init__(self, r: RendererInstance, scene, stages, use_hiz=False, hiz=None, with_triangles=False):
+        self.scene = scene
+        self.frame = PreparedFrame.create(scene, with_triangles=with_triangles)
+        self.cframe = self.frame.c()
+        self.ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL,
+                                       cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=stages)
+        r.prepared_frame = self.frame
+        r.seed_meshlet_instances(self.ctx, scene.n_meshlet_instances)
+        self.cctx = self.ctx.c()
+        self.pf, self.pc = C.byref(self.cframe), C.byref(self.cctx)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    r = RendererInstance(local_rank)
+    lib, ctxp = r._lib, r._ctx
+    stream = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    full = args.workload == "config3"
+    n_meshlets = args.meshlets or (10_000_000 if full else 1_000_000)
+    K = 1000
+    M = max(1, n_meshlets // K)
+    n_meshlets = M * K
+    spec = SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=full, seed=0x0A1DE5 + 2 + rank,
+                     tris_per_meshlet=64)
+    with torch.cuda.stream(stream):
+        base = make_scene(spec, dev)
+        bytes_per_copy = n_meshlets * 24 + (M * 212)
+        if full:
+            copies = args.copies or 1  # 10M meshlets + geometry is ~10 GB: far beyond the Infinity Cache already
+        else:
+            copies = args.copies or max(2, -(-1_150_000_000 // bytes_per_copy))
+        scenes = [base] + [base.clone() for _ in range(copies - 1)]
+        r.reserve(M, n_meshlets)
+        hiz = depth = None
+        if full:
+            depth = ImageAttachment.depth(make_depth(8192, 8192, 64, seed=3, device=dev))
+            hiz = ImageAttachment.hiz(4096, 4096, dev)
+        stages = L.STAGE_ALL if full else L.STAGE_MESHLETS
+        steps = [Step(r, s, stages, use_hiz=full, hiz=hiz, with_triangles=full) for s in scenes]
+        if full:
+            g = torch.Generator(device=dev).manual_seed(5)
+            for st in steps:  # random prior-visibility mask, p = 0.3 (config 3 restatement)
+                words = st.frame.meshlet_instance_visibility_mask_buffer.numel()
+                bits = (torch.rand((words, 32), generator=g, device=dev) < 0.3).to(torch.int64)
+                st.frame.meshlet_instance_visibility_mask_buffer.copy_((bits << torch.arange(32, device=dev)).sum(1).to(torch.int32))
+            mask0 = [st.frame.meshlet_instance_visibility_mask_buffer.clone() for st in steps]
+    stream.synchronize()
+
+    def check(st):
+        if st != L.OXC_OK:
+            raise RuntimeError(lib.oxc_last_error(ctxp).decode())
+
+    if full:
+        mg = L.MainGeometryContext()
+        mg.struct_size = C.sizeof(L.MainGeometryContext)
+        mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
+        pmg = C.byref(mg)
+
+    def run_step(i):
+        st = steps[i % copies]
+        if not full:
+            check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+            return
+        # config 3: HiZ build, then early + late pass against it (render order of
+        # RendererInstance.cpp:882-884 restated for a given depth + given mask)
+        st.frame.meshlet_instance_visibility_mask_buffer.copy_(mask0[i % copies], non_blocking=True)
+        check(lib.oxc_generate_hiz(ctxp, pmg, sp))
+        st.cctx.cull_flags = L.CULL_TEST_ALL
+        check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+        st.cctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
+        check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+
+    # ---- parity of what is being timed: copy 0 against the CPU oracle (rank 0) ----
+    bit_match = None
+    counts = {}
+    with torch.cuda.stream(stream):
+        run_step(0)
+    stream.synchronize()
+    c0 = r.read_counters(steps[0].ctx, stream)
+    counts = {"total": c0.total_visible_meshlet_instances, "early": c0.early_visible_meshlet_instances,
+              "late": c0.late_visible_meshlet_instances, "emitted": c0.cull_triangles_cmd_x, "index_count": c0.draw_index_count}
+    visible_fraction = (c0.cull_triangles_cmd_x if not full else c0.early_visible_meshlet_instances + c0.late_visible_meshlet_instances) / n_meshlets
+    cpu_scene = None
+    if rank == 0 and not full:
+        import oracle  # checker only
+
+        oracle.build()
+        cpu_scene = base.to("cpu")
+        want = oracle.cull_meshlets(cpu_scene, cpu_scene.cull_camera(), cpu_scene.meshlet_instances, nthreads=os.cpu_count() or 1)
+        got = steps[0].frame.visible_meshlet_instances_indices_buffer[: c0.cull_triangles_cmd_x].cpu()
+        bit_match = bool(want.numel() == got.numel() and torch.equal(want, got))
+
+    # ---- warmup ----
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            run_step(i)
+    stream.synchronize()
+
+    # ---- optional HIP graph over one rotation through the copies ----
+    graph = None
+    per_replay = copies
+    if not args.no_graph and not full and args.steps >= per_replay:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for i in range(per_replay):
+                run_step(i)
+        with torch.cuda.stream(stream):
+            graph.replay()
+        stream.synchronize()
+
+    gathered = None
+    if dist is not None:
+        my_counts = torch.tensor([counts["emitted"], counts["early"], counts["late"], counts["index_count"]], dtype=torch.int32, device=dev)
+        gathered = torch.zeros((world, 4), dtype=torch.int32, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- timed region: EXACTLY args.steps steps ----
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        done = 0
+        if graph is not None:
+            for _ in range(args.steps // per_replay):
+                graph.replay()
+                done += per_replay
+                if dist is not None:  # per-rank visible counts -> every rank (north star's all-gather), bucketed per rotation
+                    dist.all_gather_into_tensor(gathered, my_counts)
+        while done < args.steps:
+            run_step(done)
+            done += 1
+        if dist is not None and graph is None:
+            dist.all_gather_into_tensor(gathered, my_counts)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed_s = float(elapsed.item())
+    value = n_meshlets * world * args.steps / elapsed_s
+    ms_per_step = elapsed_s * 1e3 / args.steps
+
+    # ---- instrumented pass: per-kernel HIP-event times on the same stream, same workload ----
+    prof_steps = min(args.steps, max(copies, 96))
+    r.profile_begin()
+    with torch.cuda.stream(stream):
+        for i in range(prof_steps):
+            run_step(i)
+    prof = r.profile_end()
+    kernels = {}
+    for name, k in prof["kernels"].items():
+        avg_us = (k["total_ms"] / k["launches"] - prof["empty_pair_ms"]) * 1e3
+        kernels[name] = {"launches_per_step": k["launches"] / prof_steps, "avg_us": round(avg_us, 3)}
+
+    # measured streaming-read ceiling of this GPU (16 B/lane sum kernel over 2 GiB)
+    probe = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+    probe.random_(0, 255)
+    with torch.cuda.stream(stream):
+        r.stream_read_probe(probe, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            r.stream_read_probe(probe, stream)
+        e1.record(stream)
+    stream.synchronize()
+    stream_read_gbps = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del probe
+
+    # ---- roofline of the dominant kernel ----
+    if not full:
+        dom = "cull_meshlets_test"
+        # 8 B MeshletInstance + 16 B MeshletBounds read per meshlet + per-mesh tables
+        # 212/K B + 4*v B of visible indices written (the write is done by cull_meshlets_emit; it is
+        # charged to the stage, i.e. to this launch, as 8(d) does).
+        bytes_per_unit = 24.0 + 212.0 / K + 4.0 * visible_fraction
+        units = n_meshlets
+    else:
+        dom = "cull_triangles_test"
+        v_tot = counts["early"] + counts["late"]
+        bytes_per_unit = 4 + 8 + 16 + 3 * 64 + 4 * 64 + 8 * 64  # 988 B per visible meshlet (V=64, T=64), SURVEY 8(d) a11
+        units = v_tot / 2.0  # two launches (early, late) share the visible set
+    dom_us = kernels.get(dom, {}).get("avg_us")
+    roofline = None
+    if dom_us and dom_us > 0:
+        achieved = bytes_per_unit * units / (dom_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": round(bytes_per_unit * units), "kernel_avg_us": dom_us,
+                    "measured_stream_read_GBps": round(stream_read_gbps, 1),
+                    "frac_of_measured_stream_read": round(achieved / stream_read_gbps, 4)}
+
+    # ---- CPU baseline: the scalar C oracle over the same arrays, all host cores ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_scene is not None:
+        import oracle
+
+        cores = os.cpu_count() or 1
+        cam = cpu_scene.cull_camera()
+        n_runs, t_cpu0 = 0, time.perf_counter()
+        while True:
+            oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores)
+            n_runs += 1
+            if time.perf_counter() - t_cpu0 > args.cpu_seconds:
+                break
+        dt = time.perf_counter() - t_cpu0
+        t1c0 = time.perf_counter()
+        oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=1)
+        dt1 = time.perf_counter() - t1c0
+        cpu_baseline = {"value": round(n_meshlets * n_runs / dt, 1), "unit": "meshlets/s", "cores": cores, "kind": "port",
+                        "sample": f"{n_runs} passes of the same {n_meshlets}-meshlet scene (copy 0), oracle/oxcull_oracle.c "
+                                  f"orc_cull_meshlets_mt, {cores} threads, {dt:.1f} s",
+                        "single_thread_value": round(n_meshlets / dt1, 1)}
+
+    if rank == 0:
+        line = {
+            "metric": "meshlets/s culled",
+            "value": round(value, 1),
+            "unit": "meshlets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("configs[1]: 1M meshlets, one camera, frustum+cone cull + ordered compaction (cull_meshlets stage)"
+                             if not full else
+                             "configs[2]: 10M meshlets + 4096^2 HiZ (13 mips) from 8192^2 depth: hiz build + early/late occlusion cull + triangle cull + compaction"),
+                "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K,
+                "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
+                "hip_graph": graph is not None, "visible_fraction": round(visible_fraction, 4),
+                "sharding": f"contiguous range per rank x{world}" if world > 1 else "single GPU",
+            },
+            "bit_match": bit_match,
+            "counts": counts,
+            "kernels": kernels,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,30 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* cont
  * ceiling SURVEY 8d asks to report next to the 8 TB/s spec figure). */
 oxc_status oxc_stream_read_probe(oxc_ctx* ctx, const void* dptr, uint64_t bytes, void* hip_stream);
 
+/* ---- per-kernel timing (bench / profiling; off by default) ----
+ * Between oxc_profile_begin and oxc_profile_end every kernel the context launches is bracketed
+ * by a pair of hipEvents on the caller's stream.  oxc_profile_end synchronises and returns, per
+ * kernel, the launch count and the summed event-to-event time, plus the measured cost of an
+ * empty event pair (`empty_pair_ms`, to be subtracted per launch). */
+enum {
+  OXC_K_PREPARE = 0,
+  OXC_K_MESHES_SCAN = 1,
+  OXC_K_MESHES_EXPAND = 2,
+  OXC_K_MESHLETS_TEST = 3,
+  OXC_K_MESHLETS_EMIT = 4,
+  OXC_K_TRIANGLES_TEST = 5,
+  OXC_K_TRIANGLES_EMIT = 6,
+  OXC_K_HIZ = 7,
+  OXC_K_COUNT = 8
+};
+typedef struct oxc_kernel_times {
+  double total_ms[8];
+  uint32_t launches[8];
+  double empty_pair_ms;
+} oxc_kernel_times;
+oxc_status oxc_profile_begin(oxc_ctx* ctx);
+oxc_status oxc_profile_end(oxc_ctx* ctx, oxc_kernel_times* out);
+
 /* Test hook: decode n GPU::MeshletBounds records with the device's dequantize_half / s8/127
  * routines into 10 floats each {center.xyz, extent.xyz, cone_axis.xyz, cone_cutoff}
  * (scene.slang:401-435) -- lets the known-answer tests sweep all 65536 halfs and 256 s8s. */

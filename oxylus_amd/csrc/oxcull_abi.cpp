@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "oxcull.h"
 #include "oxcull_kernels.hpp"
@@ -48,6 +49,13 @@ struct oxc_ctx {
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
   uint32_t* sink = nullptr;
+  // profiling (oxc_profile_begin/end)
+  bool profiling = false;
+  struct Rec {
+    int id;
+    hipEvent_t a, b;
+  };
+  std::vector<Rec> recs;
 };
 
 namespace {
@@ -118,6 +126,28 @@ uint32_t* next_slot(oxc_ctx* ctx) {
   ctx->slot_cursor++;
   return s;
 }
+
+// Brackets one kernel launch with events while profiling is on.
+struct KernelTimer {
+  oxc_ctx* ctx;
+  hipStream_t s;
+  oxc_ctx::Rec r;
+  bool on;
+  KernelTimer(oxc_ctx* c, int id, hipStream_t st) : ctx(c), s(st), on(c->profiling) {
+    if (!on) return;
+    r.id = id;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(r.a, s);
+  }
+  ~KernelTimer() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    ctx->recs.push_back(r);
+  }
+};
 
 bool image_ok(const oxc_image& im) { return im.dptr && im.width && im.height && im.levels >= 1 && im.levels <= 13; }
 
@@ -193,7 +223,10 @@ oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* c, vo
   if (!tiled && (uint64_t)a.w * a.h > 4096) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: extent must be a multiple of 64 or <= 4096 texels");
   if (tiled && (h.level_offset[0] & 15u)) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: mip 0 must be 16-byte aligned");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
-  launch_hiz(a, static_cast<hipStream_t>(hip_stream));
+  {
+    KernelTimer t(ctx, OXC_K_HIZ, static_cast<hipStream_t>(hip_stream));
+    launch_hiz(a, static_cast<hipStream_t>(hip_stream));
+  }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }
@@ -288,9 +321,16 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.seed_total = 0;
   pa.cam = c->cull_camera;
   const uint32_t prep_threads = std::max(std::max(M, pa.n_supers_tris), 1u);
-  launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), s);
+  {
+    KernelTimer t(ctx, OXC_K_PREPARE, s);
+    launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), s);
+  }
   if (do_meshes) {
-    launch_scan_mesh_counts(ctx->mesh_counts, ctx->mesh_offsets, M, vis, meshlets_cmd, s);
+    {
+      KernelTimer t(ctx, OXC_K_MESHES_SCAN, s);
+      launch_scan_mesh_counts(ctx->mesh_counts, ctx->mesh_offsets, M, vis, meshlets_cmd, s);
+    }
+    KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
     launch_expand(ctx->mesh_counts, ctx->mesh_offsets, M, f->meshlet_instances_buffer.dptr, std::max(std::min(cdiv(M, 4), max_grid), 1u), s);
   }
 
@@ -315,7 +355,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
-    launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
+    {
+      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
+      launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
+    }
     MeshletEmitArgs ea;
     ea.bits = ctx->bits;
     ea.chunk_counts = ctx->m_chunk_counts;
@@ -323,6 +366,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ea.vis = vis;
     ea.tri_cmd = tri_cmd;
     ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
     launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
   }
 
@@ -337,7 +381,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.tri_masks = ctx->tri_masks;
     tt.chunk_counts = ctx->t_chunk_counts;
     tt.supers = ctx->t_supers;
-    launch_tris_test(tt, late, std::min(t_chunks, max_grid), s);
+    {
+      KernelTimer t(ctx, OXC_K_TRIANGLES_TEST, s);
+      launch_tris_test(tt, late, std::min(t_chunks, max_grid), s);
+    }
     TriEmitArgs te;
     te.tri_masks = ctx->tri_masks;
     te.visible = tt.visible;
@@ -347,6 +394,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     te.supers = ctx->t_supers;
     te.draw_cmd = draw_cmd;
     te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
+    KernelTimer t(ctx, OXC_K_TRIANGLES_EMIT, s);
     launch_tris_emit(te, late, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
   }
   OXC_HIP(ctx, hipGetLastError());
@@ -370,6 +418,50 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   out->cull_meshlets_cmd_x = mc[0];
   out->cull_triangles_cmd_x = tc[0];
   out->draw_index_count = dc[0];
+  return OXC_OK;
+}
+
+oxc_status oxc_profile_begin(oxc_ctx* ctx) {
+  if (!ctx) return OXC_INVALID_ARG;
+  ctx->recs.clear();
+  ctx->profiling = true;
+  return OXC_OK;
+}
+
+oxc_status oxc_profile_end(oxc_ctx* ctx, oxc_kernel_times* out) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!out) return fail(ctx, OXC_INVALID_ARG, "profile_end: null out");
+  ctx->profiling = false;
+  std::memset(out, 0, sizeof *out);
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_HIP(ctx, hipDeviceSynchronize());
+  for (auto& r : ctx->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.id >= 0 && r.id < OXC_K_COUNT) {
+      out->total_ms[r.id] += ms;
+      out->launches[r.id] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  ctx->recs.clear();
+  // cost of an empty event pair on an idle stream (subtract per launch)
+  hipEvent_t a, b;
+  OXC_HIP(ctx, hipEventCreate(&a));
+  OXC_HIP(ctx, hipEventCreate(&b));
+  double acc = 0;
+  const int reps = 32;
+  for (int i = 0; i < reps; i++) {
+    OXC_HIP(ctx, hipEventRecord(a, nullptr));
+    OXC_HIP(ctx, hipEventRecord(b, nullptr));
+    OXC_HIP(ctx, hipEventSynchronize(b));
+    float ms = 0.f;
+    OXC_HIP(ctx, hipEventElapsedTime(&ms, a, b));
+    acc += ms;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  out->empty_pair_ms = acc / reps;
   return OXC_OK;
 }
 

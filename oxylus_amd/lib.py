@@ -117,6 +117,8 @@ EXPORTS = [
     "oxc_read_counters",
     "oxc_stream_read_probe",
     "oxc_debug_decode_bounds",
+    "oxc_profile_begin",
+    "oxc_profile_end",
 ]
 
 
@@ -155,11 +157,21 @@ def load() -> C.CDLL:
     lib.oxc_read_counters.argtypes = [vp, C.POINTER(CullGeometryContext), C.POINTER(Counters), vp]
     lib.oxc_stream_read_probe.argtypes = [vp, vp, C.c_uint64, vp]
     lib.oxc_debug_decode_bounds.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.oxc_profile_begin.argtypes = [vp]
+    lib.oxc_profile_end.argtypes = [vp, C.POINTER(KernelTimes)]
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("total_ms", C.c_double * 8), ("launches", C.c_uint32 * 8), ("empty_pair_ms", C.c_double)]
+
+
+KERNEL_NAMES = ["prepare_instances", "cull_meshes_scan", "cull_meshes_expand", "cull_meshlets_test", "cull_meshlets_emit",
+                "cull_triangles_test", "cull_triangles_emit", "hiz"]
 
 
 class OxcError(RuntimeError):

@@ -192,3 +192,15 @@ class RendererInstance:
         out = torch.empty((n, 10), dtype=torch.float32, device=bounds.device)
         self._check(self._lib.oxc_debug_decode_bounds(self._ctx, C.c_void_p(bounds.data_ptr()), n, C.c_void_p(out.data_ptr()), self._stream(None)))
         return out
+
+    def profile_begin(self):
+        self._check(self._lib.oxc_profile_begin(self._ctx))
+
+    def profile_end(self) -> dict:
+        kt = L.KernelTimes()
+        self._check(self._lib.oxc_profile_end(self._ctx, C.byref(kt)))
+        out = {"empty_pair_ms": kt.empty_pair_ms, "kernels": {}}
+        for i, name in enumerate(L.KERNEL_NAMES):
+            if kt.launches[i]:
+                out["kernels"][name] = {"launches": int(kt.launches[i]), "total_ms": float(kt.total_ms[i])}
+        return out
