@@ -320,7 +320,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.init_vis = c->init_cull_meshes ? 1u : 0u;
   pa.seed_total = 0;
   pa.cam = c->cull_camera;
-  const uint32_t prep_threads = std::max(std::max(M, pa.n_supers_tris), 1u);
+  const uint32_t prep_threads = std::max(std::max(M * 8u, pa.n_supers_tris), 1u);  // 8 lanes per mesh instance
   {
     KernelTimer t(ctx, OXC_K_PREPARE, s);
     launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), s);

@@ -174,7 +174,7 @@ OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
 // project_aabb returned none (box crosses the near plane) -- the caller keeps it visible.
 // level_off: float offsets of each mip (LDS or global).
 OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez,
-                           const HizView& hiz, const uint32_t* level_off) {
+                           const HizView& hiz, const uint32_t* level_off, bool active) {
   float SX[4], SY[4], SZ[4], P[8][4];
   float p0x = cx - ex * 0.5f, p0y = cy - ey * 0.5f, p0z = cz - ez * 0.5f;
 #pragma unroll
@@ -197,7 +197,7 @@ OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy
   float depth = P[7][3];
 #pragma unroll
   for (int k = 6; k >= 0; k--) depth = fminf(P[k][3], depth);
-  if (depth < near_clip) return false;  // none -> stays visible (cull_meshlets_hiz.slang:61-65)
+  if (!active || depth < near_clip) return false;  // none -> stays visible (cull_meshlets_hiz.slang:61-65)
 
   float vmin[3], vmax[3];
 #pragma unroll

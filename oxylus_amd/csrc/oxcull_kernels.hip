@@ -84,76 +84,130 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
   for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i] = 0;
   for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i] = 0;
 
-  for (uint32_t mi = tid; mi < a.mesh_instance_count; mi += nthreads) {
-    GpuMeshInstance inst = a.mesh_instances[mi];
-    const GpuMesh mesh = a.meshes[inst.mesh_index];
-    const float* world = a.transforms + (size_t)inst.transform_index * 16;
+  // Eight lanes per mesh instance: lanes 0..5 each normalise one frustum plane (the sqrt +
+  // 4 divides are the long pole), lane 6 writes mvp + world rows, lane 7 the normal matrix,
+  // scale, LOD selection and the resolved LOD pointers.  Uniform code, lane-dependent data.
+  const int lane = threadIdx.x & 63;
+  const uint32_t sub = tid & 7u;
+  const uint32_t ngroups = nthreads >> 3;
+  const uint32_t rounds = (a.mesh_instance_count + ngroups - 1) / ngroups;
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t mi = round * ngroups + (tid >> 3);
+    const bool valid = mi < a.mesh_instance_count;
+    GpuMeshInstance inst = {0, 0, 0, 0, 0};
+    if (valid) inst = a.mesh_instances[mi];
+    GpuMesh mesh = {};
     float w[16], mvp[16];
+    if (valid) {
+      mesh = a.meshes[inst.mesh_index];
+      const float4* wp = reinterpret_cast<const float4*>(a.transforms + (size_t)inst.transform_index * 16);
 #pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = world[k];
+      for (int k = 0; k < 4; k++) {
+        float4 v = wp[k];
+        w[k * 4 + 0] = v.x;
+        w[k * 4 + 1] = v.y;
+        w[k * 4 + 2] = v.z;
+        w[k * 4 + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) w[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    }
     mul_mat4(a.cam.projection_view, w, mvp);
 
-    InstCache c;
-    frustum_planes(mvp, c.planes);
+    // plane `sub` (cull.slang:58-71): {r3+r0, r3-r0, r3+r1, r3-r1, r2, r3-r2}.  x - y == x + (-y)
+    // exactly, so the sign is data; plane 4 is a select, not an add.
+    const uint32_t sel = sub >> 1;  // row 0,0,1,1,2,2 (lanes 6,7: row 3, unused)
+    const bool neg = (sub & 1u) != 0u;
+    float pl[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++) c.mvp[k] = mvp[k];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 4; cc++) c.world[r * 4 + cc] = OXC_M(w, r, cc);
-    normal_matrix(w, c.nm);
-    float sx = len3(OXC_M(w, 0, 0), OXC_M(w, 0, 1), OXC_M(w, 0, 2));
-    float sy = len3(OXC_M(w, 1, 0), OXC_M(w, 1, 1), OXC_M(w, 1, 2));
-    float sz = len3(OXC_M(w, 2, 0), OXC_M(w, 2, 1), OXC_M(w, 2, 2));
-    c.scale_max = fmaxf(sx, fmaxf(sy, sz));
-    c.vis_offset = inst.meshlet_instance_visibility_offset;
-
-    const GpuMeshLOD* lods = reinterpret_cast<const GpuMeshLOD*>(mesh.lods);
-    uint32_t lod_index = inst.lod_index;
-    if (a.do_cull_meshes) {
-      uint32_t meshlet_count = 0;
-      lod_index = 0;
-      if ((a.cull_flags & OXC_CULL_TEST_FRUSTUM) &&
-          test_frustum_planes(c.planes, mesh.aabb_center[0], mesh.aabb_center[1], mesh.aabb_center[2], mesh.aabb_extent[0],
-                              mesh.aabb_extent[1], mesh.aabb_extent[2])) {
-        if (a.cull_flags & OXC_CULL_SELECT_LOD) {  // cull_meshes.slang:35-57
-          float cx = mesh.aabb_center[0], cy = mesh.aabb_center[1], cz = mesh.aabb_center[2];
-          float ex = mesh.aabb_extent[0], ey = mesh.aabb_extent[1], ez = mesh.aabb_extent[2];
-          float wc[3], we[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            wc[r] = ((OXC_M(w, r, 0) * cx + OXC_M(w, r, 1) * cy) + OXC_M(w, r, 2) * cz) + OXC_M(w, r, 3);
-            we[r] = fabsf(((OXC_M(w, r, 0) * ex + OXC_M(w, r, 1) * ey) + OXC_M(w, r, 2) * ez) + OXC_M(w, r, 3) * 0.0f);
-          }
-          float rough = fmaxf(we[0], fmaxf(we[1], we[2]));
-          float dx = wc[0] - a.cam.position[0], dy = wc[1] - a.cam.position[1], dz = wc[2] - a.cam.position[2];
-          float dist = fmaxf(len3(dx, dy, dz) - 0.5f * rough, 0.0f);
-          float pixel_size_at_1m = 2.0f / fmaxf(a.cam.resolution[0], a.cam.resolution[1]);
-          float size_at_1m = rough / dist;
-          float px = size_at_1m / pixel_size_at_1m;
-          for (uint32_t i = 1; i < mesh.lod_count; i++) {
-            float err = px * lods[i].error;
-            if (err < a.cam.acceptable_lod_error)
-              lod_index = i;
-            else
-              break;
-          }
-        }
-        meshlet_count = lods[lod_index].meshlet_count;
-      }
-      a.mesh_counts[mi] = meshlet_count;
-      if (meshlet_count > 0) a.mesh_instances[mi].lod_index = lod_index;  // cull_meshes.slang:76
+    for (int c = 0; c < 4; c++) {
+      float r0 = OXC_M(mvp, 0, c), r1 = OXC_M(mvp, 1, c), r2 = OXC_M(mvp, 2, c), r3 = OXC_M(mvp, 3, c);
+      float rk = sel == 0 ? r0 : (sel == 1 ? r1 : r2);
+      float sum = r3 + (neg ? -rk : rk);
+      pl[c] = sub == 4 ? r2 : sum;
     }
-    const GpuMeshLOD lod = lods[lod_index];
-    c.meshlet_count = lod.meshlet_count;
-    c.bounds = lod.meshlet_bounds;
-    c.meshlets = lod.meshlets;
-    c.micro = lod.local_triangle_indices;
-    c.vidx = lod.indirect_vertex_indices;
-    c.positions = mesh.vertex_positions;
+    {
+      float l = len3(pl[0], pl[1], pl[2]);
 #pragma unroll
-    for (int k = 0; k < 6; k++) c._pad[k] = 0;
-    a.cache[mi] = c;
+      for (int c = 0; c < 4; c++) pl[c] = pl[c] / l;
+    }
+    InstCache* out = a.cache + mi;
+    if (valid && sub < 6) *reinterpret_cast<float4*>(&out->planes[sub * 4]) = make_float4(pl[0], pl[1], pl[2], pl[3]);
+
+    // cull_meshes frustum test of the mesh AABB (cull_meshes.slang:34): lane k tests plane k
+    bool outside = false;
+    if (a.do_cull_meshes) {
+      float hx = mesh.aabb_extent[0] * 0.5f, hy = mesh.aabb_extent[1] * 0.5f, hz = mesh.aabb_extent[2] * 0.5f;
+      float qx = mesh.aabb_center[0] + asf(asu(hx) ^ (asu(pl[0]) & 0x80000000u));
+      float qy = mesh.aabb_center[1] + asf(asu(hy) ^ (asu(pl[1]) & 0x80000000u));
+      float qz = mesh.aabb_center[2] + asf(asu(hz) ^ (asu(pl[2]) & 0x80000000u));
+      outside = sub < 6 && (dot3(qx, qy, qz, pl[0], pl[1], pl[2]) <= -pl[3]);
+    }
+    const uint64_t out_bits = __ballot(outside);
+    const bool in_frustum = ((out_bits >> (lane & ~7)) & 0x3Full) == 0ull;
+
+    if (valid && sub == 6) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        *reinterpret_cast<float4*>(&out->mvp[k * 4]) = make_float4(mvp[k * 4], mvp[k * 4 + 1], mvp[k * 4 + 2], mvp[k * 4 + 3]);
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        *reinterpret_cast<float4*>(&out->world[r * 4]) = make_float4(OXC_M(w, r, 0), OXC_M(w, r, 1), OXC_M(w, r, 2), OXC_M(w, r, 3));
+    }
+    if (valid && sub == 7) {
+      float nm[9];
+      normal_matrix(w, nm);
+#pragma unroll
+      for (int k = 0; k < 9; k++) out->nm[k] = nm[k];
+      float sx = len3(OXC_M(w, 0, 0), OXC_M(w, 0, 1), OXC_M(w, 0, 2));
+      float sy = len3(OXC_M(w, 1, 0), OXC_M(w, 1, 1), OXC_M(w, 1, 2));
+      float sz = len3(OXC_M(w, 2, 0), OXC_M(w, 2, 1), OXC_M(w, 2, 2));
+      out->scale_max = fmaxf(sx, fmaxf(sy, sz));
+      out->vis_offset = inst.meshlet_instance_visibility_offset;
+
+      const GpuMeshLOD* lods = reinterpret_cast<const GpuMeshLOD*>(mesh.lods);
+      uint32_t lod_index = inst.lod_index;
+      if (a.do_cull_meshes) {
+        uint32_t meshlet_count = 0;
+        lod_index = 0;
+        if ((a.cull_flags & OXC_CULL_TEST_FRUSTUM) && in_frustum) {
+          if (a.cull_flags & OXC_CULL_SELECT_LOD) {  // cull_meshes.slang:35-57
+            float cx = mesh.aabb_center[0], cy = mesh.aabb_center[1], cz = mesh.aabb_center[2];
+            float ex = mesh.aabb_extent[0], ey = mesh.aabb_extent[1], ez = mesh.aabb_extent[2];
+            float wc[3], we[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              wc[r] = ((OXC_M(w, r, 0) * cx + OXC_M(w, r, 1) * cy) + OXC_M(w, r, 2) * cz) + OXC_M(w, r, 3);
+              we[r] = fabsf(((OXC_M(w, r, 0) * ex + OXC_M(w, r, 1) * ey) + OXC_M(w, r, 2) * ez) + OXC_M(w, r, 3) * 0.0f);
+            }
+            float rough = fmaxf(we[0], fmaxf(we[1], we[2]));
+            float dx = wc[0] - a.cam.position[0], dy = wc[1] - a.cam.position[1], dz = wc[2] - a.cam.position[2];
+            float dist = fmaxf(len3(dx, dy, dz) - 0.5f * rough, 0.0f);
+            float pixel_size_at_1m = 2.0f / fmaxf(a.cam.resolution[0], a.cam.resolution[1]);
+            float size_at_1m = rough / dist;
+            float px = size_at_1m / pixel_size_at_1m;
+            for (uint32_t i = 1; i < mesh.lod_count; i++) {
+              float err = px * lods[i].error;
+              if (err < a.cam.acceptable_lod_error)
+                lod_index = i;
+              else
+                break;
+            }
+          }
+          meshlet_count = lods[lod_index].meshlet_count;
+        }
+        a.mesh_counts[mi] = meshlet_count;
+        if (meshlet_count > 0) a.mesh_instances[mi].lod_index = lod_index;  // cull_meshes.slang:76
+      }
+      const GpuMeshLOD lod = lods[lod_index];
+      out->meshlet_count = lod.meshlet_count;
+      out->bounds = lod.meshlet_bounds;
+      out->meshlets = lod.meshlets;
+      out->micro = lod.local_triangle_indices;
+      out->vidx = lod.indirect_vertex_indices;
+      out->positions = mesh.vertex_positions;
+    }
   }
 }
 
@@ -281,12 +335,76 @@ OXC_DEV void update_visibility_mask(uint32_t* __restrict__ mask, uint32_t idx, b
   }
 }
 
+// Unpack the wave-loaded cache dwords into SGPRs.
+template <bool NEED_MVP>
+OXC_DEV void unpack_inst(uint32_t v0, uint32_t v1, InstU& u) {
+#pragma unroll
+  for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, k);
+  if (NEED_MVP) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) u.mvp[k] = readlane_f(v0, 24 + k);
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) u.world[k] = readlane_f(v0, 40 + k);
+#pragma unroll
+  for (int k = 0; k < 9; k++) u.nm[k] = readlane_f(v0, 52 + k);
+  u.scale_max = readlane_f(v0, 61);
+  u.vis_offset = readlane_u(v0, 62);
+  u.bounds = (uint64_t)readlane_u(v1, 0) | ((uint64_t)readlane_u(v1, 1) << 32);
+}
+
+struct LaneResult {
+  bool emit;
+  bool visible;
+  uint32_t mask_idx;
+};
+
+// The per-meshlet decision for the lanes in `mine` (all of the same mesh instance `u`).
+// Frustum first (cheap, rejects most), cone only when some lane of the wave still needs it:
+// visible = cone && frustum is order-independent, so the skip changes no result.
+template <bool HIZ, bool OCCL, bool LATE>
+OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4 b, uint32_t meshlet_index, bool mine,
+                           const HizView& hiz, const uint32_t* s_level_off, LaneResult& out) {
+  constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
+  const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16);
+  const float cz = dequantize_half(b.y & 0xFFFFu);
+  const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16);
+  const float ez = dequantize_half(b.w & 0xFFFFu);
+  uint32_t mask_idx = 0;
+  bool was_visible = true;
+  if (HIZ && OCCL && mine) {  // cull_meshlets_hiz.slang:45-51
+    mask_idx = u.vis_offset + meshlet_index;
+    was_visible = ((a.mask[mask_idx >> 5] >> (mask_idx & 31u)) & 1u) != 0u;
+  }
+  bool visible = mine && ((HIZ && !LATE) ? was_visible : true);
+  visible = visible && test_frustum_planes(u.pl, cx, cy, cz, ex, ey, ez);
+  const int32_t cutoff_s8 = (int32_t)b.w >> 24;
+  if (__any(visible && cutoff_s8 != 127)) {  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
+    const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
+    const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127(cutoff_s8);
+    visible = visible && cone_visible(u.world, u.nm, u.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez,
+                                      ax, ay, az, cutoff);
+  }
+  if (HIZ && OCCL_OR_LATE) {
+    if (__any(visible)) {
+      const bool occluded = aabb_occluded(u.mvp, a.near_clip, cx, cy, cz, ex, ey, ez, hiz, s_level_off, visible);
+      visible = visible && !occluded;
+    }
+  }
+  if (mine) {
+    out.emit = HIZ ? (visible && (!LATE || !was_visible)) : visible;
+    out.visible = visible;
+    out.mask_idx = mask_idx;
+  }
+}
+
 template <bool HIZ, bool OCCL, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_level_off[13];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.vis[0];
+  const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
   if (HIZ) {
     if (threadIdx.x < 13) s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
@@ -297,63 +415,71 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   hiz.width = a.hiz_w;
   hiz.height = a.hiz_h;
   hiz.levels = a.hiz_levels;
-
-  constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
-  const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
+  const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    uint32_t cnt = 0;
-#pragma unroll 1
+    // ---- stage A: both MeshletInstance loads of this wave
+    uint32_t group[2], idx[2];
+    bool in[2];
+    uint2 rec[2];
+#pragma unroll
     for (int j = 0; j < 2; j++) {
-      const uint32_t group = chunk * 8 + j * 4 + wave;
-      const uint32_t i = group * 64 + lane;
-      const bool in = i < N;
-      uint32_t mi = 0, meshlet_index = 0;
-      if (in) {
-        uint2 r = reinterpret_cast<const uint2*>(a.meshlet_instances)[i];
-        mi = r.x;
-        meshlet_index = r.y;
+      group[j] = chunk * 8 + j * 4 + wave;
+      idx[j] = group[j] * 64 + lane;
+      in[j] = idx[j] < N;
+      rec[j] = in[j] ? mlis[idx[j]] : make_uint2(0xFFFFFFFFu, 0u);
+    }
+    // ---- stage B: cache rows of the two leading instances (lane 0 holds the lowest index)
+    uint32_t mi_lead[2], v0[2], v1[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      mi_lead[j] = readfirst_u(rec[j].x);
+      const bool any = group[j] < nwords;  // wave-uniform
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + (any ? mi_lead[j] : 0u));
+      v0[j] = p[lane];
+      v1[j] = p[64 + (lane & 15)];
+    }
+    // ---- stage C: bounds of the lanes that belong to the leading instance
+    uint4 bnd[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint64_t bp = (uint64_t)readlane_u(v1[j], 0) | ((uint64_t)readlane_u(v1[j], 1) << 32);
+      bnd[j] = make_uint4(0, 0, 0, 0);
+      if (in[j] && rec[j].x == mi_lead[j]) bnd[j] = reinterpret_cast<const uint4*>(bp)[rec[j].y];
+    }
+    // ---- stage D: decisions
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (group[j] >= nwords) continue;  // wave-uniform
+      LaneResult res;
+      res.emit = false;
+      res.visible = false;
+      res.mask_idx = 0;
+      {
+        InstU u;
+        unpack_inst<HIZ>(v0[j], v1[j], u);
+        const bool mine = in[j] && rec[j].x == mi_lead[j];
+        eval_meshlets<HIZ, OCCL, LATE>(a, u, bnd[j], rec[j].y, mine, hiz, s_level_off, res);
       }
-      bool emit = false;
-      uint32_t mask_idx = 0;
-      bool visible_l = false;
-      uint64_t rem = __ballot(in);
+      // lanes of other mesh instances (a wave straddling instance boundaries): one more round per instance
+      uint64_t rem = __ballot(in[j] && rec[j].x != mi_lead[j]);
       while (rem) {
         const int leader = __ffsll((unsigned long long)rem) - 1;
-        const uint32_t mi_u = readlane_u(mi, leader);
-        const bool mine = in && mi == mi_u;
+        const uint32_t mi_u = readlane_u(rec[j].x, leader);
+        const bool mine = in[j] && rec[j].x == mi_u;
         InstU u;
         load_inst_uniform<HIZ>(a.cache, mi_u, lane, u);
-        if (mine) {
-          const uint4 b = reinterpret_cast<const uint4*>(u.bounds)[meshlet_index];
-          const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16);
-          const float cz = dequantize_half(b.y & 0xFFFFu);
-          const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16);
-          const float ez = dequantize_half(b.w & 0xFFFFu);
-          const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
-          const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127((int32_t)b.w >> 24);
-
-          bool was_visible = true;
-          if (HIZ && OCCL) {  // cull_meshlets_hiz.slang:45-51
-            mask_idx = u.vis_offset + meshlet_index;
-            was_visible = ((a.mask[mask_idx >> 5] >> (mask_idx & 31u)) & 1u) != 0u;
-          }
-          bool visible = (HIZ && !LATE) ? was_visible : true;
-          visible = visible && cone_visible(u.world, u.nm, u.scale_max, camx, camy, camz, cx, cy, cz, ex, ey, ez, ax, ay, az, cutoff);
-          visible = visible && test_frustum_planes(u.pl, cx, cy, cz, ex, ey, ez);
-          if (HIZ && OCCL_OR_LATE && visible) {
-            visible = !aabb_occluded(u.mvp, a.near_clip, cx, cy, cz, ex, ey, ez, hiz, s_level_off);
-          }
-          emit = HIZ ? (visible && (!LATE || !was_visible)) : visible;
-          visible_l = visible;
-        }
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (mine) b = reinterpret_cast<const uint4*>(u.bounds)[rec[j].y];
+        eval_meshlets<HIZ, OCCL, LATE>(a, u, b, rec[j].y, mine, hiz, s_level_off, res);
         rem &= ~__ballot(mine);
       }
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
-      if (HIZ && OCCL) update_visibility_mask(a.mask, mask_idx, visible_l, in, lane);
-      const uint64_t bits = __ballot(emit);
-      if (lane == 0 && group < (N + 63u) / 64u) a.bits[group] = bits;
+      if (HIZ && OCCL) update_visibility_mask(a.mask, res.mask_idx, res.visible, in[j], lane);
+      const uint64_t bits = __ballot(res.emit);
+      if (lane == 0) a.bits[group[j]] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
     // per-chunk survivor count (+ per-super accumulation)
