@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
         l.orc_cull_meshlets.restype = u32
         l.orc_cull_meshlets_mt.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32]
         l.orc_cull_meshlets_mt.restype = u32
+        l.orc_cull_meshlets_mt_passes.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32, u32]
+        l.orc_cull_meshlets_mt_passes.restype = u32
         l.orc_cull_meshlets_hiz.argtypes = [vp, vp, vp, vp, vp, u32, C.POINTER(Hiz), C.POINTER(Visibility), vp, vp, vp]
         l.orc_cull_meshlets_hiz.restype = u32
         l.orc_cull_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp]
@@ -97,27 +99,33 @@ def f32a(x) -> np.ndarray:
 
 
 # ---- scalar function wrappers (KATs) ----
+# NB: keep every converted array in a local until the call returned -- `_p(f32a(x))` alone would
+# hand C a pointer into a temporary that is already freed.
 def dequantize_half(h: int) -> float:
     return lib().orc_dequantize_half(int(h) & 0xFFFF)
 
 
 def test_frustum(mvp, center, extent) -> bool:
-    return bool(lib().orc_test_frustum(_p(f32a(mvp)), _p(f32a(center)), _p(f32a(extent))))
+    m, c, e = f32a(mvp), f32a(center), f32a(extent)
+    return bool(lib().orc_test_frustum(_p(m), _p(c), _p(e)))
 
 
 def test_cone(center, radius, axis, cutoff, cam) -> bool:
-    return bool(lib().orc_test_cone(_p(f32a(center)), float(radius), _p(f32a(axis)), float(cutoff), _p(f32a(cam))))
+    c, a, k = f32a(center), f32a(axis), f32a(cam)
+    return bool(lib().orc_test_cone(_p(c), float(radius), _p(a), float(cutoff), _p(k)))
 
 
 def project_aabb(mvp, near, center, extent):
+    m, c, e = f32a(mvp), f32a(center), f32a(extent)
     out = np.zeros(6, dtype=np.float32)
-    ok = lib().orc_project_aabb(_p(f32a(mvp)), float(near), _p(f32a(center)), _p(f32a(extent)), _p(out))
+    ok = lib().orc_project_aabb(_p(m), float(near), _p(c), _p(e), _p(out))
     return out if ok else None
 
 
 def mul_mat4(a, b) -> np.ndarray:
+    x, y = f32a(a), f32a(b)
     out = np.zeros(16, dtype=np.float32)
-    lib().orc_mul_mat4(_p(f32a(a)), _p(f32a(b)), _p(out))
+    lib().orc_mul_mat4(_p(x), _p(y), _p(out))
     return out
 
 
@@ -131,15 +139,18 @@ def make_hiz(data: np.ndarray, width: int, height: int, levels: int, level_offse
 
 
 def test_occlusion(screen_aabb, hiz: Hiz) -> bool:
-    return bool(lib().orc_test_occlusion(_p(f32a(screen_aabb)), C.byref(hiz)))
+    a = f32a(screen_aabb)
+    return bool(lib().orc_test_occlusion(_p(a), C.byref(hiz)))
 
 
 def occlusion_mip(screen_aabb, hiz: Hiz) -> int:
-    return int(lib().orc_occlusion_mip(_p(f32a(screen_aabb)), C.byref(hiz)))
+    a = f32a(screen_aabb)
+    return int(lib().orc_occlusion_mip(_p(a), C.byref(hiz)))
 
 
 def triangle_backface(clip3x4) -> bool:
-    return bool(lib().orc_test_triangle_backface(_p(f32a(clip3x4))))
+    a = f32a(clip3x4)
+    return bool(lib().orc_test_triangle_backface(_p(a)))
 
 
 def decode_bounds(bounds_i16x8: np.ndarray):
@@ -171,11 +182,12 @@ def cull_meshes(scene, cam, cull_flags: int):
     return out[:total].clone(), cmd
 
 
-def cull_meshlets(scene, cam, meshlet_instances: torch.Tensor, nthreads: int = 1, stats: MarginStats = None) -> torch.Tensor:
+def cull_meshlets(scene, cam, meshlet_instances: torch.Tensor, nthreads: int = 1, stats: MarginStats = None, passes: int = 1) -> torch.Tensor:
     n = meshlet_instances.shape[0]
     out = torch.zeros(max(n, 1), dtype=torch.int32)
-    if nthreads > 1:
-        cnt = lib().orc_cull_meshlets_mt(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), n, _p(cam), _p(out), nthreads)
+    if nthreads > 1 or passes > 1:
+        cnt = lib().orc_cull_meshlets_mt_passes(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), n, _p(cam), _p(out),
+                                                max(1, nthreads), max(1, passes))
     else:
         cnt = lib().orc_cull_meshlets(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), 0, n, _p(cam), _p(out),
                                       C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))

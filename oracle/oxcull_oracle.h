@@ -159,6 +159,12 @@ uint32_t orc_cull_meshlets_mt(const orc_mesh* meshes, const float* transforms, c
                               const orc_meshlet_instance* meshlet_instances, uint32_t total,
                               const orc_cull_camera* cam, uint32_t* visible_out, uint32_t nthreads);
 
+/* Same result; every thread repeats its range `passes` times (CPU-baseline timing without
+ * paying thread start-up per pass). */
+uint32_t orc_cull_meshlets_mt_passes(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                     const orc_meshlet_instance* meshlet_instances, uint32_t total,
+                                     const orc_cull_camera* cam, uint32_t* visible_out, uint32_t nthreads, uint32_t passes);
+
 /* passes/cull_meshlets_hiz.slang:19-88.  vis->early/late updated, mask updated in place,
  * visible_out written at [0,early) (early pass) or [early, early+late) (late pass).
  * Returns number emitted by this pass (= cull_triangles_cmd.x). */

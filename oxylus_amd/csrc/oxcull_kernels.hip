@@ -418,21 +418,22 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // ---- stage A: both MeshletInstance loads of this wave
-    uint32_t group[2], idx[2];
-    bool in[2];
-    uint2 rec[2];
+    // ---- stage A: all MeshletInstance loads of this wave
+    constexpr int G = (int)kGroupsPerWave;
+    uint32_t group[G], idx[G];
+    bool in[G];
+    uint2 rec[G];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      group[j] = chunk * 8 + j * 4 + wave;
+    for (int j = 0; j < G; j++) {
+      group[j] = chunk * (4 * G) + j * 4 + wave;
       idx[j] = group[j] * 64 + lane;
       in[j] = idx[j] < N;
       rec[j] = in[j] ? mlis[idx[j]] : make_uint2(0xFFFFFFFFu, 0u);
     }
-    // ---- stage B: cache rows of the two leading instances (lane 0 holds the lowest index)
-    uint32_t mi_lead[2], v0[2], v1[2];
+    // ---- stage B: cache rows of the leading instances (lane 0 holds the lowest index)
+    uint32_t mi_lead[G], v0[G], v1[G];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < G; j++) {
       mi_lead[j] = readfirst_u(rec[j].x);
       const bool any = group[j] < nwords;  // wave-uniform
       const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + (any ? mi_lead[j] : 0u));
@@ -440,9 +441,9 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
       v1[j] = p[64 + (lane & 15)];
     }
     // ---- stage C: bounds of the lanes that belong to the leading instance
-    uint4 bnd[2];
+    uint4 bnd[G];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < G; j++) {
       const uint64_t bp = (uint64_t)readlane_u(v1[j], 0) | ((uint64_t)readlane_u(v1[j], 1) << 32);
       bnd[j] = make_uint4(0, 0, 0, 0);
       if (in[j] && rec[j].x == mi_lead[j]) bnd[j] = reinterpret_cast<const uint4*>(bp)[rec[j].y];
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
     // ---- stage D: decisions
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < G; j++) {
       if (group[j] >= nwords) continue;  // wave-uniform
       LaneResult res;
       res.emit = false;
@@ -842,7 +843,12 @@ __global__ __launch_bounds__(256) void k_seed_slot(uint32_t* slot, uint32_t tota
 __global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ p, uint64_t n16, uint32_t* sink) {
   uint32_t acc = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16 B loads in flight per lane
+    uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) {
     uint4 v = p[i];
     acc ^= v.x ^ v.y ^ v.z ^ v.w;
   }

@@ -66,7 +66,8 @@ enum : uint32_t {
 };
 
 // Work decomposition constants (see DESIGN.md "ordered compaction").
-constexpr uint32_t kMeshletChunk = 512;      // meshlets per block iteration of the test kernel (8 ballot words)
+constexpr uint32_t kGroupsPerWave = 4;       // 64-meshlet groups each wave keeps in flight per block iteration
+constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block iteration of the test kernel
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
 constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel

@@ -1,0 +1,147 @@
+// RendererInstance.hpp -- C++ drop-in shim over the C ABI (include/oxcull.h).
+//
+// Keeps the reference's names and field meaning for the cull path so that the engine-side
+// code of RendererInstance::render (Oxylus/src/Render/RendererInstance.cpp:793-884) compiles
+// against it with `vuk::Value<vuk::Buffer>` replaced by `ox::amd::Buffer` (device pointer +
+// size) and `vuk::Value<vuk::ImageAttachment>` by `ox::amd::ImageAttachment` (linear mip
+// chain).  Mirrors:
+//   GPU::CullFlag / GPU::CullCamera           Oxylus/include/Scene/SceneGPU.hpp:222-229,345-353
+//   PreparedFrame                             Oxylus/include/Render/RendererInstance.hpp:143-169
+//   CullGeometryContext / MainGeometryContext Oxylus/include/Render/RendererInstance.hpp:171-216
+//   RendererInstance::generate_hiz / cull_geometry            ...RendererInstance.hpp:397-398
+// Error behaviour: the reference's entry points return void and abort through OX_CHECK_* on
+// programmer errors (Oxylus/include/Utils/Log.hpp:38-47); the shim throws std::runtime_error
+// carrying oxc_last_error() instead of aborting.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "oxcull.h"
+
+namespace ox::amd {
+
+namespace GPU {
+enum struct CullFlag : uint32_t {
+  None = 0,
+  TestFrustum = 1 << 0,
+  SelectLOD = 1 << 1,
+  TestOcclusion = 1 << 2,
+  LatePass = 1 << 3,
+  TestAll = TestFrustum | SelectLOD | TestOcclusion,
+};
+constexpr CullFlag operator|(CullFlag a, CullFlag b) { return static_cast<CullFlag>(static_cast<uint32_t>(a) | static_cast<uint32_t>(b)); }
+constexpr CullFlag& operator|=(CullFlag& a, CullFlag b) { return a = a | b; }
+constexpr bool operator&(CullFlag a, CullFlag b) { return (static_cast<uint32_t>(a) & static_cast<uint32_t>(b)) != 0; }
+
+using CullCamera = oxc_cull_camera;  // same 96-byte layout as GPU::CullCamera
+static_assert(sizeof(CullCamera) == 96, "GPU::CullCamera is a 96-byte push constant");
+}  // namespace GPU
+
+using Buffer = oxc_buffer;             // stands in for vuk::Value<vuk::Buffer>
+using ImageAttachment = oxc_image;     // stands in for vuk::Value<vuk::ImageAttachment>
+
+struct PreparedFrame {
+  uint32_t mesh_instance_count = 0;
+  uint32_t max_meshlet_instance_count = 0;
+  bool use_mesh_shaders = false;  // the mesh-shader path needs graphics hardware: must stay false
+  Buffer transforms_world_buffer = {};
+  Buffer meshes_buffer = {};
+  Buffer mesh_instances_buffer = {};
+  Buffer meshlet_instances_buffer = {};
+  Buffer visible_meshlet_instances_indices_buffer = {};
+  Buffer meshlet_instance_visibility_mask_buffer = {};
+  Buffer reordered_indices_buffer = {};
+};
+
+struct CullGeometryContext {
+  bool use_hiz = false;
+  bool use_hpb = false;
+  bool init_cull_meshes = false;
+  GPU::CullFlag cull_flags = GPU::CullFlag::TestAll;
+  GPU::CullCamera cull_camera = {};
+  Buffer vsm_clipmaps_buffer = {};
+  Buffer vsm_clipmap_dirty_flags_buffer = {};
+  uint32_t vsm_clipmap_count = 0;
+  ImageAttachment hiz_attachment = {};
+  ImageAttachment hpb_attachment = {};
+  Buffer visibility_buffer = {};
+  Buffer cull_meshlets_cmd_buffer = {};
+  Buffer draw_geometry_cmd_buffer = {};
+  // not in the reference struct (it is a local there, CullGeometry.cpp:125-127): the indirect
+  // dispatch command of cull_triangles, exposed so callers can read the visible-meshlet count
+  Buffer cull_triangles_cmd_buffer = {};
+};
+
+struct MainGeometryContext {
+  GPU::CullFlag cull_flags = GPU::CullFlag::TestAll;
+  GPU::CullCamera cull_camera = {};
+  ImageAttachment depth_attachment = {};
+  ImageAttachment hiz_attachment = {};
+  Buffer draw_geometry_cmd_buffer = {};
+  Buffer visibility_buffer = {};
+};
+
+class RendererInstance {
+public:
+  explicit RendererInstance(int device = 0, void* hip_stream = nullptr) : stream_(hip_stream) {
+    if (oxc_create(device, &ctx_) != OXC_OK) throw std::runtime_error("oxc_create failed");
+  }
+  ~RendererInstance() { oxc_destroy(ctx_); }
+  RendererInstance(const RendererInstance&) = delete;
+  RendererInstance& operator=(const RendererInstance&) = delete;
+
+  PreparedFrame prepared_frame = {};
+
+  void set_stream(void* hip_stream) { stream_ = hip_stream; }
+
+  // Oxylus/src/Render/Passes/CullGeometry.cpp:10-59
+  auto generate_hiz(MainGeometryContext& context) -> void {
+    oxc_main_geometry_context c = {};
+    c.struct_size = sizeof c;
+    c.depth_attachment = context.depth_attachment;
+    c.hiz_attachment = context.hiz_attachment;
+    check(oxc_generate_hiz(ctx_, &c, stream_));
+  }
+
+  // Oxylus/src/Render/Passes/CullGeometry.cpp:61-404
+  auto cull_geometry(CullGeometryContext& context) -> void {
+    if (prepared_frame.use_mesh_shaders) throw std::runtime_error("cull_geometry: the mesh-shader path is not available on the compute-only backend");
+    oxc_prepared_frame f = {};
+    f.mesh_instance_count = prepared_frame.mesh_instance_count;
+    f.max_meshlet_instance_count = prepared_frame.max_meshlet_instance_count;
+    f.meshes_buffer = prepared_frame.meshes_buffer;
+    f.transforms_world_buffer = prepared_frame.transforms_world_buffer;
+    f.mesh_instances_buffer = prepared_frame.mesh_instances_buffer;
+    f.meshlet_instances_buffer = prepared_frame.meshlet_instances_buffer;
+    f.visible_meshlet_instances_indices_buffer = prepared_frame.visible_meshlet_instances_indices_buffer;
+    f.meshlet_instance_visibility_mask_buffer = prepared_frame.meshlet_instance_visibility_mask_buffer;
+    f.reordered_indices_buffer = prepared_frame.reordered_indices_buffer;
+    oxc_cull_geometry_context c = {};
+    c.struct_size = sizeof c;
+    c.use_hiz = context.use_hiz;
+    c.use_hpb = context.use_hpb;
+    c.init_cull_meshes = context.init_cull_meshes;
+    c.cull_flags = static_cast<uint32_t>(context.cull_flags);
+    c.cull_camera = context.cull_camera;
+    c.hiz_attachment = context.hiz_attachment;
+    c.visibility_buffer = context.visibility_buffer;
+    c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
+    check(oxc_cull_geometry(ctx_, &f, &c, stream_));
+    context.visibility_buffer = c.visibility_buffer;
+    context.cull_meshlets_cmd_buffer = c.cull_meshlets_cmd_buffer;
+    context.cull_triangles_cmd_buffer = c.cull_triangles_cmd_buffer;
+    context.draw_geometry_cmd_buffer = c.draw_geometry_cmd_buffer;
+  }
+
+  oxc_ctx* native() { return ctx_; }
+
+private:
+  void check(oxc_status st) {
+    if (st != OXC_OK) throw std::runtime_error(std::string("oxcull: ") + oxc_last_error(ctx_));
+  }
+  oxc_ctx* ctx_ = nullptr;
+  void* stream_ = nullptr;
+};
+
+}  // namespace ox::amd

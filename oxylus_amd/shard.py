@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of the cull path: contiguous ranges of mesh instances, one
+process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  No data-path collective: every rank culls its own shard into shard-local
+compacted buffers with shard-local 24-bit ids.  The two exchanges are an all-gather of the
+per-rank counters and a broadcast of the HiZ pyramid from the rank that built it.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from .synth import Scene
+
+
+def shard_ranges(n_mesh_instances: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [begin, end) mesh-instance ranges, split on instance boundaries so that the
+    meshlet_instance_visibility_offset ranges of different ranks stay disjoint."""
+    return [(n_mesh_instances * r // world, n_mesh_instances * (r + 1) // world) for r in range(world)]
+
+
+def shard_scene(scene: Scene, rank: int, world: int) -> Tuple[Scene, int]:
+    """The sub-scene rank `rank` owns and the global index of its first meshlet instance.
+    Shard-local ids: mesh_instance_index and visibility offsets are rebased to the shard."""
+    a, b = shard_ranges(scene.n_mesh_instances, world)[rank]
+    K = scene.spec.meshlets_per_mesh
+    kw = {}
+    for name in ("bounds", "meshlets", "micro", "vidx", "positions", "lods", "meshes", "transforms"):
+        kw[name] = getattr(scene, name).clone()
+    mesh_instances = scene.mesh_instances[a:b].clone()
+    first_meshlet = a * K
+    mesh_instances[:, 4] -= first_meshlet  # rebase; stays a multiple of K, ranks stay disjoint
+    mli = scene.meshlet_instances[a * K:b * K].clone()
+    mli[:, 0] -= a
+    s = Scene(spec=scene.spec, device=scene.device, camera=scene.camera, n_meshes=scene.n_meshes,
+              lod_meshlet_counts=scene.lod_meshlet_counts, _lod_tables=scene._lod_tables,
+              mesh_instances=mesh_instances.contiguous(), meshlet_instances=mli.contiguous(), **kw)
+    return s.bind(), first_meshlet
+
+
+def exchange_counts(local_counts: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather of the per-rank counters {emitted, early, late, index_count} (int32[4]).
+    Returns int32 [world, 4]; every rank derives its exclusive prefix from it."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n = local_counts.numel()
+    out = torch.zeros(world * n, dtype=local_counts.dtype, device=local_counts.device)  # flat: gloo insists on it
+    dist.all_gather_into_tensor(out, local_counts.contiguous().view(-1), group=group)
+    return out.view(world, n)
+
+
+def exclusive_offsets(all_counts: torch.Tensor) -> torch.Tensor:
+    """Exclusive prefix over ranks: where each rank's lists start in a merged global list."""
+    return torch.cumsum(all_counts, 0) - all_counts
+
+
+def broadcast_hiz(hiz_data: torch.Tensor, src: int = 0, group=None) -> None:
+    """Broadcast the whole pyramid (89.5 MB for 4096^2) from the rank that built it.  The
+    "top mips only" variant is not used: a rank must never sample a mip it does not hold and
+    clamping would change results."""
+    import torch.distributed as dist
+
+    dist.broadcast(hiz_data, src=src, group=group)
+
+
+def merge_visible(local_visible: torch.Tensor, first_meshlet: int) -> torch.Tensor:
+    """Shard-local visible ids -> global meshlet-instance ids."""
+    return local_visible.to(torch.int64) + first_meshlet

@@ -41,3 +41,22 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in src and "oxcull_oracle" not in src, f"{f} references the oracle"
+
+
+def test_cpp_shim_compiles_and_links(tmp_path):
+    """oxylus_amd/host/RendererInstance.hpp (the reference-named C++ surface) builds against the
+    C ABI with plain g++ and links to liboxcull.so."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        import pytest
+
+        pytest.skip("no g++")
+    L.build()
+    exe = str(tmp_path / "shim_check")
+    subprocess.check_call(["g++", "-std=c++20", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oxylus_amd", "host"),
+                           os.path.join(ROOT, "oxylus_amd", "host", "shim_compile_check.cpp"), "-o", exe, "-L" + os.path.join(ROOT, "oxylus_amd"),
+                           "-loxcull", "-Wl,-rpath," + os.path.join(ROOT, "oxylus_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([exe]).decode()
+    assert "shim links" in out

@@ -1,0 +1,334 @@
+"""Known-answer tests of the CPU oracle.  The reference ships no tests or
+vectors for this path, so the expected values here are derived by hand from the reference
+shader text (file:line cited per test), independently of the oracle's code."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oxylus_amd import lib as L
+from oxylus_amd.synth import SceneSpec, hiz_extent_for, hiz_layout, make_scene, perspective_reversed_z
+
+IDENT = np.eye(4, dtype=np.float32).T.reshape(-1)  # column-major identity
+
+
+def col_major(rows):
+    return np.asarray(rows, dtype=np.float32).T.reshape(-1)
+
+
+# ---- B.1 dequantize_half: common/math.slang:193-201 --------------------------------------------
+def test_dequantize_half_all_inputs():
+    h = np.arange(65536, dtype=np.uint16)
+    want = h.view(np.float16).astype(np.float32)
+    exp = (h >> 10) & 0x1F
+    sign = (h.astype(np.uint32) & 0x8000) << 16
+    # denormals (exp == 0) flush to signed zero; everything else is the IEEE value
+    want_bits = np.where(exp == 0, sign, want.view(np.uint32))
+    # NaN payload: (em + 112<<10) << 13 + 112<<23 keeps the mantissa bits in place
+    nan = (exp == 31) & ((h & 0x3FF) != 0)
+    want_bits = np.where(nan, sign | 0x7F800000 | ((h.astype(np.uint32) & 0x3FF) << 13), want_bits)
+    # go through memory (orc_decode_bounds): a float return value crossing ctypes is widened to double,
+    # which quiets signalling NaNs and would hide the payload rule
+    b = np.zeros((65536, 8), dtype=np.uint16)
+    b[:, 0] = h
+    got = oracle.decode_bounds(b.view(np.int16))[:, 0].view(np.uint32)
+    assert np.array_equal(got, want_bits.astype(np.uint32))
+    assert oracle.dequantize_half(0x3C00) == 1.0 and oracle.dequantize_half(0xC000) == -2.0 and oracle.dequantize_half(0x0001) == 0.0
+
+
+def test_decode_bounds_layout():
+    # scene.slang:401-435 / SceneGPU.hpp:84-90: u16x3 centre, i8x2 axis_xy, u16x3 extent, i8 axis_z, i8 cutoff
+    b = np.zeros((1, 8), dtype=np.uint16)
+    b[0, 0:3] = np.array([1.5, -2.0, 0.25], dtype=np.float16).view(np.uint16)
+    b[0, 3] = (127 & 0xFF) | ((-127 & 0xFF) << 8)
+    b[0, 4:7] = np.array([0.5, 1.0, 2.0], dtype=np.float16).view(np.uint16)
+    b[0, 7] = (64 & 0xFF) | ((-1 & 0xFF) << 8)
+    out = oracle.decode_bounds(b.view(np.int16))[0]
+    assert list(out[0:6]) == [1.5, -2.0, 0.25, 0.5, 1.0, 2.0]
+    assert out[6] == np.float32(1.0) and out[7] == np.float32(-1.0)
+    assert out[8] == np.float32(64.0) / np.float32(127.0) and out[9] == np.float32(-1.0) / np.float32(127.0)
+
+
+# ---- B.2 test_frustum: cull.slang:57-84 -------------------------------------------------------
+def test_frustum_identity_touching_is_culled():
+    # identity mvp: planes x>=-1, x<=1, y>=-1, y<=1, z>=0, z<=1; test is `dot <= -w` => touching is culled
+    e = [0.5, 0.5, 0.5]
+    assert oracle.test_frustum(IDENT, [0.0, 0.0, 0.5], e)
+    assert not oracle.test_frustum(IDENT, [-1.25, 0.0, 0.5], e)       # max.x == -1 exactly: touching left
+    assert oracle.test_frustum(IDENT, np.float32([-1.25 + 2**-20, 0.0, 0.5]), e)
+    assert not oracle.test_frustum(IDENT, [1.25, 0.0, 0.5], e)        # touching right
+    assert not oracle.test_frustum(IDENT, [0.0, 1.25, 0.5], e)        # touching top
+    assert not oracle.test_frustum(IDENT, [0.0, -1.25, 0.5], e)
+    assert not oracle.test_frustum(IDENT, [0.0, 0.0, -0.25], e)       # max.z == 0: touching near
+    assert not oracle.test_frustum(IDENT, [0.0, 0.0, 1.25], e)        # min.z == 1: touching far
+    assert oracle.test_frustum(IDENT, [0.0, 0.0, 1.2], e)
+
+
+def test_frustum_uses_rows_and_normalises():
+    # scaled rows: mvp = diag(2,4,1,1): planes row3+-row0 = (+-2,0,0,1)/2 -> |x| < 0.5
+    m = col_major([[2, 0, 0, 0], [0, 4, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert oracle.test_frustum(m, [0.4, 0.0, 0.5], [0.1, 0.1, 0.1])
+    assert not oracle.test_frustum(m, [0.6, 0.0, 0.5], [0.1, 0.1, 0.1])   # min.x = 0.55 > 0.5
+    assert not oracle.test_frustum(m, [0.0, 0.35, 0.5], [0.1, 0.1, 0.1])  # |y| < 0.25
+    # translation lives in column 3 (glm column-major): x' = x + 10
+    t = col_major([[1, 0, 0, 10], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert oracle.test_frustum(t, [-10.0, 0.0, 0.5], [0.5, 0.5, 0.5])
+    assert not oracle.test_frustum(t, [0.0, 0.0, 0.5], [0.5, 0.5, 0.5])
+
+
+def test_frustum_reversed_z_perspective():
+    pv = perspective_reversed_z(60.0, 1.0, 0.1, 1000.0).numpy()
+    assert oracle.test_frustum(pv, [0, 0, -10], [1, 1, 1])
+    assert not oracle.test_frustum(pv, [0, 0, 10], [1, 1, 1])        # behind the camera
+    assert not oracle.test_frustum(pv, [0, 0, -1010], [1, 1, 1])     # beyond far
+    assert not oracle.test_frustum(pv, [100, 0, -10], [1, 1, 1])     # outside the 60 degree cone
+    assert oracle.test_frustum(pv, [5.0, 0, -10], [1, 1, 1])         # tan(30)*10 = 5.77
+
+
+# ---- B.3 test_cone: cull.slang:173-175 --------------------------------------------------------
+def test_cone():
+    cam = [0, 0, 0]
+    # meshlet at z=-10 facing away from the camera (axis -z), tight cone: culled
+    assert oracle.test_cone([0, 0, -10], 0.5, [0, 0, -1], 0.5, cam)
+    # facing the camera: dot = -10 < 0.5*10+0.5
+    assert not oracle.test_cone([0, 0, -10], 0.5, [0, 0, 1], 0.5, cam)
+    # edge: dot(d,axis)=10 >= cutoff*10 + r  <=> r <= 10 - 10*cutoff
+    assert oracle.test_cone([0, 0, -10], 5.0, [0, 0, -1], 0.5, cam)
+    assert not oracle.test_cone([0, 0, -10], 5.0 + 2**-18, [0, 0, -1], 0.5, cam)
+
+
+def test_cone_cutoff_127_skips(oracle_lib):
+    # cull_meshlets.slang:52: cutoff >= 1.0 => cone_visible without evaluating the cone
+    s = make_scene(SceneSpec(n_mesh_instances=1, meshlets_per_mesh=1, with_geometry=False, seed=1))
+    b = s.bounds.view(torch.uint8)
+    s.bounds[0, 0:3] = torch.tensor([0.0, 0.0, 0.0]).to(torch.float16).view(torch.int16)
+    s.bounds[0, 4:7] = torch.tensor([0.2, 0.2, 0.2]).to(torch.float16).view(torch.int16)
+    s.transforms[0] = torch.tensor(col_major([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -10], [0, 0, 0, 1]]))
+    cam = s.cull_camera()
+    b[0, 6], b[0, 7], b[0, 14] = 0, 0, 129  # axis (0,0,-127): facing away
+    b[0, 15] = 64  # cutoff 0.5 -> culled
+    assert oracle.cull_meshlets(s, cam, s.meshlet_instances).numel() == 0
+    b[0, 15] = 127  # cutoff 1.0 -> test skipped -> visible
+    assert oracle.cull_meshlets(s, cam, s.meshlet_instances).numel() == 1
+
+
+def test_world_radius_uses_rows(oracle_lib):
+    # scene.slang:305-310: world[i].xyz is ROW i.  Shear so that rows and columns differ.
+    w = col_major([[1, 3, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    import ctypes as C
+
+    r = oracle.lib().orc_to_world_radius(oracle._p(w), C.c_float(2.0))
+    assert r == np.float32(2.0) * np.sqrt(np.float32(10.0))  # row 0 = (1,3,0); the largest column is only sqrt(10) too but via (3,1,0)
+    w2 = col_major([[1, 0, 0, 0], [3, 1, 0, 0], [0, 0, 0.5, 0], [0, 0, 0, 1]])
+    r2 = oracle.lib().orc_to_world_radius(oracle._p(w2), C.c_float(1.0))
+    assert r2 == np.sqrt(np.float32(10.0))  # row 1 = (3,1,0)
+
+
+# ---- B.4 project_aabb: cull.slang:12-47 -------------------------------------------------------
+def test_project_aabb():
+    pv = perspective_reversed_z(90.0, 1.0, 0.1, 1000.0).numpy()  # tan(45)=1: x_ndc = x / -z, y flipped
+    assert oracle.project_aabb(pv, 0.1, [0, 0, 0], [1, 1, 1]) is None          # straddles the near plane (w < near)
+    assert oracle.project_aabb(pv, 0.1, [0, 0, -0.55], [1, 1, 1]) is None      # nearest w = 0.05 < 0.1
+    a = oracle.project_aabb(pv, 0.1, [0, 0, -10], [2, 2, 2])
+    assert a is not None
+    # nearest face z=-9: |x_ndc| = 1/9 -> uv = 0.5 +- 1/18
+    np.testing.assert_allclose(a[[0, 3]], [0.5 - 1 / 18, 0.5 + 1 / 18], rtol=1e-6)
+    np.testing.assert_allclose(a[[1, 4]], [0.5 - 1 / 18, 0.5 + 1 / 18], rtol=1e-6)
+    # reversed-Z: nearest (z=-9) has the LARGEST depth ~ near/dist
+    assert a[5] > a[2] > 0
+    np.testing.assert_allclose(a[5], (0.1 * 1000 / 999.9) / 9 - 0.1 / 999.9, rtol=1e-5)
+
+
+# ---- B.5 test_occlusion: cull.slang:86-135 ----------------------------------------------------
+def _hiz(size, fill, levels=None):
+    levels, offs, total = hiz_layout(size, size, levels)
+    data = np.full(total // 4, fill, dtype=np.float32)
+    return data, oracle.make_hiz(data, size, size, levels, offs), offs
+
+
+def test_occlusion_mip_selection():
+    data, h, offs = _hiz(256, 0.0)
+    aabb = lambda x0, y0, x1, y1, z=0.5: [x0 / 256, y0 / 256, 0.0, x1 / 256, y1 / 256, z]  # noqa: E731
+    assert oracle.occlusion_mip(aabb(10.2, 10.2, 10.8, 10.8), h) == 0       # single texel: size 0
+    assert oracle.occlusion_mip(aabb(10.2, 10.2, 11.8, 10.8), h) == 0       # size 1 -> log2(1) = 0
+    assert oracle.occlusion_mip(aabb(10.2, 10.2, 12.8, 10.8), h) == 1       # size 2
+    assert oracle.occlusion_mip(aabb(10.2, 10.2, 13.8, 10.8), h) == 2       # size 3 -> ceil(log2 3) = 2
+    assert oracle.occlusion_mip(aabb(10.2, 10.2, 14.8, 10.8), h) == 2       # size 4
+    assert oracle.occlusion_mip(aabb(10.2, 10.2, 15.8, 10.8), h) == 3       # size 5
+    assert oracle.occlusion_mip(aabb(0, 0, 255.9, 255.9), h) == 8           # size 255 -> top mip (9 levels)
+    # fully off-screen right: min_texel = 300 > max_texel = 255 -> u32 wrap -> clamped to the top mip
+    assert oracle.occlusion_mip(aabb(300, 10, 400, 12), h) == 8
+    # off-screen left: max_texel saturates to 0 (negative float -> u32 0)
+    assert oracle.occlusion_mip(aabb(-50, 10.2, -40, 10.8), h) == 0
+
+
+def test_occlusion_threshold_and_sampling():
+    data, h, offs = _hiz(64, 0.0)
+    d = np.float32(0.25)
+    # reversed-Z: occluded iff max.z <= d - 1e-7 where d = min of the 4 taps
+    data[offs[0] // 4: offs[0] // 4 + 64 * 64] = d
+    box = [10.2 / 64, 10.2 / 64, 0.0, 10.8 / 64, 10.8 / 64, 0.0]
+    eps = np.float32(1e-7)
+    box[5] = float(d - eps)
+    assert oracle.test_occlusion(box, h)
+    box[5] = float(np.nextafter(d - eps, np.float32(1)))
+    assert not oracle.test_occlusion(box, h)
+    # one far (0) texel among the four taps makes the box visible: taps of uv=(10/64) at mip 0 are texels 9,10
+    data[offs[0] // 4 + 9 * 64 + 9] = 0.0
+    box[5] = 0.1
+    assert not oracle.test_occlusion(box, h)
+    data[offs[0] // 4 + 9 * 64 + 9] = d
+    assert oracle.test_occlusion(box, h)
+    # HiZ cleared to 0 (first frame): only boxes wholly beyond far can be "occluded"
+    data[:] = 0.0
+    assert not oracle.test_occlusion(box, h)
+    box[5] = -1e-6
+    assert oracle.test_occlusion(box, h)
+
+
+# ---- B.6 HiZ: hiz.slang + RendererInstance.cpp:573-586 -----------------------------------------
+def test_hiz_extent_and_levels():
+    assert hiz_extent_for(3840, 2160) == (2048, 2048)
+    assert hiz_extent_for(1920, 1080) == (1024, 1024)
+    assert hiz_extent_for(2560, 1080) == (2048, 1024)
+    assert hiz_extent_for(8192, 8192) == (4096, 4096)
+    assert hiz_layout(4096, 4096)[0] == 13
+    assert hiz_layout(2048, 1024)[0] == 12
+    assert hiz_layout(64, 64)[0] == 7
+
+
+@pytest.mark.parametrize("size", [64, 256])
+def test_hiz_point_sample_quirk_and_min_pyramid(size):
+    g = torch.Generator().manual_seed(size)
+    depth = torch.rand((2 * size, 2 * size), generator=g)
+    levels, offs, total = hiz_layout(size, size)
+    data = torch.zeros(total // 4)
+    oracle.generate_hiz(depth, data, size, size, levels, offs)
+    d = depth.numpy()
+    # mip 0 = depth texel (min(2x+2, W-1), min(2y+2, H-1)): NEAREST sample at uv=(texel+1)/extent (hiz.slang:92-95)
+    idx = np.minimum(2 * np.arange(size) + 2, 2 * size - 1)
+    want0 = d[np.ix_(idx, idx)]
+    m = data[: size * size].numpy().reshape(size, size)
+    assert np.array_equal(m, want0)
+    # mips k>=1: 2x2 min of the previous mip (hiz.slang:77-83)
+    prev = want0
+    for k in range(1, levels):
+        w = size >> k
+        cur = prev.reshape(w, 2, w, 2).min(axis=(1, 3))
+        got = data[offs[k] // 4: offs[k] // 4 + w * w].numpy().reshape(w, w)
+        assert np.array_equal(got, cur), f"mip {k}"
+        prev = cur
+    assert data[offs[-1] // 4].item() == want0.min()
+
+
+def test_hiz_general_depth_ratio():
+    # 1920x1080 depth -> 1024x1024 HiZ: texel = floor((x+1)/1024 * 1920), clamped
+    depth = torch.arange(1080 * 1920, dtype=torch.float32).reshape(1080, 1920)
+    levels, offs, total = hiz_layout(1024, 1024, 1)
+    data = torch.zeros(total // 4)
+    oracle.generate_hiz(depth, data, 1024, 1024, 1, offs)
+    m = data.reshape(1024, 1024)
+    for (x, y) in [(0, 0), (7, 3), (1023, 1023), (511, 700)]:
+        sx = min((x + 1) * 1920 // 1024, 1919)
+        sy = min((y + 1) * 1080 // 1024, 1079)
+        assert m[y, x].item() == float(sy * 1920 + sx)
+
+
+# ---- B.8 cull_triangles: cull_triangles.slang:27-90, visbuffer.slang:13-14 ---------------------
+def test_triangle_backface_determinant():
+    # determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)) >= 1e-4 => backface
+    ccw = [0, 0, 0.5, 1, 1, 0, 0.5, 1, 0, 1, 0.5, 1]  # det = +1
+    cw = [0, 0, 0.5, 1, 0, 1, 0.5, 1, 1, 0, 0.5, 1]   # det = -1
+    assert oracle.triangle_backface(ccw)
+    assert not oracle.triangle_backface(cw)
+    tiny = [0, 0, 0.5, 1, 0.01, 0, 0.5, 1, 0, 0.0099, 0.5, 1]  # det = 9.9e-5 < 1e-4: kept
+    assert not oracle.triangle_backface(tiny)
+
+
+def test_cull_triangles_packed_indices(oracle_lib):
+    s = make_scene(SceneSpec(n_mesh_instances=1, meshlets_per_mesh=2, seed=3, verts_per_meshlet=4, tris_per_meshlet=3))
+    s.transforms[0] = torch.tensor(IDENT)
+    s.camera["projection_view"] = [float(x) for x in IDENT]  # clip = position
+    # meshlet 1: vertices (x,y,z): z is clip z; w = 1
+    P = torch.tensor([[0, 0, 0.5, 0], [1, 0, 0.5, 0], [0, 1, 0.5, 0], [0, 0, -0.5, 0]], dtype=torch.float32)
+    s.positions[4:8] = P.to(torch.float16).view(torch.int16)
+    m = s.meshlets[1]
+    base = int(m[1])
+    tri = torch.tensor([0, 2, 1,   # det < 0: front-facing, all z >= 0 -> kept
+                        0, 1, 2,   # det = +1 >= 1e-4: backface -> culled
+                        3, 2, 1],  # vertex 3 has clip z < 0 -> culled
+                       dtype=torch.uint8)
+    s.micro[base: base + 9] = tri
+    cam = s.cull_camera()
+    visible = torch.tensor([1], dtype=torch.int32)
+    idx = oracle.cull_triangles(s, cam, s.meshlet_instances, visible, 0, 1)
+    # packed = (meshlet_instance_index << 8) | (t*3 + k)
+    assert idx.tolist() == [(1 << 8) | 0, (1 << 8) | 1, (1 << 8) | 2]
+
+
+# ---- B.9 cull_meshes: cull_meshes.slang:17-85 --------------------------------------------------
+def test_cull_meshes_lod_threshold_and_expansion(oracle_lib):
+    s = make_scene(SceneSpec(n_mesh_instances=3, meshlets_per_mesh=8, lod_count=3, seed=5, with_geometry=False))
+    ident_at = lambda z: torch.tensor(col_major([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, z], [0, 0, 0, 1]]))  # noqa: E731
+    s.transforms[0], s.transforms[1], s.transforms[2] = ident_at(-50.0), ident_at(-50.0), ident_at(50.0)
+    m32 = s.meshes.view(torch.int32)
+    m32[:, 10:13] = torch.zeros(3, 3, dtype=torch.float32).view(torch.int32)
+    m32[:, 13:16] = torch.full((3, 3), 4.0).view(torch.int32)  # extent 4 -> rough = 4, dist = 50 - 2 = 48
+    px = np.float32(4.0) / np.float32(48.0) / (np.float32(2.0) / np.float32(4096.0))  # rough pixel size
+    l32 = s.lods.view(torch.int32)
+    err = lambda v: torch.tensor([v], dtype=torch.float32).view(torch.int32)  # noqa: E731
+    thr = np.float32(2.0) / px
+    assert np.float32(px) * thr == np.float32(2.0)  # the chosen numbers make px*error == 2.0 exactly
+    # mesh 0: LOD1 error exactly at the threshold => `<` fails => stays LOD 0
+    l32[1, 15], l32[2, 15] = err(float(thr)), err(float(thr) / 4)
+    # mesh 1: LOD1 just below => taken; LOD2 above => break
+    l32[4, 15], l32[5, 15] = err(float(np.nextafter(thr, np.float32(0)))), err(float(thr) * 2)
+    cam = s.cull_camera()
+    mli, cmd = oracle.cull_meshes(s, cam, L.CULL_TEST_ALL)
+    assert s.mesh_instances[:, 1].tolist() == [0, 1, 0]
+    # instance 2 is behind the camera: frustum-culled, contributes nothing
+    want = [(0, k) for k in range(8)] + [(1, k) for k in range(4)]
+    assert [tuple(x) for x in mli.tolist()] == want
+    assert cmd.tolist() == [1, 1, 1]
+
+
+# ---- B.7 two-pass sequence ---------------------------------------------------------------------
+def test_two_pass_sequence_static_scene(oracle_lib):
+    from oxylus_amd.synth import make_depth
+    from util import oracle_frame, oracle_hiz
+
+    s = make_scene(SceneSpec(n_mesh_instances=30, meshlets_per_mesh=50, seed=9))
+    hz, levels, offs = oracle_hiz(make_depth(256, 256, 32, seed=9), 128, 128)
+    hizd = {"data": hz, "w": 128, "h": 128, "levels": levels, "offs": offs}
+    mask0 = torch.zeros((s.n_meshlet_instances + 31) // 32, dtype=torch.int32)
+    f0 = oracle_frame(s, use_hiz=True, hiz=hizd, mask=mask0, two_pass=True, with_triangles=False)
+    assert f0["early"] == 0 and f0["late"] > 0
+    f1 = oracle_frame(s, use_hiz=True, hiz=hizd, mask=torch.from_numpy(f0["mask"]), two_pass=True, with_triangles=False)
+    assert f1["late"] == 0 and np.array_equal(f1["early_visible"], f0["late_visible"])
+    assert np.array_equal(f0["mask"], f1["mask"])
+    # mask bits == visible set
+    bits = np.unpackbits(f0["mask"].view(np.uint8), bitorder="little")[: s.n_meshlet_instances]
+    assert np.array_equal(np.nonzero(bits)[0], f0["late_visible"])
+
+
+# ---- config 1 harness --------------------------------------------------------------------------
+def test_entities_update_and_cull():
+    n = 4
+    trs = np.zeros((n, 10), dtype=np.float32)
+    trs[:, 3] = 1.0  # identity quaternion (w,x,y,z)
+    trs[:, 7:10] = 1.0
+    trs[0, 0:3] = [0, 0, -10]
+    trs[1, 0:3] = [1, 0, 0]      # child of 0 -> world (1,0,-10)
+    trs[2, 0:3] = [0, 0, 20]     # child of 1 -> world (1,0,10): behind
+    trs[3, 0:3] = [500, 0, -10]  # root, far to the right
+    parent = np.array([-1, 0, 1, -1], dtype=np.int32)
+    aabb = np.tile(np.array([-0.5, -0.5, -0.5, 0.5, 0.5, 0.5], dtype=np.float32), (n, 1))
+    s = math.sqrt(0.5)
+    planes = np.array([[s, 0, -s, 0], [-s, 0, -s, 0], [0, s, -s, 0], [0, -s, -s, 0], [0, 0, -1, 0.1], [0, 0, 1, -1000]], dtype=np.float32)
+    world = np.zeros((n, 16), dtype=np.float32)
+    vis = np.zeros(n, dtype=np.uint8)
+    nv = oracle.lib().orc_entities_update_and_cull(n, oracle._p(trs), oracle._p(parent), oracle._p(aabb), oracle._p(planes), oracle._p(world), oracle._p(vis))
+    assert vis.tolist() == [1, 1, 0, 0] and nv == 2
+    assert world[2, 12:15].tolist() == [1.0, 0.0, 10.0]
