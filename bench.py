@@ -280,13 +280,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_scene is not None:
         import oracle
 
-        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
         cam = cpu_scene.cull_camera()
         t1c0 = time.perf_counter()
         oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=1)
         dt1 = time.perf_counter() - t1c0
-        # size the sample to ~cpu_seconds of wall time: every thread repeats its contiguous range `passes` times
-        passes = max(1, int(args.cpu_seconds / max(dt1 / cores, 1e-4)))
+        # calibrate on a short multi-threaded run (thread scaling on the box is not known in advance),
+        # then size the sample to ~cpu_seconds of wall time
+        tc = time.perf_counter()
+        oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores, passes=8)
+        per_pass = (time.perf_counter() - tc) / 8
+        passes = int(min(max(1, args.cpu_seconds / max(per_pass, 1e-5)), 1_000_000))
         t_cpu0 = time.perf_counter()
         oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores, passes=passes)
         dt = time.perf_counter() - t_cpu0

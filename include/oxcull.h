@@ -79,6 +79,21 @@ typedef struct oxc_image {
   uint64_t level_offset[13]; /* bytes; hiz.slang binds at most 13 mips (CullGeometry.cpp:24,36-38) */
 } oxc_image;
 
+/* R8UI Texture2DArray with mips (the VSM hierarchical page buffer, `hpb_attachment`): level k
+ * holds `layers` planes of max(1,width>>k) x max(1,height>>k) bytes at byte offset level_offset[k]. */
+typedef struct oxc_image_array_u8 {
+  void* dptr;
+  uint32_t width, height, layers, levels;
+  uint64_t level_offset[13];
+} oxc_image_array_u8;
+
+/* GPU::VirtualClipmap (SceneGPU.hpp:335-339), 76 bytes: the element type of vsm_clipmaps_buffer. */
+typedef struct oxc_virtual_clipmap {
+  float projection_view_mat[16];
+  int32_t page_offset[2];
+  float z_near;
+} oxc_virtual_clipmap;
+
 /* GPU::CullCamera -- 96 B push constant (SceneGPU.hpp:222-229, scene.slang:196-203). */
 typedef struct oxc_cull_camera {
   float projection_view[16]; /* glm::mat4, column-major */
@@ -107,12 +122,18 @@ typedef struct oxc_prepared_frame {
 typedef struct oxc_cull_geometry_context {
   uint32_t struct_size; /* sizeof(oxc_cull_geometry_context), for ABI evolution */
   uint32_t use_hiz;     /* cull_meshlets_hiz path (two-pass occlusion) */
-  uint32_t use_hpb;     /* cull_meshlets_hpb path (VSM) -- not implemented yet: OXC_INVALID_ARG */
+  uint32_t use_hpb;     /* cull_meshlets_hpb path (VSM multi-view page cull) */
   uint32_t init_cull_meshes;
   uint32_t cull_flags;  /* OXC_CULL_* */
   uint32_t stages;      /* OXC_STAGE_*; 0 = all */
   oxc_cull_camera cull_camera;
   oxc_image hiz_attachment; /* read when use_hiz */
+  /* read when use_hpb (RendererInstance.hpp:183-192, Shadowmaps.cpp:433-463) */
+  oxc_image_array_u8 hpb_attachment;
+  oxc_buffer vsm_clipmaps_buffer;            /* oxc_virtual_clipmap[vsm_clipmap_count] */
+  oxc_buffer vsm_clipmap_dirty_flags_buffer; /* u32[vsm_clipmap_count] */
+  uint32_t vsm_clipmap_count;                /* <= 16 */
+  uint32_t _pad0;
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */

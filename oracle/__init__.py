@@ -26,6 +26,15 @@ class Hiz(C.Structure):
                 ("level_offset", C.c_uint64 * 13)]
 
 
+class VirtualClipmap(C.Structure):
+    _fields_ = [("projection_view_mat", C.c_float * 16), ("page_offset", C.c_int32 * 2), ("z_near", C.c_float)]
+
+
+class Hpb(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("layers", C.c_uint32), ("levels", C.c_uint32),
+                ("level_offset", C.c_uint64 * 13)]
+
+
 class Visibility(C.Structure):
     _fields_ = [("total", C.c_uint32), ("early", C.c_uint32), ("late", C.c_uint32)]
 
@@ -72,6 +81,9 @@ def lib() -> C.CDLL:
         l.orc_cull_meshlets_mt_passes.restype = u32
         l.orc_cull_meshlets_hiz.argtypes = [vp, vp, vp, vp, vp, u32, C.POINTER(Hiz), C.POINTER(Visibility), vp, vp, vp]
         l.orc_cull_meshlets_hiz.restype = u32
+        l.orc_test_vsm_page.argtypes = [vp, C.POINTER(Hpb), u32, vp]
+        l.orc_cull_meshlets_hpb.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32, C.POINTER(Hpb), vp]
+        l.orc_cull_meshlets_hpb.restype = u32
         l.orc_cull_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp]
         l.orc_cull_triangles.restype = u32
         l.orc_cull_triangles_mt.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, u32]
@@ -211,3 +223,27 @@ def cull_triangles(scene, cam, meshlet_instances: torch.Tensor, visible: torch.T
         n = lib().orc_cull_triangles(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
                                      _p(cam), _p(out), C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))
     return out[:n].clone()
+
+
+def make_hpb(data: torch.Tensor, width: int, height: int, layers: int, levels: int, level_offset_bytes) -> Hpb:
+    h = Hpb()
+    h.data = data.data_ptr()
+    h.width, h.height, h.layers, h.levels = width, height, layers, levels
+    for k, o in enumerate(level_offset_bytes):
+        h.level_offset[k] = o
+    return h
+
+
+def test_vsm_page(screen_aabb, hpb: Hpb, layer: int, page_offset) -> bool:
+    a = f32a(screen_aabb)
+    po = np.ascontiguousarray(np.asarray(page_offset, dtype=np.int32))
+    return bool(lib().orc_test_vsm_page(_p(a), C.byref(hpb), layer, _p(po)))
+
+
+def cull_meshlets_hpb(scene, cam, meshlet_instances: torch.Tensor, clipmaps: torch.Tensor, dirty: torch.Tensor, hpb: Hpb) -> torch.Tensor:
+    """clipmaps: uint8/int32 tensor holding V x 76-byte GPU::VirtualClipmap records; dirty: int32[V]."""
+    n = meshlet_instances.shape[0]
+    out = torch.zeros(max(n, 1), dtype=torch.int32)
+    cnt = lib().orc_cull_meshlets_hpb(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), n, _p(cam),
+                                      _p(clipmaps), _p(dirty), dirty.numel(), C.byref(hpb), _p(out))
+    return out[:cnt].clone()

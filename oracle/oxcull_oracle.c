@@ -576,6 +576,86 @@ uint32_t orc_cull_meshlets_hiz(const orc_mesh* meshes, const float* transforms, 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * cull_meshlets_hpb -- passes/cull_meshlets_hpb.slang:25-99, cull.slang:137-166,177-179
+ * ---------------------------------------------------------------------------------------- */
+/* ceil(log2(x)) for a float, from its bits: exact (log2 of a power of two is its exponent),
+ * clamped to [0, levels-1]; x <= 0 / NaN -> log2 is -inf/NaN -> the clamp yields 0. */
+static inline uint32_t ceil_log2f_clamped(float x, uint32_t levels) {
+  if (!(x > 0.0f)) return 0u;
+  uint32_t b = f2u(x);
+  int32_t e = (int32_t)((b >> 23) & 0xFFu) - 127;
+  if (((b >> 23) & 0xFFu) == 0u) return 0u; /* denormal: hugely negative */
+  int32_t c = (b & 0x7FFFFFu) ? e + 1 : e;
+  if (c < 0) c = 0;
+  if (c > (int32_t)levels - 1) c = (int32_t)levels - 1;
+  return (uint32_t)c;
+}
+
+/* Nearest, clamped SampleLevel of the R8UI array at an integral mip (CullGeometry.cpp:226) */
+static inline uint8_t hpb_sample(const orc_hpb* hpb, float u, float v, uint32_t layer, uint32_t mip) {
+  uint32_t mw = mip_dim(hpb->width, mip), mh = mip_dim(hpb->height, mip);
+  int32_t x = cvt_i32_sat(floorf(u * (float)mw)), y = cvt_i32_sat(floorf(v * (float)mh));
+  x = CLAMPI(x, 0, (int32_t)mw - 1);
+  y = CLAMPI(y, 0, (int32_t)mh - 1);
+  return hpb->data[hpb->level_offset[mip] + (size_t)layer * mw * mh + (size_t)y * mw + (size_t)x];
+}
+static inline float fractf_(float x) { return x - floorf(x); }
+
+/* cull.slang:137-166 test_vsm_page */
+int orc_test_vsm_page(const float* a, const orc_hpb* hpb, uint32_t layer, const int32_t* page_offset) {
+  float sw = (float)hpb->width, sh = (float)hpb->height;
+  float pox = (float)page_offset[0] / sw, poy = (float)page_offset[1] / sh;
+  float box_w = (a[3] - a[0]) * sw, box_h = (a[4] - a[1]) * sh;
+  uint32_t mip = ceil_log2f_clamped(max2(box_w, box_h), hpb->levels);
+  int tl = hpb_sample(hpb, fractf_(a[0] + pox), fractf_(a[1] + poy), layer, mip) != 0;
+  int tr = hpb_sample(hpb, fractf_(a[3] + pox), fractf_(a[1] + poy), layer, mip) != 0;
+  int bl = hpb_sample(hpb, fractf_(a[0] + pox), fractf_(a[4] + poy), layer, mip) != 0;
+  int br = hpb_sample(hpb, fractf_(a[3] + pox), fractf_(a[4] + poy), layer, mip) != 0;
+  return tl | tr | bl | br;
+}
+
+uint32_t orc_cull_meshlets_hpb(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                               const orc_meshlet_instance* meshlet_instances, uint32_t total, const orc_cull_camera* cam,
+                               const orc_virtual_clipmap* clipmaps, const uint32_t* dirty, uint32_t clipmap_count,
+                               const orc_hpb* hpb, uint32_t* visible_out) {
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < total; i++) {
+    const orc_meshlet_instance* mli = &meshlet_instances[i];
+    const orc_mesh_instance* inst = &mesh_instances[mli->mesh_instance_index];
+    const float* world = xform(transforms, inst->transform_index);
+    float mvp[16];
+    orc_mul_mat4(cam->projection_view, world, mvp);
+    const orc_mesh* mesh = &meshes[inst->mesh_index];
+    const orc_mesh_lod* lod = &((const orc_mesh_lod*)(uintptr_t)mesh->lods)[inst->lod_index];
+    const orc_meshlet_bounds* b = &((const orc_meshlet_bounds*)(uintptr_t)lod->meshlet_bounds)[mli->meshlet_index];
+    float center[3], extent[3], axis[3], cutoff;
+    orc_decode_bounds(b, center, extent, axis, &cutoff);
+    float nm[9], na[3];
+    orc_normal_matrix(world, nm);
+    mul_m3v(nm, axis, na);
+    float l = len3(na);
+    float cone_axis[3] = {na[0] / l, na[1] / l, na[2] / l};
+    /* cull.slang:177-179 test_cone_directional: dot(axis, view_dir) >= cutoff */
+    int cone_visible = cutoff >= 1.0f || !(dot3(cone_axis, cam->position) >= cutoff);
+    if (!(cone_visible && orc_test_frustum(mvp, center, extent))) continue;
+    int visible = 0;
+    for (uint32_t v = 0; v < clipmap_count; v++) {
+      if (dirty[v] == 0u) continue;
+      float cmvp[16], sa[6];
+      orc_mul_mat4(clipmaps[v].projection_view_mat, world, cmvp);
+      if (!orc_test_frustum(cmvp, center, extent)) continue;
+      if (orc_project_aabb(cmvp, clipmaps[v].z_near, center, extent, sa))
+        visible = orc_test_vsm_page(sa, hpb, v, clipmaps[v].page_offset);
+      else
+        visible = 1;
+      if (visible) break;
+    }
+    if (visible) visible_out[n++] = i;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
  * cull_triangles -- passes/cull_triangles.slang:27-90, scene.slang:336-382,478-484,
  * visbuffer.slang:13-14
  * ---------------------------------------------------------------------------------------- */

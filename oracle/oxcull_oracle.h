@@ -173,6 +173,30 @@ uint32_t orc_cull_meshlets_hiz(const orc_mesh* meshes, const float* transforms, 
                                uint32_t cull_flags, const orc_hiz* hiz, orc_visibility* vis, uint32_t* mask,
                                uint32_t* visible_out, orc_margin_stats* stats);
 
+/* GPU::VirtualClipmap (SceneGPU.hpp:335-339), 76 B */
+typedef struct {
+  float projection_view_mat[16];
+  int32_t page_offset[2];
+  float z_near;
+} orc_virtual_clipmap;
+
+/* R8UI Texture2DArray with mips (the hierarchical page buffer), linear: level k holds
+ * `layers` planes of max(1,w>>k) x max(1,h>>k) bytes at data + level_offset[k]. */
+typedef struct {
+  const uint8_t* data;
+  uint32_t width, height, layers, levels;
+  uint64_t level_offset[13]; /* bytes */
+} orc_hpb;
+
+int orc_test_vsm_page(const float* screen_aabb6, const orc_hpb* hpb, uint32_t layer, const int32_t* page_offset2);
+
+/* passes/cull_meshlets_hpb.slang:25-99 (VSM multi-view: visible if ANY dirty clipmap view sees it).
+ * cam->position carries -light_dir (Shadowmaps.cpp:433-455).  Returns the count; ascending. */
+uint32_t orc_cull_meshlets_hpb(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                               const orc_meshlet_instance* meshlet_instances, uint32_t total, const orc_cull_camera* cam,
+                               const orc_virtual_clipmap* clipmaps, const uint32_t* clipmap_dirty_flags, uint32_t clipmap_count,
+                               const orc_hpb* hpb, uint32_t* visible_out);
+
 /* passes/cull_triangles.slang:27-90 over `count` visible slots starting at slot `first`.
  * Returns index_count (3 * passing triangles); reordered_out gets packed indices,
  * meshlets in slot order, triangles ascending within a meshlet. */

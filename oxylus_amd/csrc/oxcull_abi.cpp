@@ -37,6 +37,8 @@ struct oxc_ctx {
   uint64_t arena_bytes = 0;
   uint32_t cap_mesh_instances = 0, cap_meshlets = 0;
   InstCache* cache = nullptr;
+  InstCache* view_cache = nullptr;  // [views][M] rows for use_hpb
+  uint32_t cap_views = 0;
   uint32_t* mesh_counts = nullptr;
   uint32_t* mesh_offsets = nullptr;
   uint64_t* bits = nullptr;
@@ -77,8 +79,9 @@ oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hi
     if (_e != hipSuccess) return fail(ctx, OXC_HIP_ERROR, #expr, _e); \
   } while (0)
 
-oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets) {
-  if (mesh_instances <= ctx->cap_mesh_instances && meshlets <= ctx->cap_meshlets && ctx->arena) return OXC_OK;
+oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets, uint32_t views = 0) {
+  if (mesh_instances <= ctx->cap_mesh_instances && meshlets <= ctx->cap_meshlets && views <= ctx->cap_views && ctx->arena) return OXC_OK;
+  const uint32_t Vw = std::max(views, ctx->cap_views);
   uint32_t M = std::max(std::max(mesh_instances, ctx->cap_mesh_instances), 1u);
   uint32_t N = std::max(std::max(meshlets, ctx->cap_meshlets), 1u);
   const uint32_t m_chunks = cdiv(N, kMeshletChunk), t_chunks = cdiv(N, kTriChunk);
@@ -89,6 +92,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
     return o;
   };
   const uint64_t o_cache = carve((uint64_t)M * sizeof(InstCache));
+  const uint64_t o_vcache = carve((uint64_t)M * Vw * sizeof(InstCache) + 64);
   const uint64_t o_counts = carve((uint64_t)M * 4);
   const uint64_t o_offsets = carve((uint64_t)M * 4);
   const uint64_t o_bits = carve((uint64_t)cdiv(N, 64) * 8);
@@ -108,6 +112,8 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   ctx->arena_bytes = off;
   char* b = static_cast<char*>(ctx->arena);
   ctx->cache = reinterpret_cast<InstCache*>(b + o_cache);
+  ctx->view_cache = reinterpret_cast<InstCache*>(b + o_vcache);
+  ctx->cap_views = Vw;
   ctx->mesh_counts = reinterpret_cast<uint32_t*>(b + o_counts);
   ctx->mesh_offsets = reinterpret_cast<uint32_t*>(b + o_offsets);
   ctx->bits = reinterpret_cast<uint64_t*>(b + o_bits);
@@ -246,7 +252,6 @@ oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c
 oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull_geometry_context* c, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   if (!f || !c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: bad frame/context struct");
-  if (c->use_hpb) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb (cull_meshlets_hpb) is not implemented");
   const uint32_t stages = c->stages ? c->stages : (uint32_t)OXC_STAGE_ALL;
   const uint32_t M = f->mesh_instance_count, N = f->max_meshlet_instance_count;
   const bool do_meshes = c->init_cull_meshes && (stages & OXC_STAGE_MESHES);
@@ -272,11 +277,21 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     if (occl && N && (!f->meshlet_instance_visibility_mask_buffer.dptr))
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing");
   }
+  const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
+  if (c->use_hpb && do_meshlets) {
+    if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
+    if (views == 0 || views > 16) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: vsm_clipmap_count must be 1..16");
+    if (!c->vsm_clipmaps_buffer.dptr || c->vsm_clipmaps_buffer.bytes < (uint64_t)views * sizeof(oxc_virtual_clipmap) || !c->vsm_clipmap_dirty_flags_buffer.dptr)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb needs vsm_clipmaps_buffer / vsm_clipmap_dirty_flags_buffer");
+    const oxc_image_array_u8& h = c->hpb_attachment;
+    if (!h.dptr || !h.width || !h.height || h.layers < views || h.levels < 1 || h.levels > 13)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb without a valid hpb_attachment (layers >= clipmaps, 1..13 levels)");
+  }
   if (!c->init_cull_meshes && (!c->visibility_buffer.dptr || !c->cull_meshlets_cmd_buffer.dptr))
     return fail(ctx, OXC_INVALID_ARG, "cull_geometry: init_cull_meshes=false needs the visibility/cull_meshlets_cmd buffers of the sequence");
 
   OXC_HIP(ctx, hipSetDevice(ctx->device));
-  oxc_status st = ensure_capacity(ctx, M, N);
+  oxc_status st = ensure_capacity(ctx, M, N, views);
   if (st != OXC_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
@@ -320,10 +335,12 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.init_vis = c->init_cull_meshes ? 1u : 0u;
   pa.seed_total = 0;
   pa.cam = c->cull_camera;
+  pa.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
+  pa.view_cache = ctx->view_cache;
   const uint32_t prep_threads = std::max(std::max(M * 8u, pa.n_supers_tris), 1u);  // 8 lanes per mesh instance
   {
     KernelTimer t(ctx, OXC_K_PREPARE, s);
-    launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), s);
+    launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), (c->use_hpb && do_meshlets) ? views : 0u, s);
   }
   if (do_meshes) {
     {
@@ -335,7 +352,42 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   }
 
   // --- meshlet stage: CullGeometry.cpp:129-335
-  if (do_meshlets) {
+  if (do_meshlets && c->use_hpb) {  // CullGeometry.cpp:199-273
+    HpbTestArgs ha;
+    std::memset(&ha, 0, sizeof ha);
+    ha.cache = ctx->cache;
+    ha.view_cache = ctx->view_cache;
+    ha.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
+    ha.vis = vis;
+    ha.bits = ctx->bits;
+    ha.chunk_counts = ctx->m_chunk_counts;
+    ha.supers = ctx->m_supers;
+    ha.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
+    ha.dirty = static_cast<const uint32_t*>(c->vsm_clipmap_dirty_flags_buffer.dptr);
+    ha.clipmap_count = views;
+    ha.mesh_instance_count = M;
+    const oxc_image_array_u8& h = c->hpb_attachment;
+    ha.hpb_data = static_cast<const uint8_t*>(h.dptr);
+    ha.hpb_w = h.width;
+    ha.hpb_h = h.height;
+    ha.hpb_layers = h.layers;
+    ha.hpb_levels = h.levels;
+    for (uint32_t k = 0; k < h.levels && k < 13; k++) ha.hpb_level_off[k] = (uint32_t)h.level_offset[k];
+    std::memcpy(ha.light_dir, c->cull_camera.position, 12);  // camera.position = -light_dir (Shadowmaps.cpp:433-437)
+    {
+      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
+      launch_hpb_test(ha, std::min(m_chunks, max_grid), s);
+    }
+    MeshletEmitArgs ea;
+    ea.bits = ctx->bits;
+    ea.chunk_counts = ctx->m_chunk_counts;
+    ea.supers = ctx->m_supers;
+    ea.vis = vis;
+    ea.tri_cmd = tri_cmd;
+    ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
+    launch_meshlets_emit(ea, false, false, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
+  } else if (do_meshlets) {
     MeshletTestArgs ta;
     std::memset(&ta, 0, sizeof ta);
     ta.cache = ctx->cache;

@@ -28,18 +28,33 @@ OXC_DEV float bperm_f(int src_lane, float v) {
   return asf((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)asu(v)));
 }
 
+// 64-bit device addresses coming out of the reference structs are integers; loading through a
+// generic pointer would emit flat_load (LDS-aperture check, lgkmcnt).  Go through address space 1.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+OXC_DEV uint32_t load_global_u32(uint64_t base, uint32_t index) {
+  return reinterpret_cast<const uint32_t __attribute__((address_space(1)))*>(base)[index];
+}
+OXC_DEV uint2 load_global_u2(uint64_t base, uint32_t index) {
+  u32x2_t v = reinterpret_cast<const u32x2_t __attribute__((address_space(1)))*>(base)[index];
+  return make_uint2(v.x, v.y);
+}
+OXC_DEV uint4 load_global_u4(uint64_t base, uint32_t index) {
+  u32x4_t v = reinterpret_cast<const u32x4_t __attribute__((address_space(1)))*>(base)[index];
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 OXC_DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx + ay * by) + az * bz; }
 OXC_DEV float len3(float x, float y, float z) { return __builtin_sqrtf(dot3(x, y, z, x, y, z)); }
 
 // com::dequantize_half, common/math.slang:193-201 (h in the low 16 bits): denormals flush to
-// signed zero, Inf/NaN keep class and payload.
+// signed zero, everything else is the IEEE value.  v_cvt_f32_f16 gives the IEEE value (4 VALU ops
+// instead of the shader's 10 integer ops); the flush is the |f| < 2^-14 select.  Only signalling
+// NaN inputs differ from the shader's bit formula (the hardware quiets them: payload bit 22 set);
+// no decision can depend on a NaN payload.
 OXC_DEV float dequantize_half(uint32_t h) {
-  uint32_t s = (h & 0x8000u) << 16;
-  int32_t em = (int32_t)(h & 0x7fffu);
-  int32_t r = (em + (112 << 10)) << 13;
-  r = (em < (1 << 10)) ? 0 : r;
-  r += (em >= (31 << 10)) ? (112 << 23) : 0;
-  return asf(s | (uint32_t)r);
+  const float f = (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+  return __builtin_fabsf(f) < 6.103515625e-05f ? asf(asu(f) & 0x80000000u) : f;
 }
 
 // i32(s8) / 127.0 (scene.slang:408-418), correctly rounded.  x * (1/127) alone is wrong for 16
@@ -108,7 +123,9 @@ OXC_DEV void frustum_planes(const float* mvp, float* pl /*24*/) {
   }
 }
 
-// cull.slang:73-83 with pre-normalised planes.
+// cull.slang:73-83 with pre-normalised planes.  (An fma(h, copysign(1,n), c) p-vertex would be
+// bit-identical and one op shorter, but the 18 extra sign SGPRs per instance push the kernel
+// into SGPR spilling -- measured: 48 -> 124 VGPRs -- so the xor form stays.)
 OXC_DEV bool test_frustum_planes(const float* pl, float cx, float cy, float cz, float ex, float ey, float ez) {
   float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
   bool inside = true;
@@ -170,11 +187,9 @@ OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
   return v ? v : 1u;
 }
 
-// cull.slang:12-47 + :86-135.  Returns true when the box is occluded; `projected` false when
-// project_aabb returned none (box crosses the near plane) -- the caller keeps it visible.
-// level_off: float offsets of each mip (LDS or global).
-OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez,
-                           const HizView& hiz, const uint32_t* level_off, bool active) {
+// cull.slang:12-47 project_aabb.  Returns false for `none` (box crosses the near plane).
+// out = {min.u, min.v, min.z, max.u, max.v, max.z}.
+OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez, float* out) {
   float SX[4], SY[4], SZ[4], P[8][4];
   float p0x = cx - ex * 0.5f, p0y = cy - ey * 0.5f, p0z = cz - ez * 0.5f;
 #pragma unroll
@@ -197,8 +212,7 @@ OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy
   float depth = P[7][3];
 #pragma unroll
   for (int k = 6; k >= 0; k--) depth = fminf(P[k][3], depth);
-  if (!active || depth < near_clip) return false;  // none -> stays visible (cull_meshlets_hiz.slang:61-65)
-
+  if (depth < near_clip) return false;
   float vmin[3], vmax[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -213,9 +227,24 @@ OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy
     vmin[j] = lo;
     vmax[j] = hi;
   }
-  float minu = vmin[0] * 0.5f + 0.5f, minv = vmin[1] * 0.5f + 0.5f;
-  float maxu = vmax[0] * 0.5f + 0.5f, maxv = vmax[1] * 0.5f + 0.5f;
-  float maxz = vmax[2];
+  out[0] = vmin[0] * 0.5f + 0.5f;
+  out[1] = vmin[1] * 0.5f + 0.5f;
+  out[2] = vmin[2];
+  out[3] = vmax[0] * 0.5f + 0.5f;
+  out[4] = vmax[1] * 0.5f + 0.5f;
+  out[5] = vmax[2];
+  return true;
+}
+
+// cull.slang:12-47 + :86-135.  Returns true when the box is occluded; a box for which
+// project_aabb returns none stays visible (cull_meshlets_hiz.slang:61-65).  Inactive lanes
+// return before touching memory.  level_off: float offsets of each mip.
+OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez,
+                           const HizView& hiz, const uint32_t* level_off, bool active) {
+  float sa[6];
+  if (!active) return false;
+  if (!project_aabb(mvp, near_clip, cx, cy, cz, ex, ey, ez, sa)) return false;
+  const float minu = sa[0], minv = sa[1], maxu = sa[3], maxv = sa[4], maxz = sa[5];
 
   // test_occlusion, cull.slang:114-135
   float sw = (float)hiz.width, sh = (float)hiz.height;
@@ -247,6 +276,57 @@ OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy
   float p11 = lvl[(size_t)y1 * mw + x1];
   float d = fminf(fminf(p00, p10), fminf(p01, p11));
   return maxz <= d - 1e-7f;
+}
+
+// Hierarchical page buffer: R8UI Texture2DArray with mips, linear (level k: `layers` planes of
+// max(1,w>>k) x max(1,h>>k) bytes at data + level_off[k]).
+struct HpbView {
+  const uint8_t* data;
+  uint32_t width, height, layers, levels;
+};
+
+// ceil(log2(x)) of a float from its bits (exact), clamped to [0, levels-1]; x <= 0 / NaN -> 0.
+OXC_DEV uint32_t ceil_log2f_clamped(float x, uint32_t levels) {
+  if (!(x > 0.0f)) return 0u;
+  uint32_t b = asu(x);
+  uint32_t be = (b >> 23) & 0xFFu;
+  if (be == 0u) return 0u;
+  int32_t c = (int32_t)be - 127 + ((b & 0x7FFFFFu) ? 1 : 0);
+  c = max(c, 0);
+  c = min(c, (int32_t)levels - 1);
+  return (uint32_t)c;
+}
+OXC_DEV uint32_t hpb_sample(const HpbView& h, const uint32_t* level_off, float u, float v, uint32_t layer, uint32_t mip) {
+  uint32_t mw = mip_dim(h.width, mip), mh = mip_dim(h.height, mip);
+  int32_t x = cvt_i32_sat(floorf(u * (float)mw)), y = cvt_i32_sat(floorf(v * (float)mh));
+  x = min(max(x, 0), (int32_t)mw - 1);
+  y = min(max(y, 0), (int32_t)mh - 1);
+  return h.data[(size_t)level_off[mip] + (size_t)layer * mw * mh + (size_t)y * mw + (size_t)x];
+}
+OXC_DEV float fract_f(float x) { return x - floorf(x); }
+
+// cull.slang:137-166 test_vsm_page (nearest, clamped SampleLevel at an integral mip).
+OXC_DEV bool test_vsm_page(const float* a, const HpbView& h, const uint32_t* level_off, uint32_t layer, int32_t pox_i, int32_t poy_i) {
+  float sw = (float)h.width, sh = (float)h.height;
+  float pox = (float)pox_i / sw, poy = (float)poy_i / sh;
+  float box_w = (a[3] - a[0]) * sw, box_h = (a[4] - a[1]) * sh;
+  uint32_t mip = ceil_log2f_clamped(fmaxf(box_w, box_h), h.levels);
+  bool tl = hpb_sample(h, level_off, fract_f(a[0] + pox), fract_f(a[1] + poy), layer, mip) != 0u;
+  bool tr = hpb_sample(h, level_off, fract_f(a[3] + pox), fract_f(a[1] + poy), layer, mip) != 0u;
+  bool bl = hpb_sample(h, level_off, fract_f(a[0] + pox), fract_f(a[4] + poy), layer, mip) != 0u;
+  bool br = hpb_sample(h, level_off, fract_f(a[3] + pox), fract_f(a[4] + poy), layer, mip) != 0u;
+  return tl | tr | bl | br;
+}
+
+// cull_meshlets_hpb.slang:53-54 + cull.slang:177-179: directional cone test.
+OXC_DEV bool cone_visible_directional(const float* nm, float dirx, float diry, float dirz, float ax, float ay, float az, float cutoff) {
+  float nx = (nm[0] * ax + nm[3] * ay) + nm[6] * az;
+  float ny = (nm[1] * ax + nm[4] * ay) + nm[7] * az;
+  float nz = (nm[2] * ax + nm[5] * ay) + nm[8] * az;
+  float l = len3(nx, ny, nz);
+  float kx = nx / l, ky = ny / l, kz = nz / l;
+  bool culled = dot3(kx, ky, kz, dirx, diry, dirz) >= cutoff;
+  return cutoff >= 1.0f || !culled;
 }
 
 }  // namespace oxc

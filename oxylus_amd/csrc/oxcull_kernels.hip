@@ -63,7 +63,18 @@ OXC_DEV uint32_t chunk_base_256(const uint32_t* __restrict__ supers, const uint3
 __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nthreads = gridDim.x * blockDim.x;
-  if (tid == 0) {
+  const uint32_t view = blockIdx.y;  // 0: the cull camera; 1 + v: VSM clipmap v (use_hpb)
+  float pv[16];
+  if (view == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) pv[k] = a.cam.projection_view[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) pv[k] = a.clipmaps[view - 1].projection_view_mat[k];
+  }
+  InstCache* const rows = view == 0 ? a.cache : a.view_cache + (size_t)(view - 1) * a.mesh_instance_count;
+  const bool main_view = view == 0;
+  if (main_view && tid == 0) {
     a.slot[SLOT_TRI_CMD + 0] = 0;
     a.slot[SLOT_TRI_CMD + 1] = 1;
     a.slot[SLOT_TRI_CMD + 2] = 1;
@@ -81,8 +92,11 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
       a.meshlets_cmd[2] = 1;
     }
   }
-  for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i] = 0;
-  for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i] = 0;
+  if (main_view) {
+    for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i] = 0;
+    for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i] = 0;
+  }
+  const bool do_cull_meshes = main_view && a.do_cull_meshes;
 
   // Eight lanes per mesh instance: lanes 0..5 each normalise one frustum plane (the sqrt +
   // 4 divides are the long pole), lane 6 writes mvp + world rows, lane 7 the normal matrix,
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
 #pragma unroll
       for (int k = 0; k < 16; k++) w[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     }
-    mul_mat4(a.cam.projection_view, w, mvp);
+    mul_mat4(pv, w, mvp);
 
     // plane `sub` (cull.slang:58-71): {r3+r0, r3-r0, r3+r1, r3-r1, r2, r3-r2}.  x - y == x + (-y)
     // exactly, so the sign is data; plane 4 is a select, not an add.
@@ -132,12 +146,12 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; c++) pl[c] = pl[c] / l;
     }
-    InstCache* out = a.cache + mi;
+    InstCache* out = rows + mi;
     if (valid && sub < 6) *reinterpret_cast<float4*>(&out->planes[sub * 4]) = make_float4(pl[0], pl[1], pl[2], pl[3]);
 
     // cull_meshes frustum test of the mesh AABB (cull_meshes.slang:34): lane k tests plane k
     bool outside = false;
-    if (a.do_cull_meshes) {
+    if (do_cull_meshes) {
       float hx = mesh.aabb_extent[0] * 0.5f, hy = mesh.aabb_extent[1] * 0.5f, hz = mesh.aabb_extent[2] * 0.5f;
       float qx = mesh.aabb_center[0] + asf(asu(hx) ^ (asu(pl[0]) & 0x80000000u));
       float qy = mesh.aabb_center[1] + asf(asu(hy) ^ (asu(pl[1]) & 0x80000000u));
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
 
       const GpuMeshLOD* lods = reinterpret_cast<const GpuMeshLOD*>(mesh.lods);
       uint32_t lod_index = inst.lod_index;
-      if (a.do_cull_meshes) {
+      if (do_cull_meshes) {
         uint32_t meshlet_count = 0;
         lod_index = 0;
         if ((a.cull_flags & OXC_CULL_TEST_FRUSTUM) && in_frustum) {
@@ -286,6 +300,7 @@ OXC_DEV void load_inst_uniform(const InstCache* __restrict__ cache, uint32_t mi,
   uint32_t v1 = p[64 + (lane & 15)];
 #pragma unroll
   for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, k);
+
   if (NEED_MVP) {
 #pragma unroll
     for (int k = 0; k < 16; k++) u.mvp[k] = readlane_f(v0, 24 + k);
@@ -340,6 +355,7 @@ template <bool NEED_MVP>
 OXC_DEV void unpack_inst(uint32_t v0, uint32_t v1, InstU& u) {
 #pragma unroll
   for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, k);
+
   if (NEED_MVP) {
 #pragma unroll
     for (int k = 0; k < 16; k++) u.mvp[k] = readlane_f(v0, 24 + k);
@@ -418,72 +434,175 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // ---- stage A: all MeshletInstance loads of this wave
+    // ---- stage A: all MeshletInstance loads of this wave (G consecutive 64-meshlet groups)
     constexpr int G = (int)kGroupsPerWave;
     uint32_t group[G], idx[G];
     bool in[G];
     uint2 rec[G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
-      group[j] = chunk * (4 * G) + j * 4 + wave;
+      group[j] = chunk * (4 * G) + wave * G + j;
       idx[j] = group[j] * 64 + lane;
       in[j] = idx[j] < N;
       rec[j] = in[j] ? mlis[idx[j]] : make_uint2(0xFFFFFFFFu, 0u);
     }
-    // ---- stage B: cache rows of the leading instances (lane 0 holds the lowest index)
-    uint32_t mi_lead[G], v0[G], v1[G];
+    // ---- stages B-D: one round per distinct mesh instance among the wave's G*64 meshlets
+    // (usually one; two when the wave straddles an instance boundary).  Per round: cache row ->
+    // SGPRs, all bounds loads of the round issued together, then the decisions.
+    LaneResult res[G];
+    uint64_t pending[G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
-      mi_lead[j] = readfirst_u(rec[j].x);
-      const bool any = group[j] < nwords;  // wave-uniform
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + (any ? mi_lead[j] : 0u));
-      v0[j] = p[lane];
-      v1[j] = p[64 + (lane & 15)];
+      res[j].emit = false;
+      res[j].visible = false;
+      res[j].mask_idx = 0;
+      pending[j] = __ballot(in[j]);
     }
-    // ---- stage C: bounds of the lanes that belong to the leading instance
-    uint4 bnd[G];
+    for (;;) {
+      // leader = first pending lane of the first pending group (wave-uniform)
+      uint32_t mi_u = 0xFFFFFFFFu;
+      bool found = false;
 #pragma unroll
-    for (int j = 0; j < G; j++) {
-      const uint64_t bp = (uint64_t)readlane_u(v1[j], 0) | ((uint64_t)readlane_u(v1[j], 1) << 32);
-      bnd[j] = make_uint4(0, 0, 0, 0);
-      if (in[j] && rec[j].x == mi_lead[j]) bnd[j] = reinterpret_cast<const uint4*>(bp)[rec[j].y];
+      for (int j = 0; j < G; j++) {
+        if (!found && pending[j]) {
+          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)pending[j]) - 1);
+          found = true;
+        }
+      }
+      if (!found) break;
+      InstU u;
+      load_inst_uniform<HIZ>(a.cache, mi_u, lane, u);
+      bool mine[G];
+      uint4 bnd[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        mine[j] = in[j] && rec[j].x == mi_u;
+        bnd[j] = make_uint4(0, 0, 0, 0);
+        if (mine[j]) bnd[j] = load_global_u4(u.bounds, rec[j].y);
+      }
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t m = __ballot(mine[j]);
+        if (m) {  // wave-uniform
+          eval_meshlets<HIZ, OCCL, LATE>(a, u, bnd[j], rec[j].y, mine[j], hiz, s_level_off, res[j]);
+          pending[j] &= ~m;
+        }
+      }
     }
-    // ---- stage D: decisions
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < G; j++) {
       if (group[j] >= nwords) continue;  // wave-uniform
-      LaneResult res;
-      res.emit = false;
-      res.visible = false;
-      res.mask_idx = 0;
-      {
-        InstU u;
-        unpack_inst<HIZ>(v0[j], v1[j], u);
-        const bool mine = in[j] && rec[j].x == mi_lead[j];
-        eval_meshlets<HIZ, OCCL, LATE>(a, u, bnd[j], rec[j].y, mine, hiz, s_level_off, res);
-      }
-      // lanes of other mesh instances (a wave straddling instance boundaries): one more round per instance
-      uint64_t rem = __ballot(in[j] && rec[j].x != mi_lead[j]);
-      while (rem) {
-        const int leader = __ffsll((unsigned long long)rem) - 1;
-        const uint32_t mi_u = readlane_u(rec[j].x, leader);
-        const bool mine = in[j] && rec[j].x == mi_u;
-        InstU u;
-        load_inst_uniform<HIZ>(a.cache, mi_u, lane, u);
-        uint4 b = make_uint4(0, 0, 0, 0);
-        if (mine) b = reinterpret_cast<const uint4*>(u.bounds)[rec[j].y];
-        eval_meshlets<HIZ, OCCL, LATE>(a, u, b, rec[j].y, mine, hiz, s_level_off, res);
-        rem &= ~__ballot(mine);
-      }
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
-      if (HIZ && OCCL) update_visibility_mask(a.mask, res.mask_idx, res.visible, in[j], lane);
-      const uint64_t bits = __ballot(res.emit);
+      if (HIZ && OCCL) update_visibility_mask(a.mask, res[j].mask_idx, res[j].visible, in[j], lane);
+      const uint64_t bits = __ballot(res[j].emit);
       if (lane == 0) a.bits[group[j]] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
     // per-chunk survivor count (+ per-super accumulation)
+    __syncthreads();
+    if (lane == 0) s_red[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      a.chunk_counts[chunk] = c;
+      if (c) atomicAdd(&a.supers[chunk / kChunksPerSuper], c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// VSM multi-view meshlet test (passes/cull_meshlets_hpb.slang:25-99): directional cone +
+// camera frustum, then "visible if ANY dirty clipmap view passes frustum + page-pyramid test".
+// The reference's `break` on the first visible view has no side effect, so the result is the OR
+// over dirty views; views a whole wave no longer needs are skipped.  Output: ballots, expanded
+// by k_cull_meshlets_emit<false,false> like the plain meshlet stage.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
+  __shared__ uint32_t s_red[4];
+  __shared__ uint32_t s_level_off[13];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t N = a.vis[0];
+  const uint32_t nwords = (N + 63u) / 64u;
+  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
+  if (threadIdx.x < 13) s_level_off[threadIdx.x] = a.hpb_level_off[threadIdx.x];
+  __syncthreads();
+  HpbView hpb;
+  hpb.data = a.hpb_data;
+  hpb.width = a.hpb_w;
+  hpb.height = a.hpb_h;
+  hpb.layers = a.hpb_layers;
+  hpb.levels = a.hpb_levels;
+  const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
+  constexpr int G = (int)kGroupsPerWave;
+
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < G; j++) {
+      const uint32_t group = chunk * (4 * G) + wave * G + j;
+      if (group >= nwords) break;  // wave-uniform
+      const uint32_t idx = group * 64 + lane;
+      const bool in = idx < N;
+      const uint2 rec = in ? mlis[idx] : make_uint2(0xFFFFFFFFu, 0u);
+      bool visible = false;
+      uint64_t pending = __ballot(in);
+      while (pending) {
+        const uint32_t mi_u = readlane_u(rec.x, __ffsll((unsigned long long)pending) - 1);
+        const bool mine = in && rec.x == mi_u;
+        // camera row: planes + normal matrix + bounds pointer
+        float pl[24], nm[9];
+        uint64_t bounds;
+        {
+          const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + mi_u);
+          uint32_t v0 = p[lane], v1 = p[64 + (lane & 15)];
+#pragma unroll
+          for (int k = 0; k < 24; k++) pl[k] = readlane_f(v0, k);
+#pragma unroll
+          for (int k = 0; k < 9; k++) nm[k] = readlane_f(v0, 52 + k);
+          bounds = (uint64_t)readlane_u(v1, 0) | ((uint64_t)readlane_u(v1, 1) << 32);
+        }
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (mine) b = load_global_u4(bounds, rec.y);
+        const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16), cz = dequantize_half(b.y & 0xFFFFu);
+        const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16), ez = dequantize_half(b.w & 0xFFFFu);
+        const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
+        const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127((int32_t)b.w >> 24);
+        bool cand = mine && test_frustum_planes(pl, cx, cy, cz, ex, ey, ez);
+        cand = cand && cone_visible_directional(nm, a.light_dir[0], a.light_dir[1], a.light_dir[2], ax, ay, az, cutoff);
+        bool vis = false;
+        for (uint32_t v = 0; v < a.clipmap_count; v++) {
+          if (a.dirty[v] == 0u) continue;          // uniform
+          if (!__any(cand && !vis)) break;         // nobody in the wave still needs a view
+          float vpl[24], vmvp[16];
+          {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(a.view_cache + (size_t)v * a.mesh_instance_count + mi_u);
+            uint32_t v0 = p[lane];
+#pragma unroll
+            for (int k = 0; k < 24; k++) vpl[k] = readlane_f(v0, k);
+#pragma unroll
+            for (int k = 0; k < 16; k++) vmvp[k] = readlane_f(v0, 24 + k);
+          }
+          const oxc_virtual_clipmap* cm = a.clipmaps + v;
+          const float z_near = cm->z_near;
+          const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
+          const bool need = cand && !vis;
+          if (need && test_frustum_planes(vpl, cx, cy, cz, ex, ey, ez)) {
+            float sa[6];
+            if (project_aabb(vmvp, z_near, cx, cy, cz, ex, ey, ez, sa))
+              vis = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
+            else
+              vis = true;
+          }
+        }
+        if (mine) visible = vis;
+        pending &= ~__ballot(mine);
+      }
+      const uint64_t bits = __ballot(visible);
+      if (lane == 0) a.bits[group] = bits;
+      cnt += (uint32_t)__popcll((unsigned long long)bits);
+    }
     __syncthreads();
     if (lane == 0) s_red[wave] = cnt;
     __syncthreads();
@@ -565,7 +684,7 @@ __global__ __launch_bounds__(256) void k_cull_triangles_test(TriTestArgs a) {
         uint2 r = reinterpret_cast<const uint2*>(a.meshlet_instances)[h_mli];
         h_mi = r.x;
         h_meshlets_ptr = a.cache[h_mi].meshlets;
-        h_meshlet = reinterpret_cast<const uint4*>(h_meshlets_ptr)[r.y];
+        h_meshlet = load_global_u4(h_meshlets_ptr, r.y);
       }
     }
     uint32_t cnt = 0;
@@ -596,8 +715,8 @@ __global__ __launch_bounds__(256) void k_cull_triangles_test(TriTestArgs a) {
       // vertex phase: lane = vertex
       float clx = 0.f, cly = 0.f, clz = -1.f, clw = 0.f;
       if ((uint32_t)lane < vertex_count) {
-        uint32_t vid = reinterpret_cast<const uint32_t*>(p_vidx)[vertex_offset + lane];
-        uint2 q = reinterpret_cast<const uint2*>(p_pos)[vid];  // u16x4, stride 8
+        uint32_t vid = load_global_u32(p_vidx, vertex_offset + lane);
+        uint2 q = load_global_u2(p_pos, vid);  // u16x4, stride 8
         float px = dequantize_half(q.x & 0xFFFFu), py = dequantize_half(q.x >> 16), pz = dequantize_half(q.y & 0xFFFFu);
         clx = ((OXC_M(mvp, 0, 0) * px + OXC_M(mvp, 0, 1) * py) + OXC_M(mvp, 0, 2) * pz) + OXC_M(mvp, 0, 3);
         cly = ((OXC_M(mvp, 1, 0) * px + OXC_M(mvp, 1, 1) * py) + OXC_M(mvp, 1, 2) * pz) + OXC_M(mvp, 1, 3);
@@ -609,9 +728,8 @@ __global__ __launch_bounds__(256) void k_cull_triangles_test(TriTestArgs a) {
       uint32_t tri = 0;
       if ((uint32_t)lane < tri_count) {  // scene.slang:336-342,365-372 via aligned dword loads
         const uint32_t boff = tri_offset + (uint32_t)lane * 3u;
-        const uint32_t* m32 = reinterpret_cast<const uint32_t*>(p_micro);
-        uint32_t d0 = m32[boff >> 2];
-        uint32_t d1 = m32[(boff + 2u) >> 2];
+        uint32_t d0 = load_global_u32(p_micro, boff >> 2);
+        uint32_t d1 = load_global_u32(p_micro, (boff + 2u) >> 2);
         tri = __builtin_amdgcn_alignbyte(d1, d0, boff & 3u);
       }
       const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
@@ -842,13 +960,14 @@ __global__ __launch_bounds__(256) void k_seed_slot(uint32_t* slot, uint32_t tota
 
 __global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ p, uint64_t n16, uint32_t* sink) {
   uint32_t acc = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16 B loads in flight per lane
-    uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+  // one contiguous 16 KiB tile per block iteration: four independent 16 B loads in flight per lane
+  const uint64_t tiles = n16 / 1024;
+  for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint4* q = p + t * 1024 + threadIdx.x;
+    uint4 a = q[0], b = q[256], c = q[512], d = q[768];
     acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
   }
-  for (; i < n16; i += stride) {
+  for (uint64_t i = tiles * 1024 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
     uint4 v = p[i];
     acc ^= v.x ^ v.y ^ v.z ^ v.w;
   }
@@ -875,7 +994,9 @@ __global__ __launch_bounds__(256) void k_debug_decode_bounds(const uint4* __rest
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launch_prepare(const PrepareArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_prepare_instances, dim3(grid), dim3(256), 0, s, a); }
+void launch_prepare(const PrepareArgs& a, uint32_t grid, uint32_t views, hipStream_t s) {
+  hipLaunchKernelGGL(k_prepare_instances, dim3(grid, 1 + views), dim3(256), 0, s, a);
+}
 
 void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s) {
   hipLaunchKernelGGL(k_scan_mesh_counts, dim3(1), dim3(1024), 0, s, counts, offsets, n, vis, cmd);
@@ -898,6 +1019,7 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
     hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false>), g, b, 0, s, a);
   }
 }
+void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_cull_meshlets_hpb_test, dim3(grid), dim3(256), 0, s, a); }
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   if (!hiz)

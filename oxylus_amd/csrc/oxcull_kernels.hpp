@@ -28,6 +28,28 @@ struct PrepareArgs {
   uint32_t init_vis;    // write vis/meshlets_cmd initial values
   uint32_t seed_total;  // initial vis.total (0 for the reference flow)
   oxc_cull_camera cam;
+  // multi-view (use_hpb): blockIdx.y = 1 + v computes rows view_cache[v * M + mi] with
+  // clipmaps[v].projection_view_mat in place of the camera matrix
+  const oxc_virtual_clipmap* clipmaps;
+  InstCache* view_cache;
+};
+
+struct HpbTestArgs {
+  const InstCache* cache;
+  const InstCache* view_cache;
+  const GpuMeshletInstance* meshlet_instances;
+  const uint32_t* vis;
+  uint64_t* bits;
+  uint32_t* chunk_counts;
+  uint32_t* supers;
+  const oxc_virtual_clipmap* clipmaps;
+  const uint32_t* dirty;
+  uint32_t clipmap_count;
+  uint32_t mesh_instance_count;
+  const uint8_t* hpb_data;
+  uint32_t hpb_w, hpb_h, hpb_layers, hpb_levels;
+  uint32_t hpb_level_off[13];
+  float light_dir[3];  // camera.position carries -light_dir
 };
 
 struct MeshletTestArgs {
@@ -84,7 +106,8 @@ struct HizArgs {
   uint32_t level_off[13];  // floats
 };
 
-void launch_prepare(const PrepareArgs& a, uint32_t grid, hipStream_t s);
+void launch_prepare(const PrepareArgs& a, uint32_t grid, uint32_t views, hipStream_t s);
+void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s);
 void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s);
 void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, void* out, uint32_t grid, hipStream_t s);
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s);

@@ -39,7 +39,8 @@ static_assert(sizeof(CullCamera) == 96, "GPU::CullCamera is a 96-byte push const
 }  // namespace GPU
 
 using Buffer = oxc_buffer;             // stands in for vuk::Value<vuk::Buffer>
-using ImageAttachment = oxc_image;     // stands in for vuk::Value<vuk::ImageAttachment>
+using ImageAttachment = oxc_image;     // stands in for vuk::Value<vuk::ImageAttachment> (R32F / D32F)
+using ImageArrayAttachment = oxc_image_array_u8;  // the R8UI mip-mapped array `hpb_attachment`
 
 struct PreparedFrame {
   uint32_t mesh_instance_count = 0;
@@ -64,7 +65,7 @@ struct CullGeometryContext {
   Buffer vsm_clipmap_dirty_flags_buffer = {};
   uint32_t vsm_clipmap_count = 0;
   ImageAttachment hiz_attachment = {};
-  ImageAttachment hpb_attachment = {};
+  ImageArrayAttachment hpb_attachment = {};
   Buffer visibility_buffer = {};
   Buffer cull_meshlets_cmd_buffer = {};
   Buffer draw_geometry_cmd_buffer = {};
@@ -125,6 +126,10 @@ public:
     c.cull_flags = static_cast<uint32_t>(context.cull_flags);
     c.cull_camera = context.cull_camera;
     c.hiz_attachment = context.hiz_attachment;
+    c.hpb_attachment = context.hpb_attachment;
+    c.vsm_clipmaps_buffer = context.vsm_clipmaps_buffer;
+    c.vsm_clipmap_dirty_flags_buffer = context.vsm_clipmap_dirty_flags_buffer;
+    c.vsm_clipmap_count = context.vsm_clipmap_count;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));

@@ -42,6 +42,21 @@ class Image(C.Structure):
     ]
 
 
+class ImageArrayU8(C.Structure):
+    _fields_ = [
+        ("dptr", C.c_void_p),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("layers", C.c_uint32),
+        ("levels", C.c_uint32),
+        ("level_offset", C.c_uint64 * 13),
+    ]
+
+
+class VirtualClipmap(C.Structure):
+    _fields_ = [("projection_view_mat", C.c_float * 16), ("page_offset", C.c_int32 * 2), ("z_near", C.c_float)]
+
+
 class CullCamera(C.Structure):
     _fields_ = [
         ("projection_view", C.c_float * 16),
@@ -77,6 +92,11 @@ class CullGeometryContext(C.Structure):
         ("stages", C.c_uint32),
         ("cull_camera", CullCamera),
         ("hiz_attachment", Image),
+        ("hpb_attachment", ImageArrayU8),
+        ("vsm_clipmaps_buffer", Buffer),
+        ("vsm_clipmap_dirty_flags_buffer", Buffer),
+        ("vsm_clipmap_count", C.c_uint32),
+        ("_pad0", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),

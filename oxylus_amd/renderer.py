@@ -60,6 +60,47 @@ class ImageAttachment:
 
 
 @dataclass
+class HpbAttachment:
+    """R8UI Texture2DArray with mips (VSM hierarchical page buffer), linear layout."""
+    data: torch.Tensor  # uint8 1-D
+    width: int
+    height: int
+    layers: int
+    levels: int
+    level_offset: list  # bytes
+
+    @staticmethod
+    def create(width: int, height: int, layers: int, levels: int, device) -> "HpbAttachment":
+        offs, off = [], 0
+        for k in range(levels):
+            offs.append(off)
+            off += layers * max(1, width >> k) * max(1, height >> k)
+            off = (off + 255) // 256 * 256
+        return HpbAttachment(torch.zeros(off, dtype=torch.uint8, device=device), width, height, layers, levels, offs)
+
+    def level(self, k: int) -> torch.Tensor:
+        w, h = max(1, self.width >> k), max(1, self.height >> k)
+        o = self.level_offset[k]
+        return self.data[o:o + self.layers * w * h].view(self.layers, h, w)
+
+    def build_mips(self):
+        """Any-bit pyramid from level 0 (what rmvsm_downsample_hpb produces: a texel is set if
+        any of its 2x2 children is)."""
+        for k in range(1, self.levels):
+            p = self.level(k - 1)
+            w, h = max(1, self.width >> k), max(1, self.height >> k)
+            self.level(k).copy_(p.view(self.layers, h, 2, w, 2).amax(dim=(2, 4)) if p.shape[1] >= 2 and p.shape[2] >= 2 else p.amax(dim=(1, 2), keepdim=True))
+
+    def c(self) -> L.ImageArrayU8:
+        im = L.ImageArrayU8()
+        im.dptr = self.data.data_ptr()
+        im.width, im.height, im.layers, im.levels = self.width, self.height, self.layers, self.levels
+        for k, o in enumerate(self.level_offset):
+            im.level_offset[k] = o
+        return im
+
+
+@dataclass
 class PreparedFrame:
     """The PreparedFrame buffers of the cull path (RendererInstance.hpp:143-169), sized as in
     RendererInstance::update (RendererInstance.cpp:1640-1732)."""
@@ -105,6 +146,10 @@ class CullGeometryContext:
     cull_flags: int = L.CULL_TEST_ALL
     cull_camera: Optional[L.CullCamera] = None
     hiz_attachment: Optional[ImageAttachment] = None
+    hpb_attachment: Optional[HpbAttachment] = None
+    vsm_clipmaps_buffer: Optional[torch.Tensor] = None            # uint8 [V*76] GPU::VirtualClipmap records
+    vsm_clipmap_dirty_flags_buffer: Optional[torch.Tensor] = None  # int32 [V]
+    vsm_clipmap_count: int = 0
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -117,6 +162,11 @@ class CullGeometryContext:
             c.cull_camera = self.cull_camera
         if self.hiz_attachment is not None:
             c.hiz_attachment = self.hiz_attachment.c()
+        if self.hpb_attachment is not None:
+            c.hpb_attachment = self.hpb_attachment.c()
+        c.vsm_clipmaps_buffer = _buf(self.vsm_clipmaps_buffer)
+        c.vsm_clipmap_dirty_flags_buffer = _buf(self.vsm_clipmap_dirty_flags_buffer)
+        c.vsm_clipmap_count = self.vsm_clipmap_count
         return c
 
 

@@ -361,3 +361,57 @@ def make_depth(w: int, h: int, n_quads: int = 64, seed: int = 1, device="cpu", n
         if x1 > x0 and y1 > y0:
             depth[y0:y1, x0:x1] = torch.clamp(depth[y0:y1, x0:x1], min=z)
     return depth
+
+
+# ---------------------------------------------------------------------------------------------
+# VSM (multi-view) helpers: Oxylus/src/Render/Passes/Shadowmaps.cpp:9-63
+# ---------------------------------------------------------------------------------------------
+def virtual_shadow_matrices(camera_position, light_dir, max_shadow_dist: float, first_clipmap_width: float, clipmap_count: int = 10,
+                            page_table_size: int = 64):
+    """calculate_virtual_shadow_matrices restated in float64 numpy (input generation only; the
+    kernels take the resulting float32 matrices).  Returns (float32 [V,16] column-major
+    projection_view_mat, int32 [V,2] page_offset, z_near)."""
+    import numpy as np
+
+    f = -np.asarray(light_dir, dtype=np.float64)
+    f = f / np.linalg.norm(f)
+    up = np.array([0.0, 1.0, 0.0])
+    if 1.0 - abs(float(f @ up)) < 1e-5:
+        up = np.array([0.0, 0.0, 1.0])
+    s = np.cross(f, up)
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    view = np.eye(4)
+    view[0, :3], view[1, :3], view[2, :3] = s, u, -f  # lookAtRH from the origin
+    mats, offs = [], []
+    for i in range(clipmap_count):
+        ext = first_clipmap_width * float(1 << i)
+        n, fa = -max_shadow_dist, max_shadow_dist
+        proj = np.eye(4)  # orthoRH_ZO(-ext, ext, -ext, ext, n, fa)
+        proj[0, 0] = 1.0 / ext
+        proj[1, 1] = -(1.0 / ext)  # proj[1][1] *= -1
+        proj[2, 2] = -1.0 / (fa - n)
+        proj[2, 3] = -n / (fa - n)
+        clip = proj @ view @ np.append(np.asarray(camera_position, dtype=np.float64), 1.0)
+        ndc = clip[:2] / clip[3]
+        page_offset = np.trunc(ndc * 0.5 * page_table_size).astype(np.int32)
+        shift = page_offset.astype(np.float64) / page_table_size * 2.0
+        tr = np.eye(4)
+        tr[0, 3], tr[1, 3] = -shift[0], -shift[1]
+        final_view = np.linalg.inv(proj) @ (tr @ proj) @ view
+        pvm = proj @ final_view
+        mats.append(pvm.T.reshape(-1).astype(np.float32))  # column-major
+        offs.append(page_offset)
+    return np.stack(mats), np.stack(offs), float(-max_shadow_dist)
+
+
+def pack_clipmaps(mats, offs, z_near: float) -> torch.Tensor:
+    """-> uint8 [V*76]: GPU::VirtualClipmap records (SceneGPU.hpp:335-339)."""
+    import numpy as np
+
+    V = mats.shape[0]
+    rec = np.zeros((V, 19), dtype=np.float32)
+    rec[:, :16] = mats
+    rec.view(np.int32)[:, 16:18] = offs
+    rec[:, 18] = z_near
+    return torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
