@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=9600)
     ap.add_argument("--warmup", type=int, default=960)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
+    ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
     ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
@@ -88,17 +89,18 @@ def main():
     sp = C.c_void_p(stream.cuda_stream)
 
     full = args.workload == "config3"
-    n_meshlets = args.meshlets or (10_000_000 if full else 1_000_000)
+    multiview = args.workload == "config5"
+    n_meshlets = args.meshlets or (10_000_000 if (full or multiview) else 1_000_000)
     K = 1000
     M = max(1, n_meshlets // K)
     n_meshlets = M * K
     spec = SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=full, seed=0x0A1DE5 + 2 + rank,
-                     tris_per_meshlet=64)
+                     tris_per_meshlet=64, lod_count=3 if multiview else 1)
     with torch.cuda.stream(stream):
         base = make_scene(spec, dev)
         bytes_per_copy = n_meshlets * 24 + (M * 212)
-        if full:
-            copies = args.copies or 1  # 10M meshlets + geometry is ~10 GB: far beyond the Infinity Cache already
+        if full or multiview:
+            copies = args.copies or 1  # 10M meshlets (+ geometry ~10 GB): far beyond the Infinity Cache already
         else:
             copies = args.copies or max(2, -(-1_150_000_000 // bytes_per_copy))
         scenes = [base] + [base.clone() for _ in range(copies - 1)]
@@ -107,7 +109,7 @@ def main():
         if full:
             depth = ImageAttachment.depth(make_depth(8192, 8192, 64, seed=3, device=dev))
             hiz = ImageAttachment.hiz(4096, 4096, dev)
-        stages = L.STAGE_ALL if full else L.STAGE_MESHLETS
+        stages = L.STAGE_ALL if full else (L.STAGE_MESHES | L.STAGE_MESHLETS if multiview else L.STAGE_MESHLETS)
         steps = [Step(r, s, stages, use_hiz=full, hiz=hiz, with_triangles=full) for s in scenes]
         if full:
             g = torch.Generator(device=dev).manual_seed(5)
@@ -128,8 +130,30 @@ def main():
         mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
         pmg = C.byref(mg)
 
+    view_cams = []
+    if multiview:
+        # config 5: orthographic cascade views with doubling extents around the camera
+        # (Shadowmaps.cpp:9-63 generalised to `--views` levels), per-view LOD select (cull_meshes)
+        from oxylus_amd.synth import virtual_shadow_matrices
+
+        mats, _, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], [0.3, -1.0, 0.2], 500.0, 2.0, args.views)
+        for v in range(args.views):
+            cam = base.cull_camera()
+            for k in range(16):
+                cam.projection_view[k] = float(mats[v][k])
+            cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
+            cam.near_clip = zn
+            view_cams.append(cam)
+
     def run_step(i):
         st = steps[i % copies]
+        if multiview:
+            st.cctx.init_cull_meshes = 1
+            st.cctx.cull_flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+            for cam in view_cams:
+                st.cctx.cull_camera = cam
+                check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+            return
         if not full:
             check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
             return
@@ -152,8 +176,9 @@ def main():
     counts = {"total": c0.total_visible_meshlet_instances, "early": c0.early_visible_meshlet_instances,
               "late": c0.late_visible_meshlet_instances, "emitted": c0.cull_triangles_cmd_x, "index_count": c0.draw_index_count}
     visible_fraction = (c0.cull_triangles_cmd_x if not full else c0.early_visible_meshlet_instances + c0.late_visible_meshlet_instances) / n_meshlets
+    units_per_step = n_meshlets * (args.views if multiview else 1)
     cpu_scene = None
-    if rank == 0 and not full:
+    if rank == 0 and not full and not multiview:
         import oracle  # checker only
 
         oracle.build()
@@ -180,7 +205,7 @@ def main():
     # ---- optional HIP graph over one rotation through the copies ----
     graph = None
     per_replay = copies
-    if not args.no_graph and not full and args.steps >= per_replay:
+    if not args.no_graph and not full and not multiview and args.steps >= per_replay:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             for i in range(per_replay):
@@ -223,7 +248,7 @@ def main():
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
-    value = n_meshlets * world * args.steps / elapsed_s
+    value = units_per_step * world * args.steps / elapsed_s
     ms_per_step = elapsed_s * 1e3 / args.steps
 
     # ---- instrumented pass: per-kernel HIP-event times on the same stream, same workload ----
@@ -254,7 +279,7 @@ def main():
 
     # ---- roofline of the dominant kernel ----
     if not full:
-        dom = "cull_meshlets_test"
+        dom = "cull_meshlets_test"  # (config5: one launch per view; bytes are per launch over the LOD-selected list)
         # 8 B MeshletInstance + 16 B MeshletBounds read per meshlet + per-mesh tables
         # 212/K B + 4*v B of visible indices written (the write is done by cull_meshlets_emit; it is
         # charged to the stage, i.e. to this launch, as 8(d) does).
@@ -318,8 +343,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("configs[1]: 1M meshlets, one camera, frustum+cone cull + ordered compaction (cull_meshlets stage)"
-                             if not full else
-                             "configs[2]: 10M meshlets + 4096^2 HiZ (13 mips) from 8192^2 depth: hiz build + early/late occlusion cull + triangle cull + compaction"),
+                             if not (full or multiview) else
+                             "configs[2]: 10M meshlets + 4096^2 HiZ (13 mips) from 8192^2 depth: hiz build + early/late occlusion cull + triangle cull + compaction"
+                             if full else
+                             f"configs[4]: 10M meshlets x {args.views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"),
                 "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K,
                 "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
                 "hip_graph": graph is not None, "visible_fraction": round(visible_fraction, 4),

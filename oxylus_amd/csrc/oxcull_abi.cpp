@@ -404,6 +404,20 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ta.hiz_h = h.height;
       ta.hiz_levels = h.levels;
       for (uint32_t k = 0; k < h.levels && k < 13; k++) ta.hiz_level_off[k] = (uint32_t)(h.level_offset[k] / 4);
+      // LDS-staged top of the pyramid: the longest suffix of levels that fits kHizLdsTexels floats
+      uint32_t first = h.levels, used = 0;
+      while (first > 0) {
+        const uint64_t n = (uint64_t)std::max(1u, h.width >> (first - 1)) * std::max(1u, h.height >> (first - 1));
+        if (used + n > kHizLdsTexels) break;
+        used += (uint32_t)n;
+        first--;
+      }
+      ta.hiz_lds_first = first;
+      uint32_t off = 0;
+      for (uint32_t k = first; k < h.levels; k++) {
+        ta.hiz_lds_off[k] = off;
+        off += std::max(1u, h.width >> k) * std::max(1u, h.height >> k);
+      }
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);

@@ -180,6 +180,11 @@ OXC_DEV bool cone_visible(const float* world, const float* nm, float scale_max, 
 struct HizView {
   const float* data;
   uint32_t width, height, levels;
+  // Top of the pyramid staged in LDS: levels >= lds_first live at lds + lds_off[level]
+  // (lds_first == levels: nothing staged).  Same values, different address space.
+  const float* lds;
+  const uint32_t* lds_off;
+  uint32_t lds_first;
 };
 
 OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
@@ -269,11 +274,20 @@ OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy
   int32_t bx1 = (int32_t)((uint32_t)bx + 1u), by1 = (int32_t)((uint32_t)by + 1u);
   int32_t x0 = min(max(bx, 0), mxx), y0 = min(max(by, 0), mxy);
   int32_t x1 = min(max(bx1, 0), mxx), y1 = min(max(by1, 0), mxy);
-  const float* lvl = hiz.data + level_off[mip];
-  float p00 = lvl[(size_t)y0 * mw + x0];
-  float p10 = lvl[(size_t)y0 * mw + x1];
-  float p01 = lvl[(size_t)y1 * mw + x0];
-  float p11 = lvl[(size_t)y1 * mw + x1];
+  float p00, p10, p01, p11;
+  if (mip >= hiz.lds_first) {  // small, heavily shared top mips: LDS-staged tile of the pyramid
+    const float* lvl = hiz.lds + hiz.lds_off[mip];
+    p00 = lvl[y0 * (int32_t)mw + x0];
+    p10 = lvl[y0 * (int32_t)mw + x1];
+    p01 = lvl[y1 * (int32_t)mw + x0];
+    p11 = lvl[y1 * (int32_t)mw + x1];
+  } else {
+    const float* lvl = hiz.data + level_off[mip];
+    p00 = lvl[(size_t)y0 * mw + x0];
+    p10 = lvl[(size_t)y0 * mw + x1];
+    p01 = lvl[(size_t)y1 * mw + x0];
+    p11 = lvl[(size_t)y1 * mw + x1];
+  }
   float d = fminf(fminf(p00, p10), fminf(p01, p11));
   return maxz <= d - 1e-7f;
 }

@@ -422,8 +422,20 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   const uint32_t N = a.vis[0];
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
+  __shared__ uint32_t s_lds_off[13];
+  __shared__ float s_hiz_top[HIZ ? kHizLdsTexels : 1];
   if (HIZ) {
-    if (threadIdx.x < 13) s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
+    if (threadIdx.x < 13) {
+      s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
+      s_lds_off[threadIdx.x] = a.hiz_lds_off[threadIdx.x];
+    }
+    // stage the top of the pyramid (levels >= hiz_lds_first) once per block
+    for (uint32_t k = a.hiz_lds_first; k < a.hiz_levels; k++) {
+      const uint32_t n = mip_dim(a.hiz_w, k) * mip_dim(a.hiz_h, k);
+      const float* src = a.hiz_data + a.hiz_level_off[k];
+      float* dst = s_hiz_top + a.hiz_lds_off[k];
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
   }
   HizView hiz;
@@ -431,6 +443,9 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   hiz.width = a.hiz_w;
   hiz.height = a.hiz_h;
   hiz.levels = a.hiz_levels;
+  hiz.lds = s_hiz_top;
+  hiz.lds_off = s_lds_off;
+  hiz.lds_first = HIZ ? a.hiz_lds_first : 0u;
   const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {

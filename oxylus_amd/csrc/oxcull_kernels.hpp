@@ -63,6 +63,8 @@ struct MeshletTestArgs {
   const float* hiz_data;
   uint32_t hiz_level_off[13];  // float offsets of each mip
   uint32_t hiz_w, hiz_h, hiz_levels;
+  uint32_t hiz_lds_first;     // first level staged in LDS (== hiz_levels: none)
+  uint32_t hiz_lds_off[13];   // float offset of each staged level inside the LDS tile
   float near_clip;
   float cam_pos[3];
 };

@@ -71,6 +71,7 @@ constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block 
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
 constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel
+constexpr uint32_t kHizLdsTexels = 5632;      // LDS budget (floats) for the staged top HiZ mips: a 64x64 level and everything above it
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
 
 }  // namespace oxc
