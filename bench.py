@@ -315,10 +315,15 @@ def main():
         dt1 = time.perf_counter() - t1c0
         # calibrate on a short multi-threaded run (thread scaling on the box is not known in advance),
         # then size the sample to ~cpu_seconds of wall time
-        tc = time.perf_counter()
-        oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores, passes=8)
-        per_pass = (time.perf_counter() - tc) / 8
-        passes = int(min(max(1, args.cpu_seconds / max(per_pass, 1e-5)), 1_000_000))
+        cal = 8
+        while True:  # grow the calibration run until thread start-up no longer dominates it
+            tc = time.perf_counter()
+            oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores, passes=cal)
+            t_cal = time.perf_counter() - tc
+            if t_cal > 0.5 or cal >= 4096:
+                break
+            cal *= 4
+        passes = int(min(max(1, args.cpu_seconds / (t_cal / cal)), 1_000_000))
         t_cpu0 = time.perf_counter()
         oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores, passes=passes)
         dt = time.perf_counter() - t_cpu0

@@ -51,6 +51,7 @@ struct oxc_ctx {
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
   uint32_t* sink = nullptr;
+  uint32_t seeded_total[1024] = {};  // per counter slot: list length given to oxc_seed_meshlet_instances (0: unknown)
   // profiling (oxc_profile_begin/end)
   bool profiling = false;
   struct Rec {
@@ -242,6 +243,7 @@ oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c
   if (!c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "seed: bad context struct");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t* slot = next_slot(ctx);
+  ctx->seeded_total[(slot - ctx->slots) / SLOT_U32S] = total;
   launch_seed_slot(slot, total, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
   c->visibility_buffer = {slot + SLOT_VIS, 12};
@@ -296,8 +298,16 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
   uint32_t* slot = next_slot(ctx);
+  ctx->seeded_total[(slot - ctx->slots) / SLOT_U32S] = 0;
   uint32_t* vis;
   uint32_t* meshlets_cmd;
+  uint32_t n_host = 0;  // list length when the host knows it (oxc_seed_meshlet_instances), else 0
+  if (!c->init_cull_meshes) {
+    const uint32_t* v = static_cast<const uint32_t*>(c->visibility_buffer.dptr);
+    if (v >= ctx->slots && v < ctx->slots + (size_t)kSlots * SLOT_U32S && ((v - ctx->slots) % SLOT_U32S) == SLOT_VIS)
+      n_host = ctx->seeded_total[(v - ctx->slots) / SLOT_U32S];
+    if (n_host > N) n_host = 0;
+  }
   if (c->init_cull_meshes) {
     vis = slot + SLOT_VIS;
     meshlets_cmd = slot + SLOT_MESHLETS_CMD;
@@ -379,6 +389,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       launch_hpb_test(ha, std::min(m_chunks, max_grid), s);
     }
     MeshletEmitArgs ea;
+    ea.n_host = 0;
     ea.bits = ctx->bits;
     ea.chunk_counts = ctx->m_chunk_counts;
     ea.supers = ctx->m_supers;
@@ -390,6 +401,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   } else if (do_meshlets) {
     MeshletTestArgs ta;
     std::memset(&ta, 0, sizeof ta);
+    ta.n_host = n_host;
     ta.cache = ctx->cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ta.vis = vis;
@@ -426,6 +438,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
     }
     MeshletEmitArgs ea;
+    ea.n_host = n_host;
     ea.bits = ctx->bits;
     ea.chunk_counts = ctx->m_chunk_counts;
     ea.supers = ctx->m_supers;

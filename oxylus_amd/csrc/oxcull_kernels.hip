@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_level_off[13];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.vis[0];
+  const uint32_t N = a.n_host ? a.n_host : a.vis[0];
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
   __shared__ uint32_t s_lds_off[13];
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
   __shared__ uint32_t s_off[64];
   __shared__ uint64_t s_bits[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.vis[0];
+  const uint32_t N = a.n_host ? a.n_host : a.vis[0];
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nspans = (N + kMeshletSpan - 1) / kMeshletSpan;
   const uint32_t out_first = (HIZ && LATE) ? a.vis[1] : 0u;  // late list follows the early one (:73)

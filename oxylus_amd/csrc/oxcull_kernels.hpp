@@ -53,6 +53,7 @@ struct HpbTestArgs {
 };
 
 struct MeshletTestArgs {
+  uint32_t n_host;  // != 0: the list length is known on the host (seeded lists); skips the dependent load of vis[0]
   const InstCache* cache;
   const GpuMeshletInstance* meshlet_instances;
   const uint32_t* vis;
@@ -70,6 +71,7 @@ struct MeshletTestArgs {
 };
 
 struct MeshletEmitArgs {
+  uint32_t n_host;
   const uint64_t* bits;
   const uint32_t* chunk_counts;
   const uint32_t* supers;
