@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
     ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
+    ap.add_argument("--streams", type=int, default=1, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
@@ -87,6 +88,11 @@ def main():
     lib, ctxp = r._lib, r._ctx
     stream = torch.cuda.Stream(device=dev)
     sp = C.c_void_p(stream.cuda_stream)
+    n_streams = max(1, args.streams) if args.workload == "config2" else 1
+    # extra contexts/streams for independent batches in flight (each context owns its scratch)
+    renderers = [r] + [RendererInstance(local_rank) for _ in range(n_streams - 1)]
+    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    sps = [C.c_void_p(s_.cuda_stream) for s_ in streams]
 
     full = args.workload == "config3"
     multiview = args.workload == "config5"
@@ -104,13 +110,14 @@ def main():
         else:
             copies = args.copies or max(2, -(-1_150_000_000 // bytes_per_copy))
         scenes = [base] + [base.clone() for _ in range(copies - 1)]
-        r.reserve(M, n_meshlets)
+        for rr in renderers:
+            rr.reserve(M, n_meshlets)
         hiz = depth = None
         if full:
             depth = ImageAttachment.depth(make_depth(8192, 8192, 64, seed=3, device=dev))
             hiz = ImageAttachment.hiz(4096, 4096, dev)
         stages = L.STAGE_ALL if full else (L.STAGE_MESHES | L.STAGE_MESHLETS if multiview else L.STAGE_MESHLETS)
-        steps = [Step(r, s, stages, use_hiz=full, hiz=hiz, with_triangles=full) for s in scenes]
+        steps = [Step(renderers[i % n_streams], s, stages, use_hiz=full, hiz=hiz, with_triangles=full) for i, s in enumerate(scenes)]
         if full:
             g = torch.Generator(device=dev).manual_seed(5)
             for st in steps:  # random prior-visibility mask, p = 0.3 (config 3 restatement)
@@ -118,7 +125,7 @@ def main():
                 bits = (torch.rand((words, 32), generator=g, device=dev) < 0.3).to(torch.int64)
                 st.frame.meshlet_instance_visibility_mask_buffer.copy_((bits << torch.arange(32, device=dev)).sum(1).to(torch.int32))
             mask0 = [st.frame.meshlet_instance_visibility_mask_buffer.clone() for st in steps]
-    stream.synchronize()
+    torch.cuda.synchronize()
 
     def check(st):
         if st != L.OXC_OK:
@@ -145,6 +152,8 @@ def main():
             cam.near_clip = zn
             view_cams.append(cam)
 
+    single_stream = [False]  # instrumented pass: every context on stream 0, so kernels do not overlap
+
     def run_step(i):
         st = steps[i % copies]
         if multiview:
@@ -155,7 +164,8 @@ def main():
                 check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
             return
         if not full:
-            check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+            k = (i % copies) % n_streams  # copy -> context/stream
+            check(lib.oxc_cull_geometry(renderers[k]._ctx, st.pf, st.pc, sps[0] if single_stream[0] else sps[k]))
             return
         # config 3: HiZ build, then early + late pass against it (render order of
         # RendererInstance.cpp:882-884 restated for a given depth + given mask)
@@ -171,7 +181,7 @@ def main():
     counts = {}
     with torch.cuda.stream(stream):
         run_step(0)
-    stream.synchronize()
+    torch.cuda.synchronize()
     c0 = r.read_counters(steps[0].ctx, stream)
     counts = {"total": c0.total_visible_meshlet_instances, "early": c0.early_visible_meshlet_instances,
               "late": c0.late_visible_meshlet_instances, "emitted": c0.cull_triangles_cmd_x, "index_count": c0.draw_index_count}
@@ -195,12 +205,12 @@ def main():
         with torch.cuda.stream(stream):
             for _ in range(20):
                 r.stream_read_probe(ramp, stream)
-        stream.synchronize()
+        torch.cuda.synchronize()
     del ramp
     with torch.cuda.stream(stream):
         for i in range(args.warmup):
             run_step(i)
-    stream.synchronize()
+    torch.cuda.synchronize()
 
     # ---- optional HIP graph over one rotation through the copies ----
     graph = None
@@ -208,12 +218,16 @@ def main():
     if not args.no_graph and not full and not multiview and args.steps >= per_replay:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
+            for s_ in streams[1:]:
+                s_.wait_stream(stream)  # fork: the side streams join the capture
             for i in range(per_replay):
                 run_step(i)
+            for s_ in streams[1:]:
+                stream.wait_stream(s_)  # join
         with torch.cuda.stream(stream):
             for _ in range(max(1, args.warmup // per_replay)):
                 graph.replay()
-        stream.synchronize()
+        torch.cuda.synchronize()
 
     gathered = None
     if dist is not None:
@@ -253,11 +267,21 @@ def main():
 
     # ---- instrumented pass: per-kernel HIP-event times on the same stream, same workload ----
     prof_steps = min(args.steps, max(2 * copies, 96))
-    r.profile_begin()
+    single_stream[0] = True
+    for rr in renderers:
+        rr.profile_begin()
     with torch.cuda.stream(stream):
         for i in range(prof_steps):
             run_step(i)
-    prof = r.profile_end()
+    prof = {"kernels": {}, "empty_pair_ms": 0.0}
+    for rr in renderers:
+        p_ = rr.profile_end()
+        prof["empty_pair_ms"] = max(prof["empty_pair_ms"], p_["empty_pair_ms"])
+        for name, k in p_["kernels"].items():
+            acc = prof["kernels"].setdefault(name, {"launches": 0, "total_ms": 0.0})
+            acc["launches"] += k["launches"]
+            acc["total_ms"] += k["total_ms"]
+    single_stream[0] = False
     kernels = {}
     for name, k in prof["kernels"].items():
         avg_us = (k["total_ms"] / k["launches"] - prof["empty_pair_ms"]) * 1e3
@@ -273,7 +297,7 @@ def main():
         for _ in range(5):
             r.stream_read_probe(probe, stream)
         e1.record(stream)
-    stream.synchronize()
+    torch.cuda.synchronize()
     stream_read_gbps = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del probe
 
@@ -354,7 +378,7 @@ def main():
                              f"configs[4]: 10M meshlets x {args.views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"),
                 "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K,
                 "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
-                "hip_graph": graph is not None, "visible_fraction": round(visible_fraction, 4),
+                "hip_graph": graph is not None, "streams": n_streams, "visible_fraction": round(visible_fraction, 4),
                 "sharding": f"contiguous range per rank x{world}" if world > 1 else "single GPU",
             },
             "bit_match": bit_match,
@@ -366,7 +390,8 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
-    r.close()
+    for rr in renderers:
+        rr.close()
 
 
 if __name__ == "__main__":

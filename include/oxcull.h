@@ -184,7 +184,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* frame, oxc_
 /* Harness helper: start a cull sequence from a caller-provided MeshletInstance list instead of
  * running cull_meshes (fills context->visibility_buffer = {total,0,0} and
  * cull_meshlets_cmd_buffer = {ceil(total/64),1,1}).  The reference always derives these from
- * cull_meshes; the synthetic benchmark configurations start from a given list. */
+ * cull_meshes; the synthetic benchmark configurations start from a given list.
+ * Seeded buffers stay valid for 512 further seeds; per-call counter buffers for 512 further calls. */
 oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* context, uint32_t total,
                                       void* hip_stream);
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -47,9 +48,17 @@ struct oxc_ctx {
   uint64_t* tri_masks = nullptr;
   uint32_t* t_chunk_counts = nullptr;
   uint32_t* t_supers = nullptr;
+  // fused-emit hand-off state (zeroed at allocation; self-resetting afterwards)
+  uint64_t* chunk_gran = nullptr;
+  uint64_t* super_gran = nullptr;
+  uint32_t* super_arrive = nullptr;
+  uint32_t* super_done = nullptr;
+  uint32_t* fsync = nullptr;
+  bool fused_emit = false;  // experiment, off by default: measured 38 us/step vs 26 us/step unfused
   // counter slots
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
+  uint32_t seed_cursor = 0;
   uint32_t* sink = nullptr;
   uint32_t seeded_total[1024] = {};  // per counter slot: list length given to oxc_seed_meshlet_instances (0: unknown)
   // profiling (oxc_profile_begin/end)
@@ -102,6 +111,12 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_tm = carve((uint64_t)N * 8);
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4);
+  const uint64_t o_sync0 = off;
+  const uint64_t o_cgran = carve((uint64_t)m_chunks * 8);
+  const uint64_t o_sgran = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 8);
+  const uint64_t o_sarr = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
+  const uint64_t o_sdone = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
+  const uint64_t o_fsync = carve(64);
   OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old arena
   if (ctx->arena) OXC_HIP(ctx, hipFree(ctx->arena));
   ctx->arena = nullptr;
@@ -123,14 +138,27 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   ctx->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   ctx->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
   ctx->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
+  ctx->chunk_gran = reinterpret_cast<uint64_t*>(b + o_cgran);
+  ctx->super_gran = reinterpret_cast<uint64_t*>(b + o_sgran);
+  ctx->super_arrive = reinterpret_cast<uint32_t*>(b + o_sarr);
+  ctx->super_done = reinterpret_cast<uint32_t*>(b + o_sdone);
+  ctx->fsync = reinterpret_cast<uint32_t*>(b + o_fsync);
+  OXC_HIP(ctx, hipMemset(b + o_sync0, 0, off - o_sync0));
   ctx->cap_mesh_instances = M;
   ctx->cap_meshlets = N;
   return OXC_OK;
 }
 
+// Per-call slots come from the lower half of the ring, seed slots (oxc_seed_meshlet_instances: they
+// must outlive many calls) from the upper half, so a wrapping call ring never lands on a live seed.
 uint32_t* next_slot(oxc_ctx* ctx) {
-  uint32_t* s = ctx->slots + (size_t)(ctx->slot_cursor % kSlots) * SLOT_U32S;
+  uint32_t* s = ctx->slots + (size_t)(ctx->slot_cursor % (kSlots / 2)) * SLOT_U32S;
   ctx->slot_cursor++;
+  return s;
+}
+uint32_t* next_seed_slot(oxc_ctx* ctx) {
+  uint32_t* s = ctx->slots + (size_t)(kSlots / 2 + ctx->seed_cursor % (kSlots / 2)) * SLOT_U32S;
+  ctx->seed_cursor++;
   return s;
 }
 
@@ -185,6 +213,7 @@ oxc_status oxc_create(int device, oxc_ctx** out) {
   }
   (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
   ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
+  if (const char* e = std::getenv("OXC_FUSED_EMIT")) ctx->fused_emit = e[0] != '0';
   *out = ctx;
   return OXC_OK;
 }
@@ -242,7 +271,7 @@ oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c
   if (!ctx) return OXC_INVALID_ARG;
   if (!c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "seed: bad context struct");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
-  uint32_t* slot = next_slot(ctx);
+  uint32_t* slot = next_seed_slot(ctx);
   ctx->seeded_total[(slot - ctx->slots) / SLOT_U32S] = total;
   launch_seed_slot(slot, total, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
@@ -298,7 +327,6 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
   uint32_t* slot = next_slot(ctx);
-  ctx->seeded_total[(slot - ctx->slots) / SLOT_U32S] = 0;
   uint32_t* vis;
   uint32_t* meshlets_cmd;
   uint32_t n_host = 0;  // list length when the host knows it (oxc_seed_meshlet_instances), else 0
@@ -435,8 +463,24 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
-      launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
+      // Single-launch variant (ordered emit fused into the test kernel) when the list length is known on
+    // the host, one chunk per block fits the resident grid, and the plain cull_meshlets pipeline runs.
+    const uint32_t exact_chunks = n_host ? cdiv(n_host, kMeshletChunk) : 0u;
+    const bool fused = ctx->fused_emit && !c->use_hiz && n_host != 0 && exact_chunks <= ctx->num_cus * 4u;
+    if (fused) {
+      ta.chunk_gran = ctx->chunk_gran;
+      ta.super_gran = ctx->super_gran;
+      ta.super_arrive = ctx->super_arrive;
+      ta.super_done = ctx->super_done;
+      ta.sync = ctx->fsync;
+      ta.tri_cmd = tri_cmd;
+      ta.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+      launch_meshlets_fused(ta, exact_chunks, s);
+    } else {
+    launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
     }
+    }
+    if (!(ctx->fused_emit && !c->use_hiz && n_host != 0 && cdiv(n_host, kMeshletChunk) <= ctx->num_cus * 4u)) {
     MeshletEmitArgs ea;
     ea.n_host = n_host;
     ea.bits = ctx->bits;
@@ -447,6 +491,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
     KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
     launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
+    }
   }
 
   // --- triangle stage: CullGeometry.cpp:337-403
@@ -490,7 +535,13 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   if (c->cull_meshlets_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(mc, c->cull_meshlets_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
   if (c->cull_triangles_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(tc, c->cull_triangles_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
   if (c->draw_geometry_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(dc, c->draw_geometry_cmd_buffer.dptr, 20, hipMemcpyDeviceToHost, s));
+  uint32_t ferr = 0;
+  if (ctx->fsync) OXC_HIP(ctx, hipMemcpyAsync(&ferr, ctx->fsync + 2, 4, hipMemcpyDeviceToHost, s));
   OXC_HIP(ctx, hipStreamSynchronize(s));
+  if (ferr) {
+    (void)hipMemset(ctx->chunk_gran, 0, reinterpret_cast<char*>(ctx->fsync) + 64 - reinterpret_cast<char*>(ctx->chunk_gran));
+    return fail(ctx, OXC_HIP_ERROR, "in-kernel hand-off of the fused meshlet emit timed out (state reset)");
+  }
   out->total_visible_meshlet_instances = vis[0];
   out->early_visible_meshlet_instances = vis[1];
   out->late_visible_meshlet_instances = vis[2];

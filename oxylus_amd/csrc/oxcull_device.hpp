@@ -177,6 +177,57 @@ OXC_DEV bool cone_visible(const float* world, const float* nm, float scale_max, 
   return cutoff >= 1.0f || !culled;
 }
 
+// Wave-level variant of test_frustum_planes: identical per-lane result; once no lane of the wave
+// that still matters (`live`) is inside, the remaining planes are skipped.
+OXC_DEV bool test_frustum_planes_wave(const float* pl, float cx, float cy, float cz, float ex, float ey, float ez, bool live) {
+  float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
+  bool inside = live;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (!__any(inside)) break;
+    float nx = pl[i * 4 + 0], ny = pl[i * 4 + 1], nz = pl[i * 4 + 2], nw = pl[i * 4 + 3];
+    float qx = cx + asf(asu(hx) ^ (asu(nx) & 0x80000000u));
+    float qy = cy + asf(asu(hy) ^ (asu(ny) & 0x80000000u));
+    float qz = cz + asf(asu(hz) ^ (asu(nz) & 0x80000000u));
+    inside = inside && !(dot3(qx, qy, qz, nx, ny, nz) <= -nw);
+  }
+  return inside;
+}
+
+// Two-tier cone test (cull_meshlets.slang:49-52, cull.slang:173-175).  Tier 1 evaluates
+//   L = dot(d, n) / |n|   and   R = cutoff * |d| + |h| * scale
+// with the 1-ulp hardware v_rsq_f32 / v_sqrt_f32 (quarter-rate single instructions) instead of three
+// IEEE divisions and three correctly rounded square roots.  Both tiers approximate the same real
+// numbers with a relative error of a few 2^-23 of (|d| + radius) -- at most ~12 roundings of
+// magnitude <= |d| + radius on either side, i.e. < 3e-6 * (|d| + radius) -- so when |L - R| exceeds
+// kConeMargin * (|d| + radius) = 1.6e-5 * (...) the canonical (tier 2) comparison is already decided.
+// Lanes inside the margin are undecided; the caller runs the exact path when any lane of the wave is.
+// Returns: 0 = culled, 1 = cone-visible, 2 = undecided.
+constexpr float kConeMargin = 1.6e-5f;
+OXC_DEV int cone_visible_fast(const float* world, const float* nm, float scale_max, float camx, float camy, float camz,
+                              float cx, float cy, float cz, float ex, float ey, float ez, float ax, float ay, float az,
+                              float cutoff) {
+  float nx = (nm[0] * ax + nm[3] * ay) + nm[6] * az;
+  float ny = (nm[1] * ax + nm[4] * ay) + nm[7] * az;
+  float nz = (nm[2] * ax + nm[5] * ay) + nm[8] * az;
+  float wx = ((world[0] * cx + world[1] * cy) + world[2] * cz) + world[3];
+  float wy = ((world[4] * cx + world[5] * cy) + world[6] * cz) + world[7];
+  float wz = ((world[8] * cx + world[9] * cy) + world[10] * cz) + world[11];
+  float dx = wx - camx, dy = wy - camy, dz = wz - camz;
+  float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
+  float inv_l = __builtin_amdgcn_rsqf(dot3(nx, ny, nz, nx, ny, nz));
+  float dlen = __builtin_amdgcn_sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+  float radius = __builtin_amdgcn_sqrtf(dot3(hx, hy, hz, hx, hy, hz)) * scale_max;
+  float L = dot3(dx, dy, dz, nx, ny, nz) * inv_l;
+  float R = cutoff * dlen + radius;
+  float T = kConeMargin * (dlen + radius);
+  float diff = L - R;
+  // NaN/Inf anywhere (degenerate axis, huge values) compares false twice -> undecided -> exact path
+  if (diff > T) return 0;
+  if (diff < -T) return 1;
+  return 2;
+}
+
 struct HizView {
   const float* data;
   uint32_t width, height, levels;

@@ -393,13 +393,21 @@ OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4
     was_visible = ((a.mask[mask_idx >> 5] >> (mask_idx & 31u)) & 1u) != 0u;
   }
   bool visible = mine && ((HIZ && !LATE) ? was_visible : true);
-  visible = visible && test_frustum_planes(u.pl, cx, cy, cz, ex, ey, ez);
+  visible = test_frustum_planes_wave(u.pl, cx, cy, cz, ex, ey, ez, visible);
   const int32_t cutoff_s8 = (int32_t)b.w >> 24;
-  if (__any(visible && cutoff_s8 != 127)) {  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
+  const bool need_cone = visible && cutoff_s8 != 127;  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
+  if (__any(need_cone)) {
     const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
     const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127(cutoff_s8);
-    visible = visible && cone_visible(u.world, u.nm, u.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez,
-                                      ax, ay, az, cutoff);
+    int tier1 = cone_visible_fast(u.world, u.nm, u.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az,
+                                  cutoff);
+    bool cone_ok = tier1 == 1;
+    if (__any(need_cone && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
+      const bool exact = cone_visible(u.world, u.nm, u.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay,
+                                      az, cutoff);
+      cone_ok = tier1 == 2 ? exact : cone_ok;
+    }
+    visible = visible && (!need_cone || cone_ok);
   }
   if (HIZ && OCCL_OR_LATE) {
     if (__any(visible)) {
@@ -414,9 +422,22 @@ OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4
   }
 }
 
-template <bool HIZ, bool OCCL, bool LATE>
+// ---- in-kernel hand-off helpers (MI355X: per-XCD L2s are not coherent; every shared word is an
+// agent-scope atomic access = global_load/store ... sc1, never a plain access) ----
+typedef unsigned long long __attribute__((address_space(1))) * gu64p;
+typedef unsigned int __attribute__((address_space(1))) * gu32p;
+OXC_DEV void st_gran(uint64_t* p, uint32_t epoch, uint32_t value) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+OXC_DEV uint64_t ld_gran(const uint64_t* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr uint32_t kMaxSpins = 1u << 20;  // bounded: a broken hand-off sets sync[2] instead of hanging the GPU
+
+template <bool HIZ, bool OCCL, bool LATE, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   __shared__ uint32_t s_red[4];
+  __shared__ uint32_t s_fused[4];  // [0] epoch, [1] base, [2] last-arriver flag
   __shared__ uint32_t s_level_off[13];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.n_host ? a.n_host : a.vis[0];
@@ -447,6 +468,9 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   hiz.lds_off = s_lds_off;
   hiz.lds_first = HIZ ? a.hiz_lds_first : 0u;
   const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
+  if (FUSED && threadIdx.x == 0) {
+    s_fused[0] = __hip_atomic_load(&a.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;  // this launch's epoch (never 0)
+  }
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     // ---- stage A: all MeshletInstance loads of this wave (G consecutive 64-meshlet groups)
@@ -505,15 +529,122 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
       }
     }
     uint32_t cnt = 0;
+    uint64_t wbits[G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
+      wbits[j] = 0;
       if (group[j] >= nwords) continue;  // wave-uniform
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
       if (HIZ && OCCL) update_visibility_mask(a.mask, res[j].mask_idx, res[j].visible, in[j], lane);
       const uint64_t bits = __ballot(res[j].emit);
-      if (lane == 0) a.bits[group[j]] = bits;
+      wbits[j] = bits;
+      if (!FUSED && lane == 0) a.bits[group[j]] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
+    }
+    if (FUSED) {
+      // ---- ordered emit inside the same launch (one chunk per block; grid == nchunks) ----
+      __syncthreads();
+      if (lane == 0) s_red[wave] = cnt;
+      __syncthreads();
+      const uint32_t block_count = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      uint32_t wave_prefix = 0;
+      for (int k = 0; k < wave; k++) wave_prefix += s_red[k];
+      const uint32_t epoch = s_fused[0];
+      const uint32_t sup = chunk / kChunksPerSuper;
+      if (wave == 0) {
+        uint32_t last = 0;
+        if (lane == 0) {
+          st_gran(&a.chunk_gran[chunk], epoch, block_count);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const uint32_t in_super = min(kChunksPerSuper, nchunks - sup * kChunksPerSuper);
+          const uint32_t old = atomicAdd(&a.super_arrive[sup], 1u);
+          last = (old + 1u == in_super) ? 1u : 0u;
+        }
+        last = readfirst_u(last);
+        bool failed = false;
+        if (last) {  // last arriver of this super: publish its total
+          const uint32_t ci = sup * kChunksPerSuper + (uint32_t)lane;
+          uint32_t v = 0;
+          for (uint32_t spin = 0;; spin++) {
+            bool ok = true;
+            v = 0;
+            if (ci < nchunks) {
+              const uint64_t g = ld_gran(&a.chunk_gran[ci]);
+              ok = (uint32_t)(g >> 32) == epoch;
+              v = (uint32_t)g;
+            }
+            if (__all(ok)) break;
+            if (spin > kMaxSpins) {
+              failed = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          const uint32_t total = wave_sum(v);
+          if (lane == 0) {
+            st_gran(&a.super_gran[sup], epoch, total);
+            __hip_atomic_store(&a.super_arrive[sup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        // exclusive base of this chunk: supers before it + chunks before it inside its super
+        uint32_t acc = 0;
+        for (uint32_t spin = 0;; spin++) {
+          bool ok = true;
+          acc = 0;
+          for (uint32_t i = (uint32_t)lane; i < sup; i += 64) {
+            const uint64_t g = ld_gran(&a.super_gran[i]);
+            ok = ok && (uint32_t)(g >> 32) == epoch;
+            acc += (uint32_t)g;
+          }
+          const uint32_t ci = sup * kChunksPerSuper + (uint32_t)lane;
+          if (ci < chunk) {
+            const uint64_t g = ld_gran(&a.chunk_gran[ci]);
+            ok = ok && (uint32_t)(g >> 32) == epoch;
+            acc += (uint32_t)g;
+          }
+          if (__all(ok)) break;
+          if (spin > kMaxSpins || __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            failed = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        uint32_t base = wave_sum(acc);
+        if (failed) {
+          base = 0;
+          if (lane == 0) __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_fused[1] = base;
+      }
+      __syncthreads();
+      const uint32_t base = s_fused[1];
+      uint32_t off = base + wave_prefix;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t bits = wbits[j];
+        if ((bits >> lane) & 1ull) {
+          const uint32_t rank = (uint32_t)__popcll((unsigned long long)(bits & ((1ull << lane) - 1ull)));
+          a.out[off + rank] = idx[j];
+        }
+        off += (uint32_t)__popcll((unsigned long long)bits);
+      }
+      if (threadIdx.x == 0) {
+        if (chunk == nchunks - 1) a.tri_cmd[0] = base + block_count;  // cull_triangles_cmd.x
+        // two-level "last block out" ticket (one address would serialise ~1000 atomics at ~88/us)
+        const uint32_t in_super = min(kChunksPerSuper, nchunks - sup * kChunksPerSuper);
+        const uint32_t d1 = atomicAdd(&a.super_done[sup], 1u);
+        if (d1 + 1u == in_super) {
+          __hip_atomic_store(&a.super_done[sup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t nsup = (nchunks + kChunksPerSuper - 1) / kChunksPerSuper;
+          const uint32_t d2 = atomicAdd(&a.sync[1], 1u);
+          if (d2 + 1u == nsup) {  // last block out: arm the next launch
+            __hip_atomic_store(&a.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sync[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      continue;  // one chunk per block in fused mode (grid == nchunks)
     }
     // per-chunk survivor count (+ per-super accumulation)
     __syncthreads();
@@ -1035,6 +1166,9 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
   }
 }
 void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_cull_meshlets_hpb_test, dim3(grid), dim3(256), 0, s, a); }
+void launch_meshlets_fused(const MeshletTestArgs& a, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+}
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   if (!hiz)

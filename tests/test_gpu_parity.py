@@ -267,3 +267,49 @@ def test_use_hpb_argument_validation(renderer):
     with pytest.raises(L.OxcError) as e:
         renderer.cull_geometry(ctx)
     assert e.value.status == L.OXC_INVALID_ARG
+
+
+def test_cone_two_tier_near_threshold(renderer, oracle_lib):
+    """The cone test has a cheap tier (hardware rsq/sqrt + margin) and the canonical IEEE tier for
+    lanes inside the margin.  Force the rare tier: instances whose cone inequality is an exact tie or
+    a few ulp off (lhs = 1 + j*ulp vs rhs = 1), mixed into waves with clearly decided meshlets."""
+    spec = SceneSpec(n_mesh_instances=300, meshlets_per_mesh=5, seed=71, with_geometry=False)
+    cpu = make_scene(spec, "cpu")
+    b = cpu.bounds
+    f16 = lambda *v: torch.tensor(v, dtype=torch.float32).to(torch.float16).view(torch.int16)  # noqa: E731
+    # every 3rd meshlet of the first 256 instances: centre 0, extent (2,0,0) -> radius 1; axis (0,0,-1); cutoff 0
+    for mi in range(256):
+        for k in (0, 3):
+            r = mi * 5 + k
+            b[r, 0:3] = f16(0.0, 0.0, 0.0)
+            b[r, 4:7] = f16(2.0, 0.0, 0.0)
+            b[r, 3] = 0
+            b[r, 7] = (129 & 0xFF) | (0 << 8)  # axis_z = -127, cutoff = 0
+        j = mi - 128
+        z = np.float32(-1.0)
+        for _ in range(abs(j)):
+            z = np.nextafter(z, np.float32(-2.0) if j > 0 else np.float32(0.0))
+        t = torch.eye(4)
+        t[3, 2] = float(z)  # column-major: translation z
+        cpu.transforms[mi] = t.reshape(-1)
+    gpu = cpu.to("cuda")
+    want = oracle_frame(cpu, with_triangles=False)
+    got = gpu_frame(renderer, gpu, with_triangles=False)
+    assert_same(want, got, ["visible"])
+    vis = set(want["visible"].tolist())
+    # exact tie (j = 0) and lhs > rhs are culled, lhs < rhs is visible: both outcomes occur
+    culled_probe = [mi * 5 for mi in range(256) if mi * 5 not in vis]
+    assert 100 < len(culled_probe) < 256 and any(mi * 5 in vis for mi in range(256))
+
+
+def test_meshlet_stage_one_million(renderer, oracle_lib):
+    """BASELINE configs[1] at full size against the oracle (multi-threaded), unsorted bit-match."""
+    import oracle
+
+    spec = SceneSpec(n_mesh_instances=1000, meshlets_per_mesh=1000, seed=0x0A1DE5 + 2, with_geometry=False)
+    gpu = make_scene(spec, "cuda")
+    cpu = gpu.to("cpu")
+    want = oracle.cull_meshlets(cpu, cpu.cull_camera(), cpu.meshlet_instances, nthreads=16)
+    got = gpu_frame(renderer, gpu, with_triangles=False)
+    assert np.array_equal(want.numpy(), got["visible"])
+    assert 0.1 < want.numel() / 1e6 < 0.6
