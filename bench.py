@@ -11,7 +11,10 @@ compaction (stages = cull_meshlets only).  The 24 MB working set would sit in th
 Cache, so steps rotate over COPIES independent copies of the scene (>= 1 GB) to stay HBM-bound
 (SURVEY.md 8d).  `--workload config3` times the full pipeline (HiZ build + two-pass occlusion +
 triangle cull) on 10M meshlets instead; it is reported in the same format but is not the
-default line.
+default line.  `--streams S` (default 3 for config 2) keeps S independent batches in flight: S contexts
+on S HIP streams inside one HIP graph -- a 1M-meshlet batch is launch/dependency-latency bound, so
+consecutive batches are overlapped the way independent views/frames would be; the one-batch-in-flight
+figure is reported next to it as "single_stream".
 
 Extra objects on the line: "roofline" (dominant kernel: algorithmic bytes / HIP-event kernel
 time vs the 8 TB/s HBM peak) and "cpu_baseline" (the scalar C oracle over the same arrays on
@@ -45,7 +48,7 @@ def parse():
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
     ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
-    ap.add_argument("--streams", type=int, default=1, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
+    ap.add_argument("--streams", type=int, default=3, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
@@ -265,6 +268,29 @@ def main():
     value = units_per_step * world * args.steps / elapsed_s
     ms_per_step = elapsed_s * 1e3 / args.steps
 
+    # ---- secondary figure: the same steps with ONE batch in flight (one stream, dependent launches) ----
+    single = None
+    if n_streams > 1 and graph is not None:
+        single_stream[0] = True
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=stream):
+            for i in range(per_replay):
+                run_step(i)
+        reps1 = max(2, min(args.steps // per_replay, 20))
+        with torch.cuda.stream(stream):
+            g1.replay()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(reps1):
+                g1.replay()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0s
+        single = {"value": round(n_meshlets * reps1 * per_replay / dts, 1), "ms_per_step": round(dts * 1e3 / (reps1 * per_replay), 6),
+                  "steps": reps1 * per_replay}
+        single_stream[0] = False
+        del g1
+
     # ---- instrumented pass: per-kernel HIP-event times on the same stream, same workload ----
     prof_steps = min(args.steps, max(2 * copies, 96))
     single_stream[0] = True
@@ -284,8 +310,11 @@ def main():
     single_stream[0] = False
     kernels = {}
     for name, k in prof["kernels"].items():
-        avg_us = (k["total_ms"] / k["launches"] - prof["empty_pair_ms"]) * 1e3
+        # raw event-to-event time per launch (what rocprofv3's kernel duration also spans: dispatch + run);
+        # the cost of an empty event pair is reported separately, not subtracted
+        avg_us = (k["total_ms"] / k["launches"]) * 1e3
         kernels[name] = {"launches_per_step": k["launches"] / prof_steps, "avg_us": round(avg_us, 3)}
+    kernels["_empty_event_pair_us"] = round(prof["empty_pair_ms"] * 1e3, 3)
 
     # measured streaming-read ceiling of this GPU (16 B/lane sum kernel over 2 GiB)
     probe = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
@@ -314,15 +343,31 @@ def main():
         v_tot = counts["early"] + counts["late"]
         bytes_per_unit = 4 + 8 + 16 + 3 * 64 + 4 * 64 + 8 * 64  # 988 B per visible meshlet (V=64, T=64), SURVEY 8(d) a11
         units = v_tot / 2.0  # two launches (early, late) share the visible set
-    dom_us = kernels.get(dom, {}).get("avg_us")
+    dom_us = (kernels.get(dom) or {}).get("avg_us")
     roofline = None
     if dom_us and dom_us > 0:
         achieved = bytes_per_unit * units / (dom_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": round(bytes_per_unit * units), "kernel_avg_us": dom_us,
                     "measured_stream_read_GBps": round(stream_read_gbps, 1),
                     "frac_of_measured_stream_read": round(achieved / stream_read_gbps, 4)}
+
+    # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary (collected in its own
+    # passes, FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 as MI355X_MICROARCH.md prescribes); PMC counters
+    # cannot be read from inside this process.
+    if roofline is not None:
+        try:
+            prof_name = {"config2": "r01_config2_pmc.json", "config3": "r01_config3_pmc.json", "config5": "r01_config5_pmc.json"}[args.workload]
+            with open(os.path.join(ROOT, "profiles", prof_name)) as fpm:
+                pm = json.load(fpm)
+            for kname, cs in pm.get("pmc", {}).items():
+                if dom in kname and ("<false, false, false" in kname or args.workload != "config2") and "hbm_read_bytes_corrected" in cs:
+                    roofline["traffic"] = cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0)
+                    roofline["traffic_source"] = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, per launch)"
+                    break
+        except (OSError, KeyError, ValueError):
+            pass
 
     # ---- CPU baseline: the scalar C oracle over the same arrays, all host cores ----
     cpu_baseline = None
@@ -382,6 +427,7 @@ def main():
                 "sharding": f"contiguous range per rank x{world}" if world > 1 else "single GPU",
             },
             "bit_match": bit_match,
+            "single_stream": single,
             "counts": counts,
             "kernels": kernels,
             "roofline": roofline,
