@@ -812,58 +812,96 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
 // ds_bpermute.  Same per-vertex arithmetic => same bits.  Result: a 64-bit pass mask per slot.
 // ------------------------------------------------------------------------------------------
 template <bool LATE>
-__global__ __launch_bounds__(256) void k_cull_triangles_test(TriTestArgs a) {
+__global__ __launch_bounds__(256, 8) void k_cull_triangles_test(TriTestArgs a) {
   __shared__ uint32_t s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
   const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;
+  constexpr int S = 16;  // slots per wave per chunk
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // lanes 0..15 fetch the headers of this wave's 16 slots in parallel
-    uint32_t h_mli = 0, h_mi = 0;
-    uint4 h_meshlet = make_uint4(0, 0, 0, 0);
-    uint64_t h_meshlets_ptr = 0;
+    // ---- headers: lanes 0..15 fetch the records of this wave's 16 slots in parallel ----
+    uint32_t h_mi = 0xFFFFFFFFu;
+    uint4 h_meshlet = make_uint4(0, 0, 0, 0);  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
+    uint64_t h_micro = 0, h_vidx = 0, h_pos = 0;
     {
       const uint32_t slot = chunk * kTriChunk + (uint32_t)(lane & 15) * 4 + wave;
-      if (lane < 16 && slot < V) {
-        h_mli = a.visible[first + slot];
-        uint2 r = reinterpret_cast<const uint2*>(a.meshlet_instances)[h_mli];
+      if (lane < S && slot < V) {
+        const uint32_t mli = a.visible[first + slot];
+        const uint2 r = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
         h_mi = r.x;
-        h_meshlets_ptr = a.cache[h_mi].meshlets;
-        h_meshlet = load_global_u4(h_meshlets_ptr, r.y);
+        const InstCache* row = a.cache + h_mi;
+        const uint64_t meshlets = row->meshlets;
+        h_micro = row->micro;
+        h_vidx = row->vidx;
+        h_pos = row->positions;
+        h_meshlet = load_global_u4(meshlets, r.y);
+        h_meshlet.z = min(h_meshlet.z, 64u);  // one lane per vertex / triangle (defines.slang:9-23)
+        h_meshlet.w = min(h_meshlet.w, 64u);
       }
+    }
+    // Per-slot uniform parameters out of the header lanes.
+    auto slot_u32 = [&](uint32_t v, int j) { return readlane_u(v, j); };
+    auto slot_u64 = [&](uint64_t v, int j) { return (uint64_t)readlane_u((uint32_t)v, j) | ((uint64_t)readlane_u((uint32_t)(v >> 32), j) << 32); };
+    // Two-deep software pipeline over the 16 slots: while slot j is being decided, slot j+1's
+    // positions and slot j+2's vertex / micro indices are already in flight (bytes in flight are
+    // what bounds this gather-heavy kernel).
+    auto issue_indices = [&](int j, uint32_t& vid, uint32_t& d0, uint32_t& d1) {
+      vid = 0;
+      d0 = 0;
+      d1 = 0;
+      if (j >= S) return;
+      const uint32_t vcount = slot_u32(h_meshlet.z, j), tcount = slot_u32(h_meshlet.w, j);
+      if ((uint32_t)lane < vcount) vid = load_global_u32(slot_u64(h_vidx, j), slot_u32(h_meshlet.x, j) + lane);
+      if ((uint32_t)lane < tcount) {  // scene.slang:336-342,365-372 via aligned dword loads
+        const uint32_t boff = slot_u32(h_meshlet.y, j) + (uint32_t)lane * 3u;
+        const uint64_t pm = slot_u64(h_micro, j);
+        d0 = load_global_u32(pm, boff >> 2);
+        d1 = load_global_u32(pm, (boff + 2u) >> 2);
+      }
+    };
+    auto issue_positions = [&](int j, uint32_t vid, uint2& q) {
+      q = make_uint2(0, 0);
+      if (j >= S) return;
+      if ((uint32_t)lane < slot_u32(h_meshlet.z, j)) q = load_global_u2(slot_u64(h_pos, j), vid);  // u16x4, stride 8
+    };
+    uint32_t vid1, m0_1, m1_1;      // slot j+1: vertex ids + micro dwords
+    uint32_t m0_0, m1_0;            // slot j:   micro dwords
+    uint2 q0;                       // slot j:   positions
+    {
+      uint32_t vid0;
+      issue_indices(0, vid0, m0_0, m1_0);
+      issue_indices(1, vid1, m0_1, m1_1);
+      issue_positions(0, vid0, q0);
     }
     uint32_t cnt = 0;
     uint32_t cur_mi = 0xFFFFFFFFu;
     float mvp[16];
-    uint64_t p_micro = 0, p_vidx = 0, p_pos = 0;
 #pragma unroll 1
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < S; j++) {
       const uint32_t slot = chunk * kTriChunk + (uint32_t)j * 4 + wave;
       if (slot >= V) break;  // wave-uniform
-      const uint32_t mi = readlane_u(h_mi, j);
-      const uint32_t vertex_offset = readlane_u(h_meshlet.x, j);
-      const uint32_t tri_offset = readlane_u(h_meshlet.y, j);
-      const uint32_t vertex_count = readlane_u(h_meshlet.z, j);
-      uint32_t tri_count = readlane_u(h_meshlet.w, j);
-      tri_count = tri_count < 64u ? tri_count : 64u;  // 64 threads, one triangle each (defines.slang:9-11)
-      if (mi != cur_mi) {  // wave-uniform
+      // ---- keep the pipeline full ----
+      uint2 q1;
+      issue_positions(j + 1, vid1, q1);
+      uint32_t vid2, m0_2, m1_2;
+      issue_indices(j + 2, vid2, m0_2, m1_2);
+      // ---- decide slot j ----
+      const uint32_t mi = slot_u32(h_mi, j);
+      const uint32_t vertex_count = slot_u32(h_meshlet.z, j);
+      const uint32_t tri_count = slot_u32(h_meshlet.w, j);
+      const uint32_t tri_offset = slot_u32(h_meshlet.y, j);
+      if (mi != cur_mi) {  // wave-uniform: projection_view * world of this mesh instance
         const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + mi);
         uint32_t v0 = p[lane];
-        uint32_t v1 = p[64 + (lane & 15)];
 #pragma unroll
         for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, 24 + k);
-        p_micro = (uint64_t)readlane_u(v1, 4) | ((uint64_t)readlane_u(v1, 5) << 32);
-        p_vidx = (uint64_t)readlane_u(v1, 6) | ((uint64_t)readlane_u(v1, 7) << 32);
-        p_pos = (uint64_t)readlane_u(v1, 8) | ((uint64_t)readlane_u(v1, 9) << 32);
         cur_mi = mi;
       }
       // vertex phase: lane = vertex
       float clx = 0.f, cly = 0.f, clz = -1.f, clw = 0.f;
       if ((uint32_t)lane < vertex_count) {
-        uint32_t vid = load_global_u32(p_vidx, vertex_offset + lane);
-        uint2 q = load_global_u2(p_pos, vid);  // u16x4, stride 8
-        float px = dequantize_half(q.x & 0xFFFFu), py = dequantize_half(q.x >> 16), pz = dequantize_half(q.y & 0xFFFFu);
+        float px = dequantize_half(q0.x & 0xFFFFu), py = dequantize_half(q0.x >> 16), pz = dequantize_half(q0.y & 0xFFFFu);
         clx = ((OXC_M(mvp, 0, 0) * px + OXC_M(mvp, 0, 1) * py) + OXC_M(mvp, 0, 2) * pz) + OXC_M(mvp, 0, 3);
         cly = ((OXC_M(mvp, 1, 0) * px + OXC_M(mvp, 1, 1) * py) + OXC_M(mvp, 1, 2) * pz) + OXC_M(mvp, 1, 3);
         clz = ((OXC_M(mvp, 2, 0) * px + OXC_M(mvp, 2, 1) * py) + OXC_M(mvp, 2, 2) * pz) + OXC_M(mvp, 2, 3);
@@ -872,12 +910,7 @@ __global__ __launch_bounds__(256) void k_cull_triangles_test(TriTestArgs a) {
       const uint64_t zok = __ballot(clz >= 0.0f);
       // triangle phase: lane = triangle
       uint32_t tri = 0;
-      if ((uint32_t)lane < tri_count) {  // scene.slang:336-342,365-372 via aligned dword loads
-        const uint32_t boff = tri_offset + (uint32_t)lane * 3u;
-        uint32_t d0 = load_global_u32(p_micro, boff >> 2);
-        uint32_t d1 = load_global_u32(p_micro, (boff + 2u) >> 2);
-        tri = __builtin_amdgcn_alignbyte(d1, d0, boff & 3u);
-      }
+      if ((uint32_t)lane < tri_count) tri = __builtin_amdgcn_alignbyte(m1_0, m0_0, (tri_offset + (uint32_t)lane * 3u) & 3u);
       const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
       const float ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
       const float bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
@@ -889,6 +922,13 @@ __global__ __launch_bounds__(256) void k_cull_triangles_test(TriTestArgs a) {
       const uint64_t mask = __ballot(passed);
       if (lane == 0) a.tri_masks[slot] = mask;
       cnt += (uint32_t)__popcll((unsigned long long)mask);
+      // ---- rotate the pipeline registers ----
+      q0 = q1;
+      m0_0 = m0_1;
+      m1_0 = m1_1;
+      vid1 = vid2;
+      m0_1 = m0_2;
+      m1_1 = m1_2;
     }
     __syncthreads();
     if (lane == 0) s_red[wave] = cnt;
@@ -912,6 +952,7 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
   __shared__ uint32_t s_off[256];
   __shared__ uint64_t s_mask[256];
   __shared__ uint32_t s_id[256];
+  __shared__ uint32_t s_strip[4 * 192];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;
@@ -939,19 +980,30 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
       a.draw_cmd[0] = (base + woff + incl) * 3u;  // DrawIndexedIndirect.index_count
     }
     __syncthreads();
-    // each wave expands 64 slots
+    // each wave expands 64 slots.  A slot's <= 192 packed indices are first laid out in rank order in a
+    // per-wave LDS strip, then written as contiguous 256-byte wave stores (a direct store would be
+    // three stride-12 scatters per slot: store-issue bound, profiles/r01_config3_pmc.json).
+    uint32_t* strip = s_strip + wave * 192;
 #pragma unroll 2
     for (int k = 0; k < 64; k++) {
       const int s = wave * 64 + k;
       const uint64_t m = s_mask[s];
+      if (m == 0ull) continue;  // wave-uniform
+      const uint32_t n3 = (uint32_t)__popcll((unsigned long long)m) * 3u;
+      const uint32_t o = (base + s_off[s]) * 3u;
       if ((m >> lane) & 1ull) {
         const uint32_t rank = (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-        const uint32_t o = (base + s_off[s] + rank) * 3u;
         const uint32_t packed = s_id[s] << 8;  // MESHLET_PRIMITIVE_BITS
         const uint32_t t3 = (uint32_t)lane * 3u;
-        a.out[o + 0] = packed | ((t3 + 0u) & 0xFFu);
-        a.out[o + 1] = packed | ((t3 + 1u) & 0xFFu);
-        a.out[o + 2] = packed | ((t3 + 2u) & 0xFFu);
+        strip[rank * 3u + 0] = packed | ((t3 + 0u) & 0xFFu);
+        strip[rank * 3u + 1] = packed | ((t3 + 1u) & 0xFFu);
+        strip[rank * 3u + 2] = packed | ((t3 + 2u) & 0xFFu);
+      }
+      // same wave, in-order LDS: the reads below see the writes above
+#pragma unroll
+      for (uint32_t r = 0; r < 3; r++) {
+        const uint32_t i = (uint32_t)lane + 64u * r;
+        if (i < n3) a.out[o + i] = strip[i];
       }
     }
     __syncthreads();
