@@ -13,8 +13,11 @@ Cache, so steps rotate over COPIES independent copies of the scene (>= 1 GB) to 
 triangle cull) on 10M meshlets instead; it is reported in the same format but is not the
 default line.  `--streams S` (default 3 for config 2) keeps S independent batches in flight: S contexts
 on S HIP streams inside one HIP graph -- a 1M-meshlet batch is launch/dependency-latency bound, so
-consecutive batches are overlapped the way independent views/frames would be; the one-batch-in-flight
-figure is reported next to it as "single_stream".
+consecutive batches are overlapped the way independent views/frames would be; the one-stream figure is
+reported next to it as "single_stream".  `--batch B` (default 4) culls B independent frames per
+oxc_cull_geometry_batch call: every stage is one launch with grid.y = B (a HIP graph sustains only ~3 us
+per kernel node on this platform, tools/launch_rate.py, so launches per frame are what limits a
+1M-meshlet batch).  A step is still one frame (one 1M-meshlet batch of synthetic input).
 
 Extra objects on the line: "roofline" (dominant kernel: algorithmic bytes / HIP-event kernel
 time vs the 8 TB/s HBM peak) and "cpu_baseline" (the scalar C oracle over the same arrays on
@@ -49,6 +52,7 @@ def parse():
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
     ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
     ap.add_argument("--streams", type=int, default=3, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
+    ap.add_argument("--batch", type=int, default=4, help="frames per oxc_cull_geometry_batch call (1 = one call per step; max 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
@@ -156,6 +160,22 @@ def main():
             view_cams.append(cam)
 
     single_stream = [False]  # instrumented pass: every context on stream 0, so kernels do not overlap
+    batch = max(1, min(4, args.batch)) if args.workload == "config2" else 1
+    groups = []  # (context index k, C arrays) : `batch` copies of the same context culled by ONE batched call
+    if batch > 1:
+        per_ctx = [[st for i, st in enumerate(steps) if i % n_streams == k] for k in range(n_streams)]
+        for k, lst in enumerate(per_ctx):
+            for j in range(0, len(lst) - len(lst) % batch, batch):
+                grp = lst[j:j + batch]
+                cf = (L.PreparedFrame * batch)(*[g_.cframe for g_ in grp])
+                cc = (L.CullGeometryContext * batch)(*[g_.cctx for g_ in grp])
+                groups.append((k, cf, cc))
+        assert groups, "--batch needs at least `batch` copies per stream"
+    steps_per_call = batch
+
+    def run_group(gi):
+        k, cf, cc = groups[gi % len(groups)]
+        check(lib.oxc_cull_geometry_batch(renderers[k]._ctx, batch, cf, cc, sps[0] if single_stream[0] else sps[k]))
 
     def run_step(i):
         st = steps[i % copies]
@@ -210,21 +230,29 @@ def main():
                 r.stream_read_probe(ramp, stream)
         torch.cuda.synchronize()
     del ramp
+    # a "unit" is one host call: one step, or `batch` steps through oxc_cull_geometry_batch
+    def run_unit(u):
+        if batch > 1:
+            run_group(u)
+        else:
+            run_step(u)
+
+    units_per_rotation = len(groups) if batch > 1 else copies
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):
-            run_step(i)
+        for u in range(-(-args.warmup // steps_per_call)):
+            run_unit(u)
     torch.cuda.synchronize()
 
     # ---- optional HIP graph over one rotation through the copies ----
     graph = None
-    per_replay = copies
+    per_replay = units_per_rotation * steps_per_call
     if not args.no_graph and not full and not multiview and args.steps >= per_replay:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             for s_ in streams[1:]:
                 s_.wait_stream(stream)  # fork: the side streams join the capture
-            for i in range(per_replay):
-                run_step(i)
+            for u in range(units_per_rotation):
+                run_unit(u)
             for s_ in streams[1:]:
                 stream.wait_stream(s_)  # join
         with torch.cuda.stream(stream):
@@ -253,7 +281,10 @@ def main():
                 done += per_replay
                 if dist is not None:  # per-rank visible counts -> every rank (north star's all-gather), bucketed per rotation
                     dist.all_gather_into_tensor(gathered, my_counts)
-        while done < args.steps:
+        while args.steps - done >= steps_per_call:
+            run_unit(done // steps_per_call)
+            done += steps_per_call
+        while done < args.steps:  # remainder smaller than a batch: single calls
             run_step(done)
             done += 1
         if dist is not None and graph is None:
@@ -274,8 +305,8 @@ def main():
         single_stream[0] = True
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, stream=stream):
-            for i in range(per_replay):
-                run_step(i)
+            for u in range(units_per_rotation):
+                run_unit(u)
         reps1 = max(2, min(args.steps // per_replay, 20))
         with torch.cuda.stream(stream):
             g1.replay()
@@ -292,13 +323,14 @@ def main():
         del g1
 
     # ---- instrumented pass: per-kernel HIP-event times on the same stream, same workload ----
-    prof_steps = min(args.steps, max(2 * copies, 96))
+    prof_units = max(1, min(args.steps, max(2 * copies, 96)) // steps_per_call)
+    prof_steps = prof_units * steps_per_call
     single_stream[0] = True
     for rr in renderers:
         rr.profile_begin()
     with torch.cuda.stream(stream):
-        for i in range(prof_steps):
-            run_step(i)
+        for u in range(prof_units):
+            run_unit(u)
     prof = {"kernels": {}, "empty_pair_ms": 0.0}
     for rr in renderers:
         p_ = rr.profile_end()
@@ -337,7 +369,7 @@ def main():
         # 212/K B + 4*v B of visible indices written (the write is done by cull_meshlets_emit; it is
         # charged to the stage, i.e. to this launch, as 8(d) does).
         bytes_per_unit = 24.0 + 212.0 / K + 4.0 * visible_fraction
-        units = n_meshlets
+        units = n_meshlets * steps_per_call  # one launch covers `batch` frames
     else:
         dom = "cull_triangles_test"
         v_tot = counts["early"] + counts["late"]
@@ -362,7 +394,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", prof_name)) as fpm:
                 pm = json.load(fpm)
             for kname, cs in pm.get("pmc", {}).items():
-                if dom in kname and ("<false, false, false" in kname or args.workload != "config2") and "hbm_read_bytes_corrected" in cs:
+                ok_variant = args.workload != "config2" or ("_batch" in kname) == (steps_per_call > 1) and ("_batch" in kname or "<false, false, false" in kname)
+                if dom in kname and ok_variant and "hbm_read_bytes_corrected" in cs:
                     roofline["traffic"] = cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0)
                     roofline["traffic_source"] = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, per launch)"
                     break
@@ -423,7 +456,7 @@ def main():
                              f"configs[4]: 10M meshlets x {args.views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"),
                 "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K,
                 "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
-                "hip_graph": graph is not None, "streams": n_streams, "visible_fraction": round(visible_fraction, 4),
+                "hip_graph": graph is not None, "streams": n_streams, "frames_per_launch": steps_per_call, "visible_fraction": round(visible_fraction, 4),
                 "sharding": f"contiguous range per rank x{world}" if world > 1 else "single GPU",
             },
             "bit_match": bit_match,

@@ -181,6 +181,16 @@ oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* conte
 oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* frame, oxc_cull_geometry_context* context,
                              void* hip_stream);
 
+/* Batched form: semantically `for i < count: oxc_cull_geometry(ctx, &frames[i], &contexts[i], stream)` for
+ * INDEPENDENT frames (no buffer of one element is written by another) -- several views or scenes culled per
+ * launch, the way the reference's cull_meshlets_hpb handles all clipmap views in one dispatch.  When every
+ * element uses the plain pipeline (use_hiz == use_hpb == 0, no LatePass) with the same `stages` and
+ * `init_cull_meshes`, and count <= 4, each stage is ONE launch with grid.y = count; otherwise the elements
+ * are processed one after the other.  A 1M-meshlet call is launch-latency bound on MI355X (a HIP graph
+ * sustains ~3 us per kernel node); batching is what amortises it. */
+oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepared_frame* frames,
+                                   oxc_cull_geometry_context* contexts, void* hip_stream);
+
 /* Harness helper: start a cull sequence from a caller-provided MeshletInstance list instead of
  * running cull_meshes (fills context->visibility_buffer = {total,0,0} and
  * cull_meshlets_cmd_buffer = {ceil(total/64),1,1}).  The reference always derives these from

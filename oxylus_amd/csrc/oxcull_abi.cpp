@@ -26,6 +26,8 @@ constexpr uint32_t kSlots = 1024;  // counter-slot ring; pointers stay valid for
 constexpr uint32_t kMaxPackedInstances = 1u << 24;  // MESHLET_INSTANCE_ID_BITS, visbuffer.slang:9-10
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+// (Sizing persistent grids to the exact SGPR-limited residency and balancing chunks per block was tried:
+// no gain for the plain kernel, 183 -> 219 us for the HiZ variant; oversubscribed grids schedule better.)
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
@@ -33,27 +35,32 @@ struct oxc_ctx {
   int device = 0;
   uint32_t num_cus = 256;
   std::string last_error;
-  // scratch arena
-  void* arena = nullptr;
-  uint64_t arena_bytes = 0;
-  uint32_t cap_mesh_instances = 0, cap_meshlets = 0;
-  InstCache* cache = nullptr;
-  InstCache* view_cache = nullptr;  // [views][M] rows for use_hpb
-  uint32_t cap_views = 0;
-  uint32_t* mesh_counts = nullptr;
-  uint32_t* mesh_offsets = nullptr;
-  uint64_t* bits = nullptr;
-  uint32_t* m_chunk_counts = nullptr;
-  uint32_t* m_supers = nullptr;
-  uint64_t* tri_masks = nullptr;
-  uint32_t* t_chunk_counts = nullptr;
-  uint32_t* t_supers = nullptr;
-  // fused-emit hand-off state (zeroed at allocation; self-resetting afterwards)
-  uint64_t* chunk_gran = nullptr;
-  uint64_t* super_gran = nullptr;
-  uint32_t* super_arrive = nullptr;
-  uint32_t* super_done = nullptr;
-  uint32_t* fsync = nullptr;
+  // scratch: one lane per batch element (lane 0 serves the single-frame entry points)
+  struct Lane {
+    void* arena = nullptr;
+    uint64_t arena_bytes = 0;
+    uint32_t cap_mesh_instances = 0, cap_meshlets = 0;
+    InstCache* cache = nullptr;
+    InstCache* view_cache = nullptr;  // [views][M] rows for use_hpb
+    uint32_t cap_views = 0;
+    uint32_t* mesh_counts = nullptr;
+    uint32_t* mesh_offsets = nullptr;
+    uint64_t* bits = nullptr;
+    uint32_t* m_chunk_counts = nullptr;
+    uint32_t* m_supers = nullptr;
+    uint64_t* tri_masks = nullptr;
+    uint32_t* t_chunk_counts = nullptr;
+    uint32_t* t_supers = nullptr;
+    // fused-emit hand-off state (zeroed at allocation; self-resetting afterwards)
+    uint64_t* chunk_gran = nullptr;
+    uint64_t* super_gran = nullptr;
+    uint32_t* super_arrive = nullptr;
+    uint32_t* super_done = nullptr;
+    uint32_t* fsync = nullptr;
+  };
+  Lane lane[kMaxBatch];
+  BatchBlob* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call
+  uint32_t ablate = 0;      // OXC_ABLATE: timing experiments only, results are wrong when set
   bool fused_emit = false;  // experiment, off by default: measured 38 us/step vs 26 us/step unfused
   // counter slots
   uint32_t* slots = nullptr;
@@ -89,12 +96,13 @@ oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hi
     if (_e != hipSuccess) return fail(ctx, OXC_HIP_ERROR, #expr, _e); \
   } while (0)
 
-oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets, uint32_t views = 0) {
-  if (mesh_instances <= ctx->cap_mesh_instances && meshlets <= ctx->cap_meshlets && views <= ctx->cap_views && ctx->arena) return OXC_OK;
-  const uint32_t Vw = std::max(views, ctx->cap_views);
-  uint32_t M = std::max(std::max(mesh_instances, ctx->cap_mesh_instances), 1u);
-  uint32_t N = std::max(std::max(meshlets, ctx->cap_meshlets), 1u);
-  const uint32_t m_chunks = cdiv(N, kMeshletChunk), t_chunks = cdiv(N, kTriChunk);
+oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets, uint32_t views = 0, uint32_t lane_index = 0) {
+  oxc_ctx::Lane* L = &ctx->lane[lane_index];
+  if (mesh_instances <= L->cap_mesh_instances && meshlets <= L->cap_meshlets && views <= L->cap_views && L->arena) return OXC_OK;
+  const uint32_t Vw = std::max(views, L->cap_views);
+  uint32_t M = std::max(std::max(mesh_instances, L->cap_mesh_instances), 1u);
+  uint32_t N = std::max(std::max(meshlets, L->cap_meshlets), 1u);
+  const uint32_t m_chunks = cdiv(N, 128u), t_chunks = cdiv(N, kTriChunk);  // meshlet counts: per wave step, >= 128 meshlets
   uint64_t off = 0;
   auto carve = [&](uint64_t bytes) {
     uint64_t o = off;
@@ -107,10 +115,10 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_offsets = carve((uint64_t)M * 4);
   const uint64_t o_bits = carve((uint64_t)cdiv(N, 64) * 8);
   const uint64_t o_mcc = carve((uint64_t)m_chunks * 4);
-  const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
+  const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4 * kSuperStride);
   const uint64_t o_tm = carve((uint64_t)N * 8);
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
-  const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4);
+  const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
   const uint64_t o_sync0 = off;
   const uint64_t o_cgran = carve((uint64_t)m_chunks * 8);
   const uint64_t o_sgran = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 8);
@@ -118,34 +126,34 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_sdone = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
   const uint64_t o_fsync = carve(64);
   OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old arena
-  if (ctx->arena) OXC_HIP(ctx, hipFree(ctx->arena));
-  ctx->arena = nullptr;
-  hipError_t e = hipMalloc(&ctx->arena, off);
+  if (L->arena) OXC_HIP(ctx, hipFree(L->arena));
+  L->arena = nullptr;
+  hipError_t e = hipMalloc(&L->arena, off);
   if (e != hipSuccess) {
-    ctx->cap_mesh_instances = ctx->cap_meshlets = 0;
+    L->cap_mesh_instances = L->cap_meshlets = 0;
     return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(scratch arena)", e);
   }
-  ctx->arena_bytes = off;
-  char* b = static_cast<char*>(ctx->arena);
-  ctx->cache = reinterpret_cast<InstCache*>(b + o_cache);
-  ctx->view_cache = reinterpret_cast<InstCache*>(b + o_vcache);
-  ctx->cap_views = Vw;
-  ctx->mesh_counts = reinterpret_cast<uint32_t*>(b + o_counts);
-  ctx->mesh_offsets = reinterpret_cast<uint32_t*>(b + o_offsets);
-  ctx->bits = reinterpret_cast<uint64_t*>(b + o_bits);
-  ctx->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
-  ctx->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
-  ctx->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
-  ctx->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
-  ctx->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
-  ctx->chunk_gran = reinterpret_cast<uint64_t*>(b + o_cgran);
-  ctx->super_gran = reinterpret_cast<uint64_t*>(b + o_sgran);
-  ctx->super_arrive = reinterpret_cast<uint32_t*>(b + o_sarr);
-  ctx->super_done = reinterpret_cast<uint32_t*>(b + o_sdone);
-  ctx->fsync = reinterpret_cast<uint32_t*>(b + o_fsync);
+  L->arena_bytes = off;
+  char* b = static_cast<char*>(L->arena);
+  L->cache = reinterpret_cast<InstCache*>(b + o_cache);
+  L->view_cache = reinterpret_cast<InstCache*>(b + o_vcache);
+  L->cap_views = Vw;
+  L->mesh_counts = reinterpret_cast<uint32_t*>(b + o_counts);
+  L->mesh_offsets = reinterpret_cast<uint32_t*>(b + o_offsets);
+  L->bits = reinterpret_cast<uint64_t*>(b + o_bits);
+  L->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
+  L->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
+  L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
+  L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
+  L->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
+  L->chunk_gran = reinterpret_cast<uint64_t*>(b + o_cgran);
+  L->super_gran = reinterpret_cast<uint64_t*>(b + o_sgran);
+  L->super_arrive = reinterpret_cast<uint32_t*>(b + o_sarr);
+  L->super_done = reinterpret_cast<uint32_t*>(b + o_sdone);
+  L->fsync = reinterpret_cast<uint32_t*>(b + o_fsync);
   OXC_HIP(ctx, hipMemset(b + o_sync0, 0, off - o_sync0));
-  ctx->cap_mesh_instances = M;
-  ctx->cap_meshlets = N;
+  L->cap_mesh_instances = M;
+  L->cap_meshlets = N;
   return OXC_OK;
 }
 
@@ -188,6 +196,65 @@ bool image_ok(const oxc_image& im) { return im.dptr && im.width && im.height && 
 
 }  // namespace
 
+// Everything oxc_cull_geometry derives from (frame, context) before it touches the device.
+struct CallInfo {
+  uint32_t stages, M, N, views;
+  bool do_meshes, do_meshlets, do_tris, occl, late;
+};
+
+static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const oxc_cull_geometry_context* c, CallInfo& ci) {
+  if (!f || !c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: bad frame/context struct");
+  const uint32_t stages = c->stages ? c->stages : (uint32_t)OXC_STAGE_ALL;
+  const uint32_t M = f->mesh_instance_count, N = f->max_meshlet_instance_count;
+  const bool do_meshes = c->init_cull_meshes && (stages & OXC_STAGE_MESHES);
+  const bool do_meshlets = (stages & OXC_STAGE_MESHLETS) != 0;
+  const bool do_tris = (stages & OXC_STAGE_TRIANGLES) != 0;
+  if (c->cull_camera.mesh_instance_count != M) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: cull_camera.mesh_instance_count != frame.mesh_instance_count");
+  if (M && (!f->meshes_buffer.dptr || !f->transforms_world_buffer.dptr || !f->mesh_instances_buffer.dptr))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshes/transforms/mesh_instances buffer missing");
+  if (f->mesh_instances_buffer.bytes < (uint64_t)M * sizeof(GpuMeshInstance)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: mesh_instances_buffer too small");
+  if (N && (!f->meshlet_instances_buffer.dptr || f->meshlet_instances_buffer.bytes < (uint64_t)N * 8))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshlet_instances_buffer missing or < 8*N bytes");
+  if (do_meshlets && N && (!f->visible_meshlet_instances_indices_buffer.dptr || f->visible_meshlet_instances_indices_buffer.bytes < (uint64_t)N * 4))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visible_meshlet_instances_indices_buffer missing or < 4*N bytes");
+  if (do_tris && N) {
+    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * 64 * 3 * 4)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes");
+    if (N > kMaxPackedInstances) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: > 2^24 meshlet instances do not fit the packed index (visbuffer.slang:9-14)");
+  }
+  const bool occl = (c->cull_flags & OXC_CULL_TEST_OCCLUSION) != 0;
+  const bool late = (c->cull_flags & OXC_CULL_LATE_PASS) != 0;
+  if (c->use_hiz && do_meshlets) {
+    if (!image_ok(c->hiz_attachment)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz without a hiz_attachment");
+    if (occl && N && (!f->meshlet_instance_visibility_mask_buffer.dptr))
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing");
+  }
+  const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
+  if (c->use_hpb && do_meshlets) {
+    if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
+    if (views == 0 || views > 16) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: vsm_clipmap_count must be 1..16");
+    if (!c->vsm_clipmaps_buffer.dptr || c->vsm_clipmaps_buffer.bytes < (uint64_t)views * sizeof(oxc_virtual_clipmap) || !c->vsm_clipmap_dirty_flags_buffer.dptr)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb needs vsm_clipmaps_buffer / vsm_clipmap_dirty_flags_buffer");
+    const oxc_image_array_u8& h = c->hpb_attachment;
+    if (!h.dptr || !h.width || !h.height || h.layers < views || h.levels < 1 || h.levels > 13)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb without a valid hpb_attachment (layers >= clipmaps, 1..13 levels)");
+  }
+  if (!c->init_cull_meshes && (!c->visibility_buffer.dptr || !c->cull_meshlets_cmd_buffer.dptr))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: init_cull_meshes=false needs the visibility/cull_meshlets_cmd buffers of the sequence");
+
+
+  ci.stages = stages;
+  ci.M = M;
+  ci.N = N;
+  ci.views = views;
+  ci.do_meshes = do_meshes;
+  ci.do_meshlets = do_meshlets;
+  ci.do_tris = do_tris;
+  ci.occl = occl;
+  ci.late = late;
+  return OXC_OK;
+}
+
 extern "C" {
 
 uint32_t oxc_abi_version(void) { return OXC_ABI_VERSION; }
@@ -214,6 +281,7 @@ oxc_status oxc_create(int device, oxc_ctx** out) {
   (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
   ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
   if (const char* e = std::getenv("OXC_FUSED_EMIT")) ctx->fused_emit = e[0] != '0';
+  if (const char* e = std::getenv("OXC_ABLATE")) ctx->ablate = (uint32_t)std::atoi(e);
   *out = ctx;
   return OXC_OK;
 }
@@ -222,7 +290,9 @@ void oxc_destroy(oxc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  if (ctx->arena) (void)hipFree(ctx->arena);
+  for (auto& ln : ctx->lane)
+    if (ln.arena) (void)hipFree(ln.arena);
+  if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
   if (ctx->slots) (void)hipFree(ctx->slots);
   delete ctx;
 }
@@ -282,45 +352,13 @@ oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c
 
 oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull_geometry_context* c, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
-  if (!f || !c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: bad frame/context struct");
-  const uint32_t stages = c->stages ? c->stages : (uint32_t)OXC_STAGE_ALL;
-  const uint32_t M = f->mesh_instance_count, N = f->max_meshlet_instance_count;
-  const bool do_meshes = c->init_cull_meshes && (stages & OXC_STAGE_MESHES);
-  const bool do_meshlets = (stages & OXC_STAGE_MESHLETS) != 0;
-  const bool do_tris = (stages & OXC_STAGE_TRIANGLES) != 0;
-  if (c->cull_camera.mesh_instance_count != M) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: cull_camera.mesh_instance_count != frame.mesh_instance_count");
-  if (M && (!f->meshes_buffer.dptr || !f->transforms_world_buffer.dptr || !f->mesh_instances_buffer.dptr))
-    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshes/transforms/mesh_instances buffer missing");
-  if (f->mesh_instances_buffer.bytes < (uint64_t)M * sizeof(GpuMeshInstance)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: mesh_instances_buffer too small");
-  if (N && (!f->meshlet_instances_buffer.dptr || f->meshlet_instances_buffer.bytes < (uint64_t)N * 8))
-    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshlet_instances_buffer missing or < 8*N bytes");
-  if (do_meshlets && N && (!f->visible_meshlet_instances_indices_buffer.dptr || f->visible_meshlet_instances_indices_buffer.bytes < (uint64_t)N * 4))
-    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visible_meshlet_instances_indices_buffer missing or < 4*N bytes");
-  if (do_tris && N) {
-    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * 64 * 3 * 4)
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes");
-    if (N > kMaxPackedInstances) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: > 2^24 meshlet instances do not fit the packed index (visbuffer.slang:9-14)");
+  CallInfo ci;
+  {
+    oxc_status vst = check_call(ctx, f, c, ci);
+    if (vst != OXC_OK) return vst;
   }
-  const bool occl = (c->cull_flags & OXC_CULL_TEST_OCCLUSION) != 0;
-  const bool late = (c->cull_flags & OXC_CULL_LATE_PASS) != 0;
-  if (c->use_hiz && do_meshlets) {
-    if (!image_ok(c->hiz_attachment)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz without a hiz_attachment");
-    if (occl && N && (!f->meshlet_instance_visibility_mask_buffer.dptr))
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing");
-  }
-  const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
-  if (c->use_hpb && do_meshlets) {
-    if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
-    if (views == 0 || views > 16) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: vsm_clipmap_count must be 1..16");
-    if (!c->vsm_clipmaps_buffer.dptr || c->vsm_clipmaps_buffer.bytes < (uint64_t)views * sizeof(oxc_virtual_clipmap) || !c->vsm_clipmap_dirty_flags_buffer.dptr)
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb needs vsm_clipmaps_buffer / vsm_clipmap_dirty_flags_buffer");
-    const oxc_image_array_u8& h = c->hpb_attachment;
-    if (!h.dptr || !h.width || !h.height || h.layers < views || h.levels < 1 || h.levels > 13)
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb without a valid hpb_attachment (layers >= clipmaps, 1..13 levels)");
-  }
-  if (!c->init_cull_meshes && (!c->visibility_buffer.dptr || !c->cull_meshlets_cmd_buffer.dptr))
-    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: init_cull_meshes=false needs the visibility/cull_meshlets_cmd buffers of the sequence");
-
+  const uint32_t M = ci.M, N = ci.N, views = ci.views;
+  const bool do_meshes = ci.do_meshes, do_meshlets = ci.do_meshlets, do_tris = ci.do_tris, occl = ci.occl, late = ci.late;
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   oxc_status st = ensure_capacity(ctx, M, N, views);
   if (st != OXC_OK) return st;
@@ -358,14 +396,14 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
   pa.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
   pa.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
-  pa.cache = ctx->cache;
-  pa.mesh_counts = ctx->mesh_counts;
+  pa.cache = ctx->lane[0].cache;
+  pa.mesh_counts = ctx->lane[0].mesh_counts;
   pa.slot = slot;
   pa.vis = vis;
   pa.meshlets_cmd = meshlets_cmd;
-  pa.supers_meshlets = ctx->m_supers;
-  pa.supers_tris = ctx->t_supers;
-  pa.n_supers_meshlets = cdiv(m_chunks, kChunksPerSuper);
+  pa.supers_meshlets = ctx->lane[0].m_supers;
+  pa.supers_tris = ctx->lane[0].t_supers;
+  pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 128u), kChunksPerSuper);
   pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
   pa.mesh_instance_count = M;
   pa.cull_flags = c->cull_flags;
@@ -374,7 +412,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.seed_total = 0;
   pa.cam = c->cull_camera;
   pa.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
-  pa.view_cache = ctx->view_cache;
+  pa.view_cache = ctx->lane[0].view_cache;
   const uint32_t prep_threads = std::max(std::max(M * 8u, pa.n_supers_tris), 1u);  // 8 lanes per mesh instance
   {
     KernelTimer t(ctx, OXC_K_PREPARE, s);
@@ -383,23 +421,23 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   if (do_meshes) {
     {
       KernelTimer t(ctx, OXC_K_MESHES_SCAN, s);
-      launch_scan_mesh_counts(ctx->mesh_counts, ctx->mesh_offsets, M, vis, meshlets_cmd, s);
+      launch_scan_mesh_counts(ctx->lane[0].mesh_counts, ctx->lane[0].mesh_offsets, M, vis, meshlets_cmd, s);
     }
     KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
-    launch_expand(ctx->mesh_counts, ctx->mesh_offsets, M, f->meshlet_instances_buffer.dptr, std::max(std::min(cdiv(M, 4), max_grid), 1u), s);
+    launch_expand(ctx->lane[0].mesh_counts, ctx->lane[0].mesh_offsets, M, f->meshlet_instances_buffer.dptr, std::max(std::min(cdiv(M, 4), max_grid), 1u), s);
   }
 
   // --- meshlet stage: CullGeometry.cpp:129-335
   if (do_meshlets && c->use_hpb) {  // CullGeometry.cpp:199-273
     HpbTestArgs ha;
     std::memset(&ha, 0, sizeof ha);
-    ha.cache = ctx->cache;
-    ha.view_cache = ctx->view_cache;
+    ha.cache = ctx->lane[0].cache;
+    ha.view_cache = ctx->lane[0].view_cache;
     ha.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ha.vis = vis;
-    ha.bits = ctx->bits;
-    ha.chunk_counts = ctx->m_chunk_counts;
-    ha.supers = ctx->m_supers;
+    ha.bits = ctx->lane[0].bits;
+    ha.chunk_counts = ctx->lane[0].m_chunk_counts;
+    ha.supers = ctx->lane[0].m_supers;
     ha.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
     ha.dirty = static_cast<const uint32_t*>(c->vsm_clipmap_dirty_flags_buffer.dptr);
     ha.clipmap_count = views;
@@ -418,9 +456,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     MeshletEmitArgs ea;
     ea.n_host = 0;
-    ea.bits = ctx->bits;
-    ea.chunk_counts = ctx->m_chunk_counts;
-    ea.supers = ctx->m_supers;
+    ea.count_meshlets = kMeshletChunk;  // the HPB test kernel publishes one count per 1024-meshlet block
+    ea.bits = ctx->lane[0].bits;
+    ea.chunk_counts = ctx->lane[0].m_chunk_counts;
+    ea.supers = ctx->lane[0].m_supers;
     ea.vis = vis;
     ea.tri_cmd = tri_cmd;
     ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
@@ -429,14 +468,15 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   } else if (do_meshlets) {
     MeshletTestArgs ta;
     std::memset(&ta, 0, sizeof ta);
+    ta.ablate = ctx->ablate;
     ta.n_host = n_host;
-    ta.cache = ctx->cache;
+    ta.cache = ctx->lane[0].cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ta.vis = vis;
     ta.mask = static_cast<uint32_t*>(f->meshlet_instance_visibility_mask_buffer.dptr);
-    ta.bits = ctx->bits;
-    ta.chunk_counts = ctx->m_chunk_counts;
-    ta.supers = ctx->m_supers;
+    ta.bits = ctx->lane[0].bits;
+    ta.chunk_counts = ctx->lane[0].m_chunk_counts;
+    ta.supers = ctx->lane[0].m_supers;
     if (c->use_hiz) {
       const oxc_image& h = c->hiz_attachment;
       ta.hiz_data = static_cast<const float*>(h.dptr);
@@ -468,11 +508,11 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     const uint32_t exact_chunks = n_host ? cdiv(n_host, kMeshletChunk) : 0u;
     const bool fused = ctx->fused_emit && !c->use_hiz && n_host != 0 && exact_chunks <= ctx->num_cus * 4u;
     if (fused) {
-      ta.chunk_gran = ctx->chunk_gran;
-      ta.super_gran = ctx->super_gran;
-      ta.super_arrive = ctx->super_arrive;
-      ta.super_done = ctx->super_done;
-      ta.sync = ctx->fsync;
+      ta.chunk_gran = ctx->lane[0].chunk_gran;
+      ta.super_gran = ctx->lane[0].super_gran;
+      ta.super_arrive = ctx->lane[0].super_arrive;
+      ta.super_done = ctx->lane[0].super_done;
+      ta.sync = ctx->lane[0].fsync;
       ta.tri_cmd = tri_cmd;
       ta.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
       launch_meshlets_fused(ta, exact_chunks, s);
@@ -483,9 +523,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     if (!(ctx->fused_emit && !c->use_hiz && n_host != 0 && cdiv(n_host, kMeshletChunk) <= ctx->num_cus * 4u)) {
     MeshletEmitArgs ea;
     ea.n_host = n_host;
-    ea.bits = ctx->bits;
-    ea.chunk_counts = ctx->m_chunk_counts;
-    ea.supers = ctx->m_supers;
+    ea.count_meshlets = c->use_hiz ? 128u : 256u;  // one count per wave step: 64 * groups per wave
+    ea.bits = ctx->lane[0].bits;
+    ea.chunk_counts = ctx->lane[0].m_chunk_counts;
+    ea.supers = ctx->lane[0].m_supers;
     ea.vis = vis;
     ea.tri_cmd = tri_cmd;
     ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
@@ -497,29 +538,200 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   // --- triangle stage: CullGeometry.cpp:337-403
   if (do_tris) {
     TriTestArgs tt;
-    tt.cache = ctx->cache;
+    tt.cache = ctx->lane[0].cache;
     tt.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     tt.visible = static_cast<const uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
     tt.vis = vis;
     tt.tri_cmd = tri_cmd;
-    tt.tri_masks = ctx->tri_masks;
-    tt.chunk_counts = ctx->t_chunk_counts;
-    tt.supers = ctx->t_supers;
+    tt.tri_masks = ctx->lane[0].tri_masks;
+    tt.chunk_counts = ctx->lane[0].t_chunk_counts;
+    tt.supers = ctx->lane[0].t_supers;
     {
       KernelTimer t(ctx, OXC_K_TRIANGLES_TEST, s);
       launch_tris_test(tt, late, std::min(t_chunks, max_grid), s);
     }
     TriEmitArgs te;
-    te.tri_masks = ctx->tri_masks;
+    te.tri_masks = ctx->lane[0].tri_masks;
     te.visible = tt.visible;
     te.vis = vis;
     te.tri_cmd = tri_cmd;
-    te.chunk_counts = ctx->t_chunk_counts;
-    te.supers = ctx->t_supers;
+    te.chunk_counts = ctx->lane[0].t_chunk_counts;
+    te.supers = ctx->lane[0].t_supers;
     te.draw_cmd = draw_cmd;
     te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     KernelTimer t(ctx, OXC_K_TRIANGLES_EMIT, s);
     launch_tris_emit(te, late, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
+  }
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepared_frame* frames, oxc_cull_geometry_context* contexts,
+                                   void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (count == 0) return OXC_OK;
+  if (!frames || !contexts) return fail(ctx, OXC_INVALID_ARG, "cull_geometry_batch: null frames/contexts");
+  CallInfo ci[kMaxBatch];
+  bool fusable = count > 1 && count <= kMaxBatch;
+  for (uint32_t e = 0; fusable && e < count; e++) {
+    oxc_status vst = check_call(ctx, &frames[e], &contexts[e], ci[e]);
+    if (vst != OXC_OK) return vst;
+    const oxc_cull_geometry_context& c = contexts[e];
+    fusable = !c.use_hiz && !c.use_hpb && !ci[e].late && ci[e].stages == ci[0].stages && ci[e].do_meshes == ci[0].do_meshes &&
+              (c.init_cull_meshes != 0) == (contexts[0].init_cull_meshes != 0);
+  }
+  if (!fusable) {
+    for (uint32_t e = 0; e < count; e++) {
+      oxc_status st = oxc_cull_geometry(ctx, &frames[e], &contexts[e], hip_stream);
+      if (st != OXC_OK) return st;
+    }
+    return OXC_OK;
+  }
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  for (uint32_t e = 0; e < count; e++) {
+    oxc_status st = ensure_capacity(ctx, ci[e].M, ci[e].N, 0, e);
+    if (st != OXC_OK) return st;
+  }
+  if (!ctx->batch_dev) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->batch_dev), sizeof(BatchBlob));
+    if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(batch argument block)", e);
+  }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const uint32_t max_grid = ctx->num_cus * 8;
+  const bool do_meshes = ci[0].do_meshes, do_meshlets = ci[0].do_meshlets, do_tris = ci[0].do_tris;
+  BatchBlob blob;
+  std::memset(&blob, 0, sizeof blob);
+  blob.count = count;
+  uint32_t g_prep = 1, g_expand = 1, g_test = 1, g_emit = 1, g_ttest = 1, g_temit = 1;
+  for (uint32_t e = 0; e < count; e++) {
+    const oxc_prepared_frame* f = &frames[e];
+    oxc_cull_geometry_context* c = &contexts[e];
+    oxc_ctx::Lane& L = ctx->lane[e];
+    const uint32_t M = ci[e].M, N = ci[e].N;
+    uint32_t* slot = next_slot(ctx);
+    uint32_t *vis, *meshlets_cmd;
+    uint32_t n_host = 0;
+    if (c->init_cull_meshes) {
+      vis = slot + SLOT_VIS;
+      meshlets_cmd = slot + SLOT_MESHLETS_CMD;
+      c->visibility_buffer = {vis, 12};
+      c->cull_meshlets_cmd_buffer = {meshlets_cmd, 12};
+    } else {
+      vis = static_cast<uint32_t*>(c->visibility_buffer.dptr);
+      meshlets_cmd = static_cast<uint32_t*>(c->cull_meshlets_cmd_buffer.dptr);
+      if (vis >= ctx->slots && vis < ctx->slots + (size_t)kSlots * SLOT_U32S && ((vis - ctx->slots) % SLOT_U32S) == SLOT_VIS)
+        n_host = ctx->seeded_total[(vis - ctx->slots) / SLOT_U32S];
+      if (n_host > N) n_host = 0;
+    }
+    uint32_t* tri_cmd = slot + SLOT_TRI_CMD;
+    uint32_t* draw_cmd = slot + SLOT_DRAW_CMD;
+    c->cull_triangles_cmd_buffer = {tri_cmd, 12};
+    c->draw_geometry_cmd_buffer = {draw_cmd, 20};
+    const uint32_t m_chunks = cdiv(std::max(N, 1u), kMeshletChunk), t_chunks = cdiv(std::max(N, 1u), kTriChunk);
+
+    PrepareArgs& pa = blob.prep[e];
+    pa.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
+    pa.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
+    pa.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
+    pa.cache = L.cache;
+    pa.mesh_counts = L.mesh_counts;
+    pa.slot = slot;
+    pa.vis = vis;
+    pa.meshlets_cmd = meshlets_cmd;
+    pa.supers_meshlets = L.m_supers;
+    pa.supers_tris = L.t_supers;
+    pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 128u), kChunksPerSuper);
+    pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
+    pa.mesh_instance_count = M;
+    pa.cull_flags = c->cull_flags;
+    pa.do_cull_meshes = do_meshes ? 1u : 0u;
+    pa.init_vis = c->init_cull_meshes ? 1u : 0u;
+    pa.seed_total = 0;
+    pa.cam = c->cull_camera;
+    pa.clipmaps = nullptr;
+    pa.view_cache = L.view_cache;
+    g_prep = std::max(g_prep, std::min(cdiv(std::max(std::max(M * 8u, pa.n_supers_tris), 1u), 256), max_grid));
+
+    blob.scan[e] = ScanArgs{L.mesh_counts, L.mesh_offsets, M, vis, meshlets_cmd};
+    blob.expand[e] = ExpandArgs{L.mesh_counts, L.mesh_offsets, M, static_cast<GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr)};
+    g_expand = std::max(g_expand, std::max(std::min(cdiv(M, 4), max_grid), 1u));
+
+    MeshletTestArgs& ta = blob.test[e];
+    ta.ablate = ctx->ablate;
+    ta.n_host = n_host;
+    ta.cache = L.cache;
+    ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
+    ta.vis = vis;
+    ta.mask = nullptr;
+    ta.bits = L.bits;
+    ta.chunk_counts = L.m_chunk_counts;
+    ta.supers = L.m_supers;
+    ta.near_clip = c->cull_camera.near_clip;
+    std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
+    g_test = std::max(g_test, std::min(m_chunks, max_grid));
+
+    MeshletEmitArgs& ea = blob.emit[e];
+    ea.n_host = n_host;
+    ea.count_meshlets = 256u;
+    ea.bits = L.bits;
+    ea.chunk_counts = L.m_chunk_counts;
+    ea.supers = L.m_supers;
+    ea.vis = vis;
+    ea.tri_cmd = tri_cmd;
+    ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    g_emit = std::max(g_emit, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid));
+
+    TriTestArgs& tt = blob.ttest[e];
+    tt.cache = L.cache;
+    tt.meshlet_instances = ta.meshlet_instances;
+    tt.visible = ea.out;
+    tt.vis = vis;
+    tt.tri_cmd = tri_cmd;
+    tt.tri_masks = L.tri_masks;
+    tt.chunk_counts = L.t_chunk_counts;
+    tt.supers = L.t_supers;
+    g_ttest = std::max(g_ttest, std::min(t_chunks, max_grid));
+
+    TriEmitArgs& te = blob.temit[e];
+    te.tri_masks = L.tri_masks;
+    te.visible = ea.out;
+    te.vis = vis;
+    te.tri_cmd = tri_cmd;
+    te.chunk_counts = L.t_chunk_counts;
+    te.supers = L.t_supers;
+    te.draw_cmd = draw_cmd;
+    te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
+    g_temit = std::max(g_temit, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid));
+  }
+  // grid.y = count; a modest grid.x cap keeps the whole batch within the resident-block budget
+  const uint32_t cap = std::max(max_grid / count, ctx->num_cus);
+  {
+    KernelTimer t(ctx, OXC_K_PREPARE, s);
+    launch_prepare_batch(blob, ctx->batch_dev, g_prep, s);
+  }
+  if (do_meshes) {
+    {
+      KernelTimer t(ctx, OXC_K_MESHES_SCAN, s);
+      launch_scan_batch(ctx->batch_dev, count, s);
+    }
+    KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
+    launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, cap), s);
+  }
+  if (do_meshlets) {
+    {
+      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
+      launch_meshlets_test_batch(ctx->batch_dev, count, std::min(g_test, cap), s);
+    }
+    KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
+    launch_meshlets_emit_batch(ctx->batch_dev, count, std::min(g_emit, cap), s);
+  }
+  if (do_tris) {
+    {
+      KernelTimer t(ctx, OXC_K_TRIANGLES_TEST, s);
+      launch_tris_test_batch(ctx->batch_dev, count, std::min(g_ttest, cap), s);
+    }
+    KernelTimer t(ctx, OXC_K_TRIANGLES_EMIT, s);
+    launch_tris_emit_batch(ctx->batch_dev, count, std::min(g_temit, cap), s);
   }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
@@ -536,10 +748,10 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   if (c->cull_triangles_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(tc, c->cull_triangles_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
   if (c->draw_geometry_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(dc, c->draw_geometry_cmd_buffer.dptr, 20, hipMemcpyDeviceToHost, s));
   uint32_t ferr = 0;
-  if (ctx->fsync) OXC_HIP(ctx, hipMemcpyAsync(&ferr, ctx->fsync + 2, 4, hipMemcpyDeviceToHost, s));
+  if (ctx->lane[0].fsync) OXC_HIP(ctx, hipMemcpyAsync(&ferr, ctx->lane[0].fsync + 2, 4, hipMemcpyDeviceToHost, s));
   OXC_HIP(ctx, hipStreamSynchronize(s));
   if (ferr) {
-    (void)hipMemset(ctx->chunk_gran, 0, reinterpret_cast<char*>(ctx->fsync) + 64 - reinterpret_cast<char*>(ctx->chunk_gran));
+    (void)hipMemset(ctx->lane[0].chunk_gran, 0, reinterpret_cast<char*>(ctx->lane[0].fsync) + 64 - reinterpret_cast<char*>(ctx->lane[0].chunk_gran));
     return fail(ctx, OXC_HIP_ERROR, "in-kernel hand-off of the fused meshlet emit timed out (state reset)");
   }
   out->total_visible_meshlet_instances = vis[0];

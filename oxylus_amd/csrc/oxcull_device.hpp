@@ -30,6 +30,16 @@ OXC_DEV float bperm_f(int src_lane, float v) {
 
 // 64-bit device addresses coming out of the reference structs are integers; loading through a
 // generic pointer would emit flat_load (LDS-aperture check, lgkmcnt).  Go through address space 1.
+// Generic -> global pointer (pointers that come out of memory-resident argument blocks are generic
+// to the compiler and would be accessed with flat_* instructions).
+template <typename T>
+OXC_DEV T __attribute__((address_space(1))) * gptr(T* p) {
+  return (T __attribute__((address_space(1)))*)p;
+}
+template <typename T>
+OXC_DEV const T __attribute__((address_space(1))) * gptr(const T* p) {
+  return (const T __attribute__((address_space(1)))*)p;
+}
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 OXC_DEV uint32_t load_global_u32(uint64_t base, uint32_t index) {

@@ -48,9 +48,9 @@ OXC_DEV uint32_t chunk_base_256(const uint32_t* __restrict__ supers, const uint3
                                 uint32_t* s_red) {
   uint32_t s = c / kChunksPerSuper;
   uint32_t acc = 0;
-  for (uint32_t i = threadIdx.x; i < s; i += 256) acc += supers[i];
+  for (uint32_t i = threadIdx.x; i < s; i += 256) acc += gptr(supers)[i * kSuperStride];
   uint32_t j = s * kChunksPerSuper + threadIdx.x;
-  if (j < c) acc += chunk_counts[j];  // at most 63 terms
+  if (j < c) acc += gptr(chunk_counts)[j];  // at most 63 terms
   return block_sum_256(acc, s_red);
 }
 
@@ -60,10 +60,10 @@ OXC_DEV uint32_t chunk_base_256(const uint32_t* __restrict__ supers, const uint3
 // slot like the reference's scratch_buffer initial values (CullGeometry.cpp:97-100,125-127,
 // 380-382) and zeroes the super-chunk accumulators.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
+OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nthreads = gridDim.x * blockDim.x;
-  const uint32_t view = blockIdx.y;  // 0: the cull camera; 1 + v: VSM clipmap v (use_hpb)
+  // view 0: the cull camera; 1 + v: VSM clipmap v (use_hpb)
   float pv[16];
   if (view == 0) {
 #pragma unroll
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
     }
   }
   if (main_view) {
-    for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i] = 0;
-    for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i] = 0;
+    for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i * kSuperStride] = 0;
+    for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i * kSuperStride] = 0;
   }
   const bool do_cull_meshes = main_view && a.do_cull_meshes;
 
@@ -229,9 +229,12 @@ __global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) {
 // cull_meshes expansion (passes/cull_meshes.slang:60-84), deterministic: exclusive scan of the
 // per-instance meshlet counts, then one wave per instance writes its MeshletInstance records.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_mesh_counts(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                            uint32_t n, uint32_t* __restrict__ vis,
-                                                            uint32_t* __restrict__ meshlets_cmd) {
+OXC_DEV void scan_body(const ScanArgs& a) {
+  const uint32_t* __restrict__ counts = a.counts;
+  uint32_t* __restrict__ offsets = a.offsets;
+  const uint32_t n = a.n;
+  uint32_t* __restrict__ vis = a.vis;
+  uint32_t* __restrict__ meshlets_cmd = a.meshlets_cmd;
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -258,9 +261,11 @@ __global__ __launch_bounds__(1024) void k_scan_mesh_counts(const uint32_t* __res
   }
 }
 
-__global__ __launch_bounds__(256) void k_expand_meshlet_instances(const uint32_t* __restrict__ counts,
-                                                                   const uint32_t* __restrict__ offsets, uint32_t n,
-                                                                   GpuMeshletInstance* __restrict__ out) {
+OXC_DEV void expand_body(const ExpandArgs& a) {
+  const uint32_t* __restrict__ counts = a.counts;
+  const uint32_t* __restrict__ offsets = a.offsets;
+  const uint32_t n = a.n;
+  GpuMeshletInstance* __restrict__ out = a.out;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -283,35 +288,43 @@ __global__ __launch_bounds__(256) void k_expand_meshlet_instances(const uint32_t
 // only touches per-meshlet values.  A wave whose 64 meshlets span several mesh instances runs
 // the body once per distinct instance under the exec mask.
 // ------------------------------------------------------------------------------------------
+// Wave-uniform instance data.  Only what every wave needs is unpacked into SGPRs eagerly (the six
+// planes, the bounds pointer, the mask offset); the cone data (world rows, normal matrix, scale) and
+// mvp are pulled out of the still-resident row dwords `v0` inside the wave-uniform branches that use
+// them.  Fewer live SGPRs = more resident waves (the kernel's throughput is residency / chain latency).
 struct InstU {
   float pl[24];
+  uint32_t vis_offset;
+  uint64_t bounds;
+  uint32_t v0;  // VGPR: dword `lane` of the InstCache row
+};
+struct ConeU {
   float world[12];
   float nm[9];
   float scale_max;
-  uint32_t vis_offset;
-  uint64_t bounds;
-  float mvp[16];
 };
+OXC_DEV void unpack_cone(uint32_t v0, ConeU& c) {
+#pragma unroll
+  for (int k = 0; k < 12; k++) c.world[k] = readlane_f(v0, 40 + k);
+#pragma unroll
+  for (int k = 0; k < 9; k++) c.nm[k] = readlane_f(v0, 52 + k);
+  c.scale_max = readlane_f(v0, 61);
+}
+OXC_DEV void unpack_mvp(uint32_t v0, float* mvp) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, 24 + k);
+}
 
 template <bool NEED_MVP>
 OXC_DEV void load_inst_uniform(const InstCache* __restrict__ cache, uint32_t mi, int lane, InstU& u) {
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(cache + mi);
-  uint32_t v0 = p[lane];
-  uint32_t v1 = p[64 + (lane & 15)];
+  const uint64_t p = reinterpret_cast<uint64_t>(cache + mi);
+  uint32_t v0 = load_global_u32(p, lane);
+  uint32_t v1 = load_global_u32(p, 64 + (lane & 15));
 #pragma unroll
   for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, k);
-
-  if (NEED_MVP) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) u.mvp[k] = readlane_f(v0, 24 + k);
-  }
-#pragma unroll
-  for (int k = 0; k < 12; k++) u.world[k] = readlane_f(v0, 40 + k);
-#pragma unroll
-  for (int k = 0; k < 9; k++) u.nm[k] = readlane_f(v0, 52 + k);
-  u.scale_max = readlane_f(v0, 61);
   u.vis_offset = readlane_u(v0, 62);
   u.bounds = (uint64_t)readlane_u(v1, 0) | ((uint64_t)readlane_u(v1, 1) << 32);
+  u.v0 = v0;
 }
 
 // Set/clear bits of the persistent visibility mask for the lanes in `active`.
@@ -350,25 +363,6 @@ OXC_DEV void update_visibility_mask(uint32_t* __restrict__ mask, uint32_t idx, b
   }
 }
 
-// Unpack the wave-loaded cache dwords into SGPRs.
-template <bool NEED_MVP>
-OXC_DEV void unpack_inst(uint32_t v0, uint32_t v1, InstU& u) {
-#pragma unroll
-  for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, k);
-
-  if (NEED_MVP) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) u.mvp[k] = readlane_f(v0, 24 + k);
-  }
-#pragma unroll
-  for (int k = 0; k < 12; k++) u.world[k] = readlane_f(v0, 40 + k);
-#pragma unroll
-  for (int k = 0; k < 9; k++) u.nm[k] = readlane_f(v0, 52 + k);
-  u.scale_max = readlane_f(v0, 61);
-  u.vis_offset = readlane_u(v0, 62);
-  u.bounds = (uint64_t)readlane_u(v1, 0) | ((uint64_t)readlane_u(v1, 1) << 32);
-}
-
 struct LaneResult {
   bool emit;
   bool visible;
@@ -393,17 +387,19 @@ OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4
     was_visible = ((a.mask[mask_idx >> 5] >> (mask_idx & 31u)) & 1u) != 0u;
   }
   bool visible = mine && ((HIZ && !LATE) ? was_visible : true);
-  visible = test_frustum_planes_wave(u.pl, cx, cy, cz, ex, ey, ez, visible);
+  if (!(a.ablate & 2u)) visible = test_frustum_planes_wave(u.pl, cx, cy, cz, ex, ey, ez, visible);
   const int32_t cutoff_s8 = (int32_t)b.w >> 24;
-  const bool need_cone = visible && cutoff_s8 != 127;  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
+  const bool need_cone = visible && cutoff_s8 != 127 && !(a.ablate & 1u);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
   if (__any(need_cone)) {
     const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
     const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127(cutoff_s8);
-    int tier1 = cone_visible_fast(u.world, u.nm, u.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az,
+    ConeU cu;
+    unpack_cone(u.v0, cu);
+    int tier1 = cone_visible_fast(cu.world, cu.nm, cu.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az,
                                   cutoff);
     bool cone_ok = tier1 == 1;
     if (__any(need_cone && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-      const bool exact = cone_visible(u.world, u.nm, u.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay,
+      const bool exact = cone_visible(cu.world, cu.nm, cu.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay,
                                       az, cutoff);
       cone_ok = tier1 == 2 ? exact : cone_ok;
     }
@@ -411,7 +407,9 @@ OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4
   }
   if (HIZ && OCCL_OR_LATE) {
     if (__any(visible)) {
-      const bool occluded = aabb_occluded(u.mvp, a.near_clip, cx, cy, cz, ex, ey, ez, hiz, s_level_off, visible);
+      float mvp[16];
+      unpack_mvp(u.v0, mvp);
+      const bool occluded = aabb_occluded(mvp, a.near_clip, cx, cy, cz, ex, ey, ez, hiz, s_level_off, visible);
       visible = visible && !occluded;
     }
   }
@@ -434,13 +432,15 @@ OXC_DEV uint64_t ld_gran(const uint64_t* p) {
 }
 constexpr uint32_t kMaxSpins = 1u << 20;  // bounded: a broken hand-off sets sync[2] instead of hanging the GPU
 
-template <bool HIZ, bool OCCL, bool LATE, bool FUSED = false>
-__global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
-  __shared__ uint32_t s_red[4];
+// G = 64-meshlet groups per wave per chunk; the block has 16/G waves so a chunk is always 1024 meshlets.
+template <bool HIZ, bool OCCL, bool LATE, bool FUSED, int G>
+OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
+  constexpr int kWaves = 16 / G;
+  __shared__ uint32_t s_red[kWaves];
   __shared__ uint32_t s_fused[4];  // [0] epoch, [1] base, [2] last-arriver flag
   __shared__ uint32_t s_level_off[13];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : a.vis[0];
+  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
   __shared__ uint32_t s_lds_off[13];
@@ -467,24 +467,29 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
   hiz.lds = s_hiz_top;
   hiz.lds_off = s_lds_off;
   hiz.lds_first = HIZ ? a.hiz_lds_first : 0u;
-  const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
+  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
+  const uint32_t last_index = N ? N - 1u : 0u;
   if (FUSED && threadIdx.x == 0) {
     s_fused[0] = __hip_atomic_load(&a.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;  // this launch's epoch (never 0)
   }
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     // ---- stage A: all MeshletInstance loads of this wave (G consecutive 64-meshlet groups)
-    constexpr int G = (int)kGroupsPerWave;
     uint32_t group[G], idx[G];
     bool in[G];
     uint2 rec[G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
-      group[j] = chunk * (4 * G) + wave * G + j;
+      group[j] = chunk * 16 + wave * G + j;
       idx[j] = group[j] * 64 + lane;
       in[j] = idx[j] < N;
-      rec[j] = in[j] ? mlis[idx[j]] : make_uint2(0xFFFFFFFFu, 0u);
+      // unconditional load at a clamped index: a `cond ? load : x` is lowered to an exec-masked block
+      // with s_waitcnt vmcnt(0) inside, which serialises the G loads (one HBM round trip each)
+      rec[j] = load_global_u2(mlis, min(idx[j], last_index));
     }
+#pragma unroll
+    for (int j = 0; j < G; j++)
+      if (!in[j]) rec[j] = make_uint2(0xFFFFFFFFu, 0u);
     // ---- stages B-D: one round per distinct mesh instance among the wave's G*64 meshlets
     // (usually one; two when the wave straddles an instance boundary).  Per round: cache row ->
     // SGPRs, all bounds loads of the round issued together, then the decisions.
@@ -510,20 +515,30 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
       }
       if (!found) break;
       InstU u;
-      load_inst_uniform<HIZ>(a.cache, mi_u, lane, u);
+      if (a.ablate & 16u) {  // timing experiment: no cache-row load / SGPR unpack
+#pragma unroll
+        for (int k = 0; k < 24; k++) u.pl[k] = a.cam_pos[k % 3];
+        u.vis_offset = 0;
+        u.bounds = reinterpret_cast<uint64_t>(a.cache);
+        u.v0 = 0;
+      } else
+        load_inst_uniform<HIZ>(a.cache, mi_u, lane, u);
       bool mine[G];
       uint4 bnd[G];
 #pragma unroll
       for (int j = 0; j < G; j++) {
         mine[j] = in[j] && rec[j].x == mi_u;
-        bnd[j] = make_uint4(0, 0, 0, 0);
-        if (mine[j]) bnd[j] = load_global_u4(u.bounds, rec[j].y);
+        // unconditional (see above); lanes of other instances read element 0 of this instance's bounds
+        bnd[j] = load_global_u4(u.bounds, (mine[j] && !(a.ablate & 4u)) ? rec[j].y : 0u);
       }
 #pragma unroll
       for (int j = 0; j < G; j++) {
         const uint64_t m = __ballot(mine[j]);
         if (m) {  // wave-uniform
-          eval_meshlets<HIZ, OCCL, LATE>(a, u, bnd[j], rec[j].y, mine[j], hiz, s_level_off, res[j]);
+          if (a.ablate & 8u) {
+            if (mine[j]) res[j].emit = (rec[j].y & 3u) == 0u;
+          } else
+            eval_meshlets<HIZ, OCCL, LATE>(a, u, bnd[j], rec[j].y, mine[j], hiz, s_level_off, res[j]);
           pending[j] &= ~m;
         }
       }
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
       if (HIZ && OCCL) update_visibility_mask(a.mask, res[j].mask_idx, res[j].visible, in[j], lane);
       const uint64_t bits = __ballot(res[j].emit);
       wbits[j] = bits;
-      if (!FUSED && lane == 0) a.bits[group[j]] = bits;
+      if (!FUSED && lane == 0) gptr(a.bits)[group[j]] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
     if (FUSED) {
@@ -547,7 +562,9 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
       __syncthreads();
       if (lane == 0) s_red[wave] = cnt;
       __syncthreads();
-      const uint32_t block_count = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      uint32_t block_count = 0;
+#pragma unroll
+      for (int k = 0; k < kWaves; k++) block_count += s_red[k];
       uint32_t wave_prefix = 0;
       for (int k = 0; k < wave; k++) wave_prefix += s_red[k];
       const uint32_t epoch = s_fused[0];
@@ -646,14 +663,14 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_test(MeshletTestArgs a) {
       }
       continue;  // one chunk per block in fused mode (grid == nchunks)
     }
-    // per-chunk survivor count (+ per-super accumulation)
-    __syncthreads();
-    if (lane == 0) s_red[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      a.chunk_counts[chunk] = c;
-      if (c) atomicAdd(&a.supers[chunk / kChunksPerSuper], c);
+    // per-WAVE survivor count (+ per-super accumulation), published by lane 0 without a block barrier:
+    // a __syncthreads() here re-couples the block's waves every iteration and costs ~25 % of the
+    // kernel (they can no longer run ahead of each other to overlap loads with arithmetic).
+    if (a.ablate & 32u) continue;
+    if (lane == 0 && group[0] < nwords) {
+      const uint32_t wchunk = chunk * kWaves + wave;  // counts are per 64*G meshlets
+      gptr(a.chunk_counts)[wchunk] = cnt;
+      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -755,7 +772,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
     if (threadIdx.x == 0) {
       uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
       a.chunk_counts[chunk] = c;
-      if (c) atomicAdd(&a.supers[chunk / kChunksPerSuper], c);
+      if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -766,29 +783,30 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
 // One block iteration = one span of 4096 candidates = 64 ballot words.
 // ------------------------------------------------------------------------------------------
 template <bool HIZ, bool LATE>
-__global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
+OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_off[64];
   __shared__ uint64_t s_bits[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : a.vis[0];
+  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nspans = (N + kMeshletSpan - 1) / kMeshletSpan;
-  const uint32_t out_first = (HIZ && LATE) ? a.vis[1] : 0u;  // late list follows the early one (:73)
-  constexpr uint32_t kChunksPerSpan = kMeshletSpan / kMeshletChunk;
+  const uint32_t out_first = (HIZ && LATE) ? gptr(a.vis)[1] : 0u;  // late list follows the early one (:73)
+  const uint32_t counts_per_span = kMeshletSpan / a.count_meshlets;
   for (uint32_t span = blockIdx.x; span < nspans; span += gridDim.x) {
-    const uint32_t base = chunk_base_256(a.supers, a.chunk_counts, span * kChunksPerSpan, s_red);
+    const uint32_t base = chunk_base_256(a.supers, a.chunk_counts, span * counts_per_span, s_red);
     if (wave == 0) {
       uint32_t w = span * 64 + lane;
-      uint64_t bits = w < nwords ? a.bits[w] : 0ull;
+      uint64_t bits = gptr(a.bits)[min(w, nwords ? nwords - 1u : 0u)];
+      if (w >= nwords) bits = 0ull;
       uint32_t c = (uint32_t)__popcll((unsigned long long)bits);
       uint32_t incl = wave_incl_scan(c, lane);
       s_off[lane] = incl - c;
       s_bits[lane] = bits;
       if (lane == 63 && span == nspans - 1) {
         uint32_t total = base + incl;
-        a.tri_cmd[0] = total;  // cull_triangles_cmd.x (one WG per visible meshlet in the reference)
-        if (HIZ) a.vis[LATE ? 2 : 1] = total;
+        gptr(a.tri_cmd)[0] = total;  // cull_triangles_cmd.x (one WG per visible meshlet in the reference)
+        if (HIZ) gptr(a.vis)[LATE ? 2 : 1] = total;
       }
     }
     __syncthreads();
@@ -798,7 +816,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
       const uint64_t bits = s_bits[w];
       if ((bits >> lane) & 1ull) {
         uint32_t rank = (uint32_t)__popcll((unsigned long long)(bits & ((1ull << lane) - 1ull)));
-        a.out[out_first + base + s_off[w] + rank] = (span * 64 + w) * 64 + lane;
+        gptr(a.out)[out_first + base + s_off[w] + rank] = (span * 64 + w) * 64 + lane;
       }
     }
     __syncthreads();
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
 // ds_bpermute.  Same per-vertex arithmetic => same bits.  Result: a 64-bit pass mask per slot.
 // ------------------------------------------------------------------------------------------
 template <bool LATE>
-__global__ __launch_bounds__(256, 8) void k_cull_triangles_test(TriTestArgs a) {
+OXC_DEV void tris_test_body(const TriTestArgs& a) {
   __shared__ uint32_t s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
@@ -936,7 +954,7 @@ __global__ __launch_bounds__(256, 8) void k_cull_triangles_test(TriTestArgs a) {
     if (threadIdx.x == 0) {
       uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
       a.chunk_counts[chunk] = c;
-      if (c) atomicAdd(&a.supers[chunk / kChunksPerSuper], c);
+      if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -946,7 +964,7 @@ __global__ __launch_bounds__(256, 8) void k_cull_triangles_test(TriTestArgs a) {
 // (visbuffer.slang:13-14, cull_triangles.slang:82-88) and DrawIndexedIndirect.index_count.
 // ------------------------------------------------------------------------------------------
 template <bool LATE>
-__global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
+OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_off[256];
@@ -1190,6 +1208,62 @@ __global__ __launch_bounds__(256) void k_debug_decode_bounds(const uint4* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// kernel entry points: single-frame wrappers and batched wrappers (blockIdx.y = batch element)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare_instances(PrepareArgs a) { prepare_body(a, blockIdx.y); }
+__global__ __launch_bounds__(1024) void k_scan_mesh_counts(ScanArgs a) { scan_body(a); }
+__global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) { expand_body(a); }
+// (Capping SGPRs at 80 for 8 waves/SIMD -- the compiler otherwise keeps ~106 live -- was measured:
+// plain kernel 36.7 -> 38.8 us per 4M meshlets, HiZ variant 183 -> 175 us; not kept.)
+template <bool HIZ, bool OCCL, bool LATE, bool FUSED = false, int G = (int)kGroupsPerWave>
+__global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
+  meshlets_test_body<HIZ, OCCL, LATE, FUSED, G>(a);
+}
+template <bool HIZ, bool LATE>
+__global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
+  meshlets_emit_body<HIZ, LATE>(a);
+}
+template <bool LATE>
+__global__ __launch_bounds__(256, 8) void k_cull_triangles_test(TriTestArgs a) {
+  tris_test_body<LATE>(a);
+}
+template <bool LATE>
+__global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
+  tris_emit_body<LATE>(a);
+}
+
+// Batched prepare: gets the whole blob by value (kernarg), publishes it for the later kernels of the
+// call, and runs its own element.  The switch keeps the kernarg indexing static (a dynamic index into
+// a by-value aggregate would be lowered through scratch).
+__global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchBlob* __restrict__ dev) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&blob);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(dev);
+    for (uint32_t i = threadIdx.x; i < sizeof(BatchBlob) / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  switch (blockIdx.y) {
+    case 0: prepare_body(blob.prep[0], 0u); break;
+    case 1: prepare_body(blob.prep[1], 0u); break;
+    case 2: prepare_body(blob.prep[2], 0u); break;
+    default: prepare_body(blob.prep[3], 0u); break;
+  }
+}
+__global__ __launch_bounds__(1024) void k_scan_batch(const BatchBlob* __restrict__ dev) { scan_body(dev->scan[blockIdx.y]); }
+__global__ __launch_bounds__(256) void k_expand_batch(const BatchBlob* __restrict__ dev) { expand_body(dev->expand[blockIdx.y]); }
+__global__ __launch_bounds__(256) void k_cull_meshlets_test_batch(const BatchBlob* __restrict__ dev) {
+  meshlets_test_body<false, false, false, false, (int)kGroupsPerWave>(dev->test[blockIdx.y]);
+}
+__global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlob* __restrict__ dev) {
+  meshlets_emit_body<false, false>(dev->emit[blockIdx.y]);
+}
+__global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchBlob* __restrict__ dev) {
+  tris_test_body<false>(dev->ttest[blockIdx.y]);
+}
+__global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchBlob* __restrict__ dev) {
+  tris_emit_body<false>(dev->temit[blockIdx.y]);
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_prepare(const PrepareArgs& a, uint32_t grid, uint32_t views, hipStream_t s) {
@@ -1197,24 +1271,46 @@ void launch_prepare(const PrepareArgs& a, uint32_t grid, uint32_t views, hipStre
 }
 
 void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan_mesh_counts, dim3(1), dim3(1024), 0, s, counts, offsets, n, vis, cmd);
+  ScanArgs a{counts, offsets, n, vis, cmd};
+  hipLaunchKernelGGL(k_scan_mesh_counts, dim3(1), dim3(1024), 0, s, a);
 }
 void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, void* out, uint32_t grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_expand_meshlet_instances, dim3(grid), dim3(256), 0, s, counts, offsets, n, reinterpret_cast<GpuMeshletInstance*>(out));
+  ExpandArgs a{counts, offsets, n, reinterpret_cast<GpuMeshletInstance*>(out)};
+  hipLaunchKernelGGL(k_expand_meshlet_instances, dim3(grid), dim3(256), 0, s, a);
+}
+void launch_prepare_batch(const BatchBlob& blob, BatchBlob* dev, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_prepare_batch, dim3(grid, blob.count), dim3(256), 0, s, blob, dev);
+}
+void launch_scan_batch(const BatchBlob* dev, uint32_t count, hipStream_t s) { hipLaunchKernelGGL(k_scan_batch, dim3(1, count), dim3(1024), 0, s, dev); }
+void launch_expand_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_expand_batch, dim3(grid, count), dim3(256), 0, s, dev);
+}
+void launch_meshlets_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_cull_meshlets_test_batch, dim3(grid, count), dim3(256), 0, s, dev);
+}
+void launch_meshlets_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_cull_meshlets_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
+}
+void launch_tris_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_cull_triangles_test_batch, dim3(grid, count), dim3(256), 0, s, dev);
+}
+void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_cull_triangles_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
 
+constexpr int kHizGroups = 2;  // occlusion variants: 2 groups per wave, 8-wave blocks (register pressure)
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), g, b, 0, s, a);
   } else if (occl && late) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true>), g, b, 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else if (occl) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, false>), g, b, 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, false, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else if (late) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, true>), g, b, 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false>), g, b, 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   }
 }
 void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_cull_meshlets_hpb_test, dim3(grid), dim3(256), 0, s, a); }

@@ -53,6 +53,7 @@ struct HpbTestArgs {
 };
 
 struct MeshletTestArgs {
+  uint32_t ablate;  // timing experiments only (OXC_ABLATE): 1 skip cone, 2 skip frustum, 4 skip bounds load, 8 skip evaluation
   uint32_t n_host;  // != 0: the list length is known on the host (seeded lists); skips the dependent load of vis[0]
   const InstCache* cache;
   const GpuMeshletInstance* meshlet_instances;
@@ -80,6 +81,7 @@ struct MeshletTestArgs {
 
 struct MeshletEmitArgs {
   uint32_t n_host;
+  uint32_t count_meshlets;  // meshlets per published count (64 * groups-per-wave of the test kernel that ran)
   const uint64_t* bits;
   const uint32_t* chunk_counts;
   const uint32_t* supers;
@@ -110,6 +112,38 @@ struct TriEmitArgs {
   uint32_t* out;  // reordered_indices
 };
 
+struct ScanArgs {
+  const uint32_t* counts;
+  uint32_t* offsets;
+  uint32_t n;
+  uint32_t* vis;
+  uint32_t* meshlets_cmd;
+};
+
+struct ExpandArgs {
+  const uint32_t* counts;
+  const uint32_t* offsets;
+  uint32_t n;
+  GpuMeshletInstance* out;
+};
+
+// Argument blocks of one oxc_cull_geometry_batch call (plain pipeline, <= kMaxBatch independent
+// frames).  Passed by value to the batched prepare kernel, which copies it to the context's device
+// buffer; every later kernel of the call reads its element through blockIdx.y from there.
+constexpr uint32_t kMaxBatch = 4;
+struct BatchBlob {
+  PrepareArgs prep[kMaxBatch];
+  ScanArgs scan[kMaxBatch];
+  ExpandArgs expand[kMaxBatch];
+  MeshletTestArgs test[kMaxBatch];
+  MeshletEmitArgs emit[kMaxBatch];
+  TriTestArgs ttest[kMaxBatch];
+  TriEmitArgs temit[kMaxBatch];
+  uint32_t count;
+  uint32_t _pad;
+};
+static_assert(sizeof(BatchBlob) <= 4000, "must fit the kernarg segment");
+
 struct HizArgs {
   const float* depth;
   float* hiz;
@@ -128,6 +162,14 @@ void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_
 void launch_tris_test(const TriTestArgs& a, bool late, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, uint32_t grid, hipStream_t s);
 void launch_hiz(const HizArgs& a, hipStream_t s);
+// batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch
+void launch_prepare_batch(const BatchBlob& blob, BatchBlob* dev, uint32_t grid, hipStream_t s);
+void launch_scan_batch(const BatchBlob* dev, uint32_t count, hipStream_t s);
+void launch_expand_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_meshlets_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_meshlets_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_tris_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);

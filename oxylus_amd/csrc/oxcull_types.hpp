@@ -72,6 +72,7 @@ constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of 
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
 constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel
 constexpr uint32_t kHizLdsTexels = 5632;      // LDS budget (floats) for the staged top HiZ mips: a 64x64 level and everything above it
+constexpr uint32_t kSuperStride = 64;         // words between super-chunk accumulators: one per 256 B so their atomics do not serialise on a cache line
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
 
 }  // namespace oxc

@@ -133,6 +133,7 @@ EXPORTS = [
     "oxc_reserve",
     "oxc_generate_hiz",
     "oxc_cull_geometry",
+    "oxc_cull_geometry_batch",
     "oxc_seed_meshlet_instances",
     "oxc_read_counters",
     "oxc_stream_read_probe",
@@ -173,6 +174,7 @@ def load() -> C.CDLL:
     lib.oxc_reserve.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.oxc_generate_hiz.argtypes = [vp, C.POINTER(MainGeometryContext), vp]
     lib.oxc_cull_geometry.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(CullGeometryContext), vp]
+    lib.oxc_cull_geometry_batch.argtypes = [vp, C.c_uint32, C.POINTER(PreparedFrame), C.POINTER(CullGeometryContext), vp]
     lib.oxc_seed_meshlet_instances.argtypes = [vp, C.POINTER(CullGeometryContext), C.c_uint32, vp]
     lib.oxc_read_counters.argtypes = [vp, C.POINTER(CullGeometryContext), C.POINTER(Counters), vp]
     lib.oxc_stream_read_probe.argtypes = [vp, vp, C.c_uint64, vp]

@@ -226,6 +226,18 @@ class RendererInstance:
         f = self.prepared_frame.c()
         self._check(self._lib.oxc_cull_geometry(self._ctx, C.byref(f), C.byref(context.c()), self._stream(stream)))
 
+    def cull_geometry_batch(self, frames, contexts, stream=None):
+        """Batched cull of independent (PreparedFrame, CullGeometryContext) pairs (oxc_cull_geometry_batch).
+        The contexts' output buffers are updated like cull_geometry does."""
+        n = len(frames)
+        assert n == len(contexts) and n > 0
+        cf = (L.PreparedFrame * n)(*[f.c() for f in frames])
+        cc = (L.CullGeometryContext * n)(*[c.c() for c in contexts])
+        self._check(self._lib.oxc_cull_geometry_batch(self._ctx, n, cf, cc, self._stream(stream)))
+        for i, c in enumerate(contexts):
+            for name in ("visibility_buffer", "cull_meshlets_cmd_buffer", "cull_triangles_cmd_buffer", "draw_geometry_cmd_buffer"):
+                setattr(c._c, name, getattr(cc[i], name))
+
     def seed_meshlet_instances(self, context: CullGeometryContext, total: int, stream=None):
         self._check(self._lib.oxc_seed_meshlet_instances(self._ctx, C.byref(context.c()), total, self._stream(stream)))
 

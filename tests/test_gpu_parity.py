@@ -313,3 +313,37 @@ def test_meshlet_stage_one_million(renderer, oracle_lib):
     got = gpu_frame(renderer, gpu, with_triangles=False)
     assert np.array_equal(want.numpy(), got["visible"])
     assert 0.1 < want.numel() / 1e6 < 0.6
+
+
+@pytest.mark.parametrize("run_cull_meshes", [True, False])
+def test_cull_geometry_batch_equals_individual_calls(renderer, oracle_lib, run_cull_meshes):
+    """oxc_cull_geometry_batch: several independent frames per launch (grid.y = batch element) must give
+    exactly what one call per frame gives."""
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    specs = [SceneSpec(n_mesh_instances=40, meshlets_per_mesh=90, lod_count=3, seed=81),
+             SceneSpec(n_mesh_instances=7, meshlets_per_mesh=500, lod_count=3, seed=82, ragged=True),
+             SceneSpec(n_mesh_instances=120, meshlets_per_mesh=11, lod_count=3, seed=83),
+             SceneSpec(n_mesh_instances=1, meshlets_per_mesh=3000, lod_count=3, seed=84)]
+    pairs = [_pair(sp) for sp in specs]
+    wants = [oracle_frame(cpu, run_cull_meshes=run_cull_meshes) for cpu, _ in pairs]
+    frames, ctxs = [], []
+    for _, gpu in pairs:
+        fr = PreparedFrame.create(gpu, expand=not run_cull_meshes)
+        cx = CullGeometryContext(init_cull_meshes=run_cull_meshes, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera())
+        if not run_cull_meshes:
+            renderer.prepared_frame = fr
+            renderer.seed_meshlet_instances(cx, gpu.n_meshlet_instances)
+        frames.append(fr)
+        ctxs.append(cx)
+    renderer.cull_geometry_batch(frames, ctxs)
+    for want, fr, cx, (_, gpu) in zip(wants, frames, ctxs, pairs):
+        c = renderer.read_counters(cx)
+        assert c.total_visible_meshlet_instances == want["total"]
+        got_vis = fr.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu().numpy()
+        got_idx = fr.reordered_indices_buffer[: c.draw_index_count].cpu().numpy()
+        assert np.array_equal(got_vis, want["visible"])
+        assert np.array_equal(got_idx, want["indices"])
+        if run_cull_meshes:
+            assert np.array_equal(fr.meshlet_instances_buffer[: want["total"]].cpu().numpy(), want["meshlet_instances"])
+            assert np.array_equal(gpu.mesh_instances[:, 1].cpu().numpy(), want["lod_index"])
