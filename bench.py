@@ -193,7 +193,12 @@ def main():
         # config 3: HiZ build, then early + late pass against it (render order of
         # RendererInstance.cpp:882-884 restated for a given depth + given mask)
         st.frame.meshlet_instance_visibility_mask_buffer.copy_(mask0[i % copies], non_blocking=True)
-        check(lib.oxc_generate_hiz(ctxp, pmg, sp))
+        # multi-GPU (configs[3]): depth is produced where rasterisation happens -- rank 0 builds the
+        # pyramid and broadcasts it over RCCL/xGMI (89.5 MB); every rank culls its own shard against it
+        if world == 1 or rank == 0:
+            check(lib.oxc_generate_hiz(ctxp, pmg, sp))
+        if dist is not None:
+            dist.broadcast(hiz.data, src=0)
         st.cctx.cull_flags = L.CULL_TEST_ALL
         check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
         st.cctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
@@ -457,7 +462,8 @@ def main():
                 "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K,
                 "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
                 "hip_graph": graph is not None, "streams": n_streams, "frames_per_launch": steps_per_call, "visible_fraction": round(visible_fraction, 4),
-                "sharding": f"contiguous range per rank x{world}" if world > 1 else "single GPU",
+                "sharding": (f"contiguous range per rank x{world}; all-gather of per-rank counters"
+                             + ("; HiZ built on rank 0 and broadcast" if full else "")) if world > 1 else "single GPU",
             },
             "bit_match": bit_match,
             "single_stream": single,

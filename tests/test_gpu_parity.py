@@ -347,3 +347,73 @@ def test_cull_geometry_batch_equals_individual_calls(renderer, oracle_lib, run_c
         if run_cull_meshes:
             assert np.array_equal(fr.meshlet_instances_buffer[: want["total"]].cpu().numpy(), want["meshlet_instances"])
             assert np.array_equal(gpu.mesh_instances[:, 1].cpu().numpy(), want["lod_index"])
+
+
+def test_stage_subsets_and_argument_validation(renderer, oracle_lib):
+    """`stages` runs a prefix of the pipeline; bad arguments come back as OXC_INVALID_ARG with a message."""
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    spec = SceneSpec(n_mesh_instances=20, meshlets_per_mesh=50, lod_count=2, seed=91)
+    cpu, gpu = _pair(spec)
+    want = oracle_frame(cpu, run_cull_meshes=True)
+    # meshes only
+    frame = PreparedFrame.create(gpu, expand=False)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), stages=L.STAGE_MESHES)
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    assert c.total_visible_meshlet_instances == want["total"] and c.cull_meshlets_cmd_x == want["cull_meshlets_cmd_x"]
+    assert c.cull_triangles_cmd_x == 0 and c.draw_index_count == 0
+    assert np.array_equal(frame.meshlet_instances_buffer[: want["total"]].cpu().numpy(), want["meshlet_instances"])
+    # then meshlets + triangles as a later call of the same sequence
+    ctx.init_cull_meshes = False
+    ctx.stages = L.STAGE_MESHLETS | L.STAGE_TRIANGLES
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    assert np.array_equal(frame.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu().numpy(), want["visible"])
+    assert np.array_equal(frame.reordered_indices_buffer[: c.draw_index_count].cpu().numpy(), want["indices"])
+
+    def expect_invalid(mutate):
+        fr = PreparedFrame.create(gpu, expand=True)
+        cx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera())
+        mutate(fr, cx)
+        renderer.prepared_frame = fr
+        with pytest.raises(L.OxcError) as e:
+            renderer.cull_geometry(cx)
+        assert e.value.status == L.OXC_INVALID_ARG and len(str(e.value)) > 20
+
+    def too_small_reordered(fr, cx):
+        fr.reordered_indices_buffer = fr.reordered_indices_buffer[:100]
+
+    def wrong_instance_count(fr, cx):
+        cx.cull_camera.mesh_instance_count += 1
+
+    def hiz_without_image(fr, cx):
+        cx.use_hiz = True
+
+    def late_without_sequence(fr, cx):
+        cx.init_cull_meshes = False
+
+    for m in (too_small_reordered, wrong_instance_count, hiz_without_image, late_without_sequence):
+        expect_invalid(m)
+
+
+def test_batch_falls_back_for_mixed_or_large_batches(renderer, oracle_lib):
+    """More than 4 elements (or a HiZ element) is processed one call at a time with the same results."""
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    pairs = [_pair(SceneSpec(n_mesh_instances=6, meshlets_per_mesh=40 + 7 * i, seed=100 + i)) for i in range(6)]
+    wants = [oracle_frame(cpu) for cpu, _ in pairs]
+    frames, ctxs = [], []
+    for _, gpu in pairs:
+        fr = PreparedFrame.create(gpu)
+        cx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera())
+        renderer.prepared_frame = fr
+        renderer.seed_meshlet_instances(cx, gpu.n_meshlet_instances)
+        frames.append(fr)
+        ctxs.append(cx)
+    renderer.cull_geometry_batch(frames, ctxs)
+    for want, fr, cx in zip(wants, frames, ctxs):
+        c = renderer.read_counters(cx)
+        assert np.array_equal(fr.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu().numpy(), want["visible"])
+        assert np.array_equal(fr.reordered_indices_buffer[: c.draw_index_count].cpu().numpy(), want["indices"])
