@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=9600)
     ap.add_argument("--warmup", type=int, default=960)
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
+    ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses the wide packed index extension (<= 8M meshlets)")
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
     ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
@@ -63,12 +64,12 @@ class Step:
     """One pre-marshalled cull_geometry call (C structs built once; the hot loop only calls into
     liboxcull.so)."""
 
-    def __init__(self, r: RendererInstance, scene, stages, use_hiz=False, hiz=None, with_triangles=False):
+    def __init__(self, r: RendererInstance, scene, stages, use_hiz=False, hiz=None, with_triangles=False, wide=False):
         self.scene = scene
-        self.frame = PreparedFrame.create(scene, with_triangles=with_triangles)
+        self.frame = PreparedFrame.create(scene, with_triangles=with_triangles, max_tris=128 if wide else 64)
         self.cframe = self.frame.c()
         self.ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL,
-                                       cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=stages)
+                                       cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=stages, wide_triangle_index=wide)
         r.prepared_frame = self.frame
         r.seed_meshlet_instances(self.ctx, scene.n_meshlet_instances)
         self.cctx = self.ctx.c()
@@ -104,11 +105,14 @@ def main():
     full = args.workload == "config3"
     multiview = args.workload == "config5"
     n_meshlets = args.meshlets or (10_000_000 if (full or multiview) else 1_000_000)
+    wide = full and args.tris > 64
+    if wide:
+        n_meshlets = min(n_meshlets, 8_000_000)  # 23-bit instance id of the wide index
     K = 1000
     M = max(1, n_meshlets // K)
     n_meshlets = M * K
     spec = SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=full, seed=0x0A1DE5 + 2 + rank,
-                     tris_per_meshlet=64, lod_count=3 if multiview else 1)
+                     tris_per_meshlet=(args.tris if full else 64), lod_count=3 if multiview else 1)
     with torch.cuda.stream(stream):
         base = make_scene(spec, dev)
         bytes_per_copy = n_meshlets * 24 + (M * 212)
@@ -124,7 +128,7 @@ def main():
             depth = ImageAttachment.depth(make_depth(8192, 8192, 64, seed=3, device=dev))
             hiz = ImageAttachment.hiz(4096, 4096, dev)
         stages = L.STAGE_ALL if full else (L.STAGE_MESHES | L.STAGE_MESHLETS if multiview else L.STAGE_MESHLETS)
-        steps = [Step(renderers[i % n_streams], s, stages, use_hiz=full, hiz=hiz, with_triangles=full) for i, s in enumerate(scenes)]
+        steps = [Step(renderers[i % n_streams], s, stages, use_hiz=full, hiz=hiz, with_triangles=full, wide=wide) for i, s in enumerate(scenes)]
         if full:
             g = torch.Generator(device=dev).manual_seed(5)
             for st in steps:  # random prior-visibility mask, p = 0.3 (config 3 restatement)
@@ -378,7 +382,7 @@ def main():
     else:
         dom = "cull_triangles_test"
         v_tot = counts["early"] + counts["late"]
-        bytes_per_unit = 4 + 8 + 16 + 3 * 64 + 4 * 64 + 8 * 64  # 988 B per visible meshlet (V=64, T=64), SURVEY 8(d) a11
+        bytes_per_unit = 4 + 8 + 16 + (3 * args.tris + 3) // 4 * 4 + 4 * 64 + 8 * 64  # 988 B per visible meshlet (V=64, T=64; 1168 B at T=124), SURVEY 8(d) a11
         units = v_tot / 2.0  # two launches (early, late) share the visible set
     dom_us = (kernels.get(dom) or {}).get("avg_us")
     roofline = None
@@ -459,7 +463,7 @@ def main():
                              "configs[2]: 10M meshlets + 4096^2 HiZ (13 mips) from 8192^2 depth: hiz build + early/late occlusion cull + triangle cull + compaction"
                              if full else
                              f"configs[4]: 10M meshlets x {args.views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"),
-                "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K,
+                "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris if full else None,
                 "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
                 "hip_graph": graph is not None, "streams": n_streams, "frames_per_launch": steps_per_call, "visible_fraction": round(visible_fraction, 4),
                 "sharding": (f"contiguous range per rank x{world}; all-gather of per-rank counters"

@@ -133,7 +133,10 @@ typedef struct oxc_cull_geometry_context {
   oxc_buffer vsm_clipmaps_buffer;            /* oxc_virtual_clipmap[vsm_clipmap_count] */
   oxc_buffer vsm_clipmap_dirty_flags_buffer; /* u32[vsm_clipmap_count] */
   uint32_t vsm_clipmap_count;                /* <= 16 */
-  uint32_t _pad0;
+  /* Extension (no reference behaviour): 0 = the reference's packed index (id << 8) | (3t+k),
+   * 64 triangles per meshlet; 1 = wide index (id << 9) | (3t+k) for meshlets of up to 128 triangles
+   * (at most 2^23 meshlet instances per call, reordered_indices_buffer >= N*128*3*4 bytes). */
+  uint32_t wide_triangle_index;
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */

@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
         l.orc_cull_meshlets_hpb.restype = u32
         l.orc_cull_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp]
         l.orc_cull_triangles.restype = u32
+        l.orc_cull_triangles_wide.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp]
+        l.orc_cull_triangles_wide.restype = u32
         l.orc_cull_triangles_mt.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, u32]
         l.orc_cull_triangles_mt.restype = u32
         l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
@@ -214,9 +216,12 @@ def cull_meshlets_hiz(scene, cam, meshlet_instances: torch.Tensor, cull_flags: i
 
 
 def cull_triangles(scene, cam, meshlet_instances: torch.Tensor, visible: torch.Tensor, first: int, count: int, nthreads: int = 1,
-                   stats: MarginStats = None) -> torch.Tensor:
-    out = torch.zeros(max(count, 1) * 192, dtype=torch.int32)
-    if nthreads > 1:
+                   stats: MarginStats = None, wide: bool = False) -> torch.Tensor:
+    out = torch.zeros(max(count, 1) * (384 if wide else 192), dtype=torch.int32)
+    if wide:
+        n = lib().orc_cull_triangles_wide(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
+                                          _p(cam), _p(out))
+    elif nthreads > 1:
         n = lib().orc_cull_triangles_mt(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
                                         _p(cam), _p(out), nthreads)
     else:

@@ -664,9 +664,11 @@ static inline uint32_t micro_index(const uint32_t* buf, uint32_t byte_offset) { 
   return (pack >> ((byte_offset & 3u) * 8u)) & 0xFFu;
 }
 
-uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
-                            const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
-                            uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats) {
+static uint32_t cull_triangles_impl(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                    const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                    uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats,
+                                    uint32_t max_tris, uint32_t corner_bits) {
+  const uint32_t corner_mask = (1u << corner_bits) - 1u;
   uint32_t n = 0;
   for (uint32_t s = 0; s < count; s++) {
     uint32_t mli_index = visible[first + s];
@@ -681,7 +683,7 @@ uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, con
     const uint32_t* vidx = (const uint32_t*)(uintptr_t)lod->indirect_vertex_indices;
     const uint16_t* pos = (const uint16_t*)(uintptr_t)mesh->vertex_positions;
     /* one thread per triangle; the kernel has 64 threads (defines.slang:9-11) */
-    uint32_t tcount = ml->triangle_count < 64u ? ml->triangle_count : 64u;
+    uint32_t tcount = ml->triangle_count < max_tris ? ml->triangle_count : max_tris;
     for (uint32_t t = 0; t < tcount; t++) {
       float cp[12];
       for (int k = 0; k < 3; k++) {
@@ -696,15 +698,28 @@ uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, con
       passed = passed && !backface_m(cp, stats ? &nr : NULL);
       if (stats && nr) stats->triangles_near_threshold++;
       if (passed) {
-        uint32_t base = mli_index << 8; /* MESHLET_PRIMITIVE_BITS = 8 */
-        out[n + 0] = base | ((t * 3u + 0u) & 0xFFu);
-        out[n + 1] = base | ((t * 3u + 1u) & 0xFFu);
-        out[n + 2] = base | ((t * 3u + 2u) & 0xFFu);
+        uint32_t base = mli_index << corner_bits; /* MESHLET_PRIMITIVE_BITS = 8 in the reference */
+        out[n + 0] = base | ((t * 3u + 0u) & corner_mask);
+        out[n + 1] = base | ((t * 3u + 1u) & corner_mask);
+        out[n + 2] = base | ((t * 3u + 2u) & corner_mask);
         n += 3;
       }
     }
   }
   return n;
+}
+
+uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                            const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                            uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats) {
+  /* one thread per triangle, 64 threads (defines.slang:9-11); 24+8 bit packing (visbuffer.slang:9-14) */
+  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, stats, 64u, 8u);
+}
+
+uint32_t orc_cull_triangles_wide(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                 const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                 uint32_t count, const orc_cull_camera* cam, uint32_t* out) {
+  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, NULL, 128u, 9u);
 }
 
 static void* mt_triangles(void* p) {

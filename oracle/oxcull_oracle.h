@@ -205,6 +205,12 @@ uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, con
                             uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out,
                             orc_margin_stats* stats);
 
+/* Extension (no reference behaviour): meshlets with up to 128 triangles and the wide
+ * packed index (meshlet_instance_index << 9) | (t*3+k).  Same per-triangle test. */
+uint32_t orc_cull_triangles_wide(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                 const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                 uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out);
+
 uint32_t orc_cull_triangles_mt(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out, uint32_t nthreads);

@@ -116,7 +116,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_bits = carve((uint64_t)cdiv(N, 64) * 8);
   const uint64_t o_mcc = carve((uint64_t)m_chunks * 4);
   const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4 * kSuperStride);
-  const uint64_t o_tm = carve((uint64_t)N * 8);
+  const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
   const uint64_t o_sync0 = off;
@@ -218,9 +218,11 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
   if (do_meshlets && N && (!f->visible_meshlet_instances_indices_buffer.dptr || f->visible_meshlet_instances_indices_buffer.bytes < (uint64_t)N * 4))
     return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visible_meshlet_instances_indices_buffer missing or < 4*N bytes");
   if (do_tris && N) {
-    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * 64 * 3 * 4)
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes");
-    if (N > kMaxPackedInstances) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: > 2^24 meshlet instances do not fit the packed index (visbuffer.slang:9-14)");
+    const uint64_t tris_per_meshlet = c->wide_triangle_index ? 128u : 64u;
+    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * tris_per_meshlet * 3 * 4)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes (N*128*3*4 with wide_triangle_index)");
+    if (N > (c->wide_triangle_index ? kMaxPackedInstances / 2 : kMaxPackedInstances))
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: too many meshlet instances for the packed index (2^24, visbuffer.slang:9-14; 2^23 with wide_triangle_index)");
   }
   const bool occl = (c->cull_flags & OXC_CULL_TEST_OCCLUSION) != 0;
   const bool late = (c->cull_flags & OXC_CULL_LATE_PASS) != 0;
@@ -501,10 +503,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
-    {
-      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
-      // Single-launch variant (ordered emit fused into the test kernel) when the list length is known on
-    // the host, one chunk per block fits the resident grid, and the plain cull_meshlets pipeline runs.
+    // Experimental single-launch variant (ordered emit fused into the test kernel, OXC_FUSED_EMIT=1): needs the
+    // list length on the host, one chunk per block within the resident grid, and the plain pipeline.
     const uint32_t exact_chunks = n_host ? cdiv(n_host, kMeshletChunk) : 0u;
     const bool fused = ctx->fused_emit && !c->use_hiz && n_host != 0 && exact_chunks <= ctx->num_cus * 4u;
     if (fused) {
@@ -515,23 +515,24 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ta.sync = ctx->lane[0].fsync;
       ta.tri_cmd = tri_cmd;
       ta.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
       launch_meshlets_fused(ta, exact_chunks, s);
     } else {
-    launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
-    }
-    }
-    if (!(ctx->fused_emit && !c->use_hiz && n_host != 0 && cdiv(n_host, kMeshletChunk) <= ctx->num_cus * 4u)) {
-    MeshletEmitArgs ea;
-    ea.n_host = n_host;
-    ea.count_meshlets = c->use_hiz ? 128u : 256u;  // one count per wave step: 64 * groups per wave
-    ea.bits = ctx->lane[0].bits;
-    ea.chunk_counts = ctx->lane[0].m_chunk_counts;
-    ea.supers = ctx->lane[0].m_supers;
-    ea.vis = vis;
-    ea.tri_cmd = tri_cmd;
-    ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
-    KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
-    launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
+      {
+        KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
+        launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
+      }
+      MeshletEmitArgs ea;
+      ea.n_host = n_host;
+      ea.count_meshlets = c->use_hiz ? 128u : 256u;  // one count per wave step: 64 * groups per wave
+      ea.bits = ctx->lane[0].bits;
+      ea.chunk_counts = ctx->lane[0].m_chunk_counts;
+      ea.supers = ctx->lane[0].m_supers;
+      ea.vis = vis;
+      ea.tri_cmd = tri_cmd;
+      ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+      KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
+      launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
     }
   }
 
@@ -548,7 +549,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.supers = ctx->lane[0].t_supers;
     {
       KernelTimer t(ctx, OXC_K_TRIANGLES_TEST, s);
-      launch_tris_test(tt, late, std::min(t_chunks, max_grid), s);
+      launch_tris_test(tt, late, c->wide_triangle_index != 0, std::min(t_chunks, max_grid), s);
     }
     TriEmitArgs te;
     te.tri_masks = ctx->lane[0].tri_masks;
@@ -560,7 +561,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     te.draw_cmd = draw_cmd;
     te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     KernelTimer t(ctx, OXC_K_TRIANGLES_EMIT, s);
-    launch_tris_emit(te, late, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
+    launch_tris_emit(te, late, c->wide_triangle_index != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
   }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
@@ -577,7 +578,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     oxc_status vst = check_call(ctx, &frames[e], &contexts[e], ci[e]);
     if (vst != OXC_OK) return vst;
     const oxc_cull_geometry_context& c = contexts[e];
-    fusable = !c.use_hiz && !c.use_hpb && !ci[e].late && ci[e].stages == ci[0].stages && ci[e].do_meshes == ci[0].do_meshes &&
+    fusable = !c.use_hiz && !c.use_hpb && !c.wide_triangle_index && !ci[e].late && ci[e].stages == ci[0].stages && ci[e].do_meshes == ci[0].do_meshes &&
               (c.init_cull_meshes != 0) == (contexts[0].init_cull_meshes != 0);
   }
   if (!fusable) {

@@ -829,8 +829,11 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 // once per referencing triangle corner; the triangle lanes then pick their three corners with
 // ds_bpermute.  Same per-vertex arithmetic => same bits.  Result: a 64-bit pass mask per slot.
 // ------------------------------------------------------------------------------------------
-template <bool LATE>
+// WIDE (extension): up to 128 triangles per meshlet -> two 64-lane triangle passes and two
+// 64-bit pass masks per slot (tri_masks[2*slot + half]).
+template <bool LATE, bool WIDE>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
+  constexpr int H = WIDE ? 2 : 1;
   __shared__ uint32_t s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
@@ -855,7 +858,7 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         h_pos = row->positions;
         h_meshlet = load_global_u4(meshlets, r.y);
         h_meshlet.z = min(h_meshlet.z, 64u);  // one lane per vertex / triangle (defines.slang:9-23)
-        h_meshlet.w = min(h_meshlet.w, 64u);
+        h_meshlet.w = min(h_meshlet.w, 64u * (uint32_t)H);
       }
     }
     // Per-slot uniform parameters out of the header lanes.
@@ -864,18 +867,22 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
     // Two-deep software pipeline over the 16 slots: while slot j is being decided, slot j+1's
     // positions and slot j+2's vertex / micro indices are already in flight (bytes in flight are
     // what bounds this gather-heavy kernel).
-    auto issue_indices = [&](int j, uint32_t& vid, uint32_t& d0, uint32_t& d1) {
+    auto issue_indices = [&](int j, uint32_t& vid, uint32_t (&d0)[H], uint32_t (&d1)[H]) {
       vid = 0;
-      d0 = 0;
-      d1 = 0;
+#pragma unroll
+      for (int h = 0; h < H; h++) d0[h] = d1[h] = 0;
       if (j >= S) return;
       const uint32_t vcount = slot_u32(h_meshlet.z, j), tcount = slot_u32(h_meshlet.w, j);
       if ((uint32_t)lane < vcount) vid = load_global_u32(slot_u64(h_vidx, j), slot_u32(h_meshlet.x, j) + lane);
-      if ((uint32_t)lane < tcount) {  // scene.slang:336-342,365-372 via aligned dword loads
-        const uint32_t boff = slot_u32(h_meshlet.y, j) + (uint32_t)lane * 3u;
-        const uint64_t pm = slot_u64(h_micro, j);
-        d0 = load_global_u32(pm, boff >> 2);
-        d1 = load_global_u32(pm, (boff + 2u) >> 2);
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const uint32_t t = (uint32_t)lane + 64u * (uint32_t)h;
+        if (t < tcount) {  // scene.slang:336-342,365-372 via aligned dword loads
+          const uint32_t boff = slot_u32(h_meshlet.y, j) + t * 3u;
+          const uint64_t pm = slot_u64(h_micro, j);
+          d0[h] = load_global_u32(pm, boff >> 2);
+          d1[h] = load_global_u32(pm, (boff + 2u) >> 2);
+        }
       }
     };
     auto issue_positions = [&](int j, uint32_t vid, uint2& q) {
@@ -883,9 +890,9 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       if (j >= S) return;
       if ((uint32_t)lane < slot_u32(h_meshlet.z, j)) q = load_global_u2(slot_u64(h_pos, j), vid);  // u16x4, stride 8
     };
-    uint32_t vid1, m0_1, m1_1;      // slot j+1: vertex ids + micro dwords
-    uint32_t m0_0, m1_0;            // slot j:   micro dwords
-    uint2 q0;                       // slot j:   positions
+    uint32_t vid1, m0_1[H], m1_1[H];  // slot j+1: vertex ids + micro dwords
+    uint32_t m0_0[H], m1_0[H];        // slot j:   micro dwords
+    uint2 q0;                         // slot j:   positions
     {
       uint32_t vid0;
       issue_indices(0, vid0, m0_0, m1_0);
@@ -902,7 +909,7 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       // ---- keep the pipeline full ----
       uint2 q1;
       issue_positions(j + 1, vid1, q1);
-      uint32_t vid2, m0_2, m1_2;
+      uint32_t vid2, m0_2[H], m1_2[H];
       issue_indices(j + 2, vid2, m0_2, m1_2);
       // ---- decide slot j ----
       const uint32_t mi = slot_u32(h_mi, j);
@@ -926,27 +933,34 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         clw = ((OXC_M(mvp, 3, 0) * px + OXC_M(mvp, 3, 1) * py) + OXC_M(mvp, 3, 2) * pz) + OXC_M(mvp, 3, 3);
       }
       const uint64_t zok = __ballot(clz >= 0.0f);
-      // triangle phase: lane = triangle
-      uint32_t tri = 0;
-      if ((uint32_t)lane < tri_count) tri = __builtin_amdgcn_alignbyte(m1_0, m0_0, (tri_offset + (uint32_t)lane * 3u) & 3u);
-      const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
-      const float ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
-      const float bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
-      const float cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
-      const bool z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
-      // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
-      const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
-      const bool passed = (uint32_t)lane < tri_count && z_all && !(det >= 0.0001f);
-      const uint64_t mask = __ballot(passed);
-      if (lane == 0) a.tri_masks[slot] = mask;
-      cnt += (uint32_t)__popcll((unsigned long long)mask);
+      // triangle phase: lane = triangle (two passes of 64 when WIDE)
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const uint32_t t = (uint32_t)lane + 64u * (uint32_t)h;
+        uint32_t tri = 0;
+        if (t < tri_count) tri = __builtin_amdgcn_alignbyte(m1_0[h], m0_0[h], (tri_offset + t * 3u) & 3u);
+        const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
+        const float ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
+        const float bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
+        const float cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
+        const bool z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
+        // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
+        const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
+        const bool passed = t < tri_count && z_all && !(det >= 0.0001f);
+        const uint64_t mask = __ballot(passed);
+        if (lane == 0) a.tri_masks[(size_t)slot * H + h] = mask;
+        cnt += (uint32_t)__popcll((unsigned long long)mask);
+      }
       // ---- rotate the pipeline registers ----
       q0 = q1;
-      m0_0 = m0_1;
-      m1_0 = m1_1;
       vid1 = vid2;
-      m0_1 = m0_2;
-      m1_1 = m1_2;
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        m0_0[h] = m0_1[h];
+        m1_0[h] = m1_1[h];
+        m0_1[h] = m0_2[h];
+        m1_1[h] = m1_2[h];
+      }
     }
     __syncthreads();
     if (lane == 0) s_red[wave] = cnt;
@@ -963,14 +977,17 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 // Triangle stage, emit kernel: ordered expansion of the pass masks into packed indices
 // (visbuffer.slang:13-14, cull_triangles.slang:82-88) and DrawIndexedIndirect.index_count.
 // ------------------------------------------------------------------------------------------
-template <bool LATE>
+template <bool LATE, bool WIDE>
 OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
+  constexpr int H = WIDE ? 2 : 1;
+  constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;  // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
+  constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_off[256];
-  __shared__ uint64_t s_mask[256];
+  __shared__ uint64_t s_mask[256 * H];
   __shared__ uint32_t s_id[256];
-  __shared__ uint32_t s_strip[4 * 192];
+  __shared__ uint32_t s_strip[4 * 192 * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;
@@ -979,47 +996,55 @@ OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
   for (uint32_t span = blockIdx.x; span < nspans; span += gridDim.x) {
     const uint32_t base = chunk_base_256(a.supers, a.chunk_counts, span * kChunksPerSpan, s_red);
     const uint32_t slot = span * kTriSpan + threadIdx.x;
-    uint64_t mask = 0;
+    uint64_t mask[H];
     uint32_t id = 0;
-    if (slot < V) {
-      mask = a.tri_masks[slot];
-      id = a.visible[first + slot];
+    uint32_t c = 0;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      mask[h] = slot < V ? a.tri_masks[(size_t)slot * H + h] : 0ull;
+      c += (uint32_t)__popcll((unsigned long long)mask[h]);
     }
-    const uint32_t c = (uint32_t)__popcll((unsigned long long)mask);
+    if (slot < V) id = a.visible[first + slot];
     const uint32_t incl = wave_incl_scan(c, lane);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     uint32_t woff = 0;
     for (int k = 0; k < wave; k++) woff += s_wave[k];
     s_off[threadIdx.x] = woff + incl - c;
-    s_mask[threadIdx.x] = mask;
+#pragma unroll
+    for (int h = 0; h < H; h++) s_mask[threadIdx.x * H + h] = mask[h];
     s_id[threadIdx.x] = id;
     if (threadIdx.x == 255 && span == nspans - 1) {
       a.draw_cmd[0] = (base + woff + incl) * 3u;  // DrawIndexedIndirect.index_count
     }
     __syncthreads();
-    // each wave expands 64 slots.  A slot's <= 192 packed indices are first laid out in rank order in a
+    // each wave expands 64 slots.  A slot's packed indices are first laid out in rank order in a
     // per-wave LDS strip, then written as contiguous 256-byte wave stores (a direct store would be
     // three stride-12 scatters per slot: store-issue bound, profiles/r01_config3_pmc.json).
-    uint32_t* strip = s_strip + wave * 192;
+    uint32_t* strip = s_strip + wave * (192 * H);
 #pragma unroll 2
     for (int k = 0; k < 64; k++) {
       const int s = wave * 64 + k;
-      const uint64_t m = s_mask[s];
-      if (m == 0ull) continue;  // wave-uniform
-      const uint32_t n3 = (uint32_t)__popcll((unsigned long long)m) * 3u;
-      const uint32_t o = (base + s_off[s]) * 3u;
-      if ((m >> lane) & 1ull) {
-        const uint32_t rank = (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-        const uint32_t packed = s_id[s] << 8;  // MESHLET_PRIMITIVE_BITS
-        const uint32_t t3 = (uint32_t)lane * 3u;
-        strip[rank * 3u + 0] = packed | ((t3 + 0u) & 0xFFu);
-        strip[rank * 3u + 1] = packed | ((t3 + 1u) & 0xFFu);
-        strip[rank * 3u + 2] = packed | ((t3 + 2u) & 0xFFu);
+      uint32_t n3 = 0, before = 0;
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const uint64_t m = s_mask[s * H + h];
+        if ((m >> lane) & 1ull) {
+          const uint32_t rank = before + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+          const uint32_t packed = s_id[s] << kCornerBits;
+          const uint32_t t3 = ((uint32_t)lane + 64u * (uint32_t)h) * 3u;
+          strip[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
+          strip[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
+          strip[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
+        }
+        before += (uint32_t)__popcll((unsigned long long)m);
       }
+      n3 = before * 3u;
+      if (n3 == 0u) continue;  // wave-uniform
+      const uint32_t o = (base + s_off[s]) * 3u;
       // same wave, in-order LDS: the reads below see the writes above
 #pragma unroll
-      for (uint32_t r = 0; r < 3; r++) {
+      for (uint32_t r = 0; r < 3u * H; r++) {
         const uint32_t i = (uint32_t)lane + 64u * r;
         if (i < n3) a.out[o + i] = strip[i];
       }
@@ -1223,13 +1248,13 @@ template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
   meshlets_emit_body<HIZ, LATE>(a);
 }
-template <bool LATE>
-__global__ __launch_bounds__(256, 8) void k_cull_triangles_test(TriTestArgs a) {
-  tris_test_body<LATE>(a);
+template <bool LATE, bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 6 : 8) void k_cull_triangles_test(TriTestArgs a) {
+  tris_test_body<LATE, WIDE>(a);
 }
-template <bool LATE>
+template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
-  tris_emit_body<LATE>(a);
+  tris_emit_body<LATE, WIDE>(a);
 }
 
 // Batched prepare: gets the whole blob by value (kernarg), publishes it for the later kernels of the
@@ -1257,10 +1282,10 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlo
   meshlets_emit_body<false, false>(dev->emit[blockIdx.y]);
 }
 __global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchBlob* __restrict__ dev) {
-  tris_test_body<false>(dev->ttest[blockIdx.y]);
+  tris_test_body<false, false>(dev->ttest[blockIdx.y]);
 }
 __global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchBlob* __restrict__ dev) {
-  tris_emit_body<false>(dev->temit[blockIdx.y]);
+  tris_emit_body<false, false>(dev->temit[blockIdx.y]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1326,17 +1351,27 @@ void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_
   else
     hipLaunchKernelGGL((k_cull_meshlets_emit<true, false>), g, b, 0, s, a);
 }
-void launch_tris_test(const TriTestArgs& a, bool late, uint32_t grid, hipStream_t s) {
-  if (late)
-    hipLaunchKernelGGL((k_cull_triangles_test<true>), dim3(grid), dim3(256), 0, s, a);
+void launch_tris_test(const TriTestArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {
+  dim3 g(grid), b(256);
+  if (late && wide)
+    hipLaunchKernelGGL((k_cull_triangles_test<true, true>), g, b, 0, s, a);
+  else if (late)
+    hipLaunchKernelGGL((k_cull_triangles_test<true, false>), g, b, 0, s, a);
+  else if (wide)
+    hipLaunchKernelGGL((k_cull_triangles_test<false, true>), g, b, 0, s, a);
   else
-    hipLaunchKernelGGL((k_cull_triangles_test<false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_cull_triangles_test<false, false>), g, b, 0, s, a);
 }
-void launch_tris_emit(const TriEmitArgs& a, bool late, uint32_t grid, hipStream_t s) {
-  if (late)
-    hipLaunchKernelGGL((k_cull_triangles_emit<true>), dim3(grid), dim3(256), 0, s, a);
+void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {
+  dim3 g(grid), b(256);
+  if (late && wide)
+    hipLaunchKernelGGL((k_cull_triangles_emit<true, true>), g, b, 0, s, a);
+  else if (late)
+    hipLaunchKernelGGL((k_cull_triangles_emit<true, false>), g, b, 0, s, a);
+  else if (wide)
+    hipLaunchKernelGGL((k_cull_triangles_emit<false, true>), g, b, 0, s, a);
   else
-    hipLaunchKernelGGL((k_cull_triangles_emit<false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_cull_triangles_emit<false, false>), g, b, 0, s, a);
 }
 void launch_hiz(const HizArgs& a, hipStream_t s) {
   if (a.w % 64 == 0 && a.h % 64 == 0) {

@@ -159,8 +159,8 @@ void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, 
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s);
 void launch_meshlets_fused(const MeshletTestArgs& a, uint32_t grid, hipStream_t s);
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
-void launch_tris_test(const TriTestArgs& a, bool late, uint32_t grid, hipStream_t s);
-void launch_tris_emit(const TriEmitArgs& a, bool late, uint32_t grid, hipStream_t s);
+void launch_tris_test(const TriTestArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
+void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
 void launch_hiz(const HizArgs& a, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch
 void launch_prepare_batch(const BatchBlob& blob, BatchBlob* dev, uint32_t grid, hipStream_t s);

@@ -72,6 +72,8 @@ struct CullGeometryContext {
   // not in the reference struct (it is a local there, CullGeometry.cpp:125-127): the indirect
   // dispatch command of cull_triangles, exposed so callers can read the visible-meshlet count
   Buffer cull_triangles_cmd_buffer = {};
+  // extension: wide packed index for meshlets of up to 128 triangles
+  bool wide_triangle_index = false;
 };
 
 struct MainGeometryContext {
@@ -130,6 +132,7 @@ public:
     c.vsm_clipmaps_buffer = context.vsm_clipmaps_buffer;
     c.vsm_clipmap_dirty_flags_buffer = context.vsm_clipmap_dirty_flags_buffer;
     c.vsm_clipmap_count = context.vsm_clipmap_count;
+    c.wide_triangle_index = context.wide_triangle_index;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));

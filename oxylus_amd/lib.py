@@ -96,7 +96,7 @@ class CullGeometryContext(C.Structure):
         ("vsm_clipmaps_buffer", Buffer),
         ("vsm_clipmap_dirty_flags_buffer", Buffer),
         ("vsm_clipmap_count", C.c_uint32),
-        ("_pad0", C.c_uint32),
+        ("wide_triangle_index", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),

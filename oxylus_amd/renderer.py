@@ -112,14 +112,14 @@ class PreparedFrame:
     reordered_indices_buffer: Optional[torch.Tensor]
 
     @staticmethod
-    def create(scene: Scene, with_triangles: bool = True, expand: bool = True) -> "PreparedFrame":
+    def create(scene: Scene, with_triangles: bool = True, expand: bool = True, max_tris: int = 64) -> "PreparedFrame":
         dev = scene.device
         n = scene.n_meshlet_instances
         mli = scene.meshlet_instances.clone() if expand else torch.zeros((n, 2), dtype=torch.int32, device=dev)
         vis_idx = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         # zero-filled on (re)upload of the instances, RendererInstance.cpp:1651-1665
         mask = torch.zeros(max((n + 31) // 32, 1), dtype=torch.int32, device=dev)
-        reordered = torch.zeros(max(n, 1) * 64 * 3, dtype=torch.int32, device=dev) if with_triangles else None
+        reordered = torch.zeros(max(n, 1) * max_tris * 3, dtype=torch.int32, device=dev) if with_triangles else None
         return PreparedFrame(scene, n, mli, vis_idx, mask, reordered)
 
     def c(self) -> L.PreparedFrame:
@@ -150,6 +150,7 @@ class CullGeometryContext:
     vsm_clipmaps_buffer: Optional[torch.Tensor] = None            # uint8 [V*76] GPU::VirtualClipmap records
     vsm_clipmap_dirty_flags_buffer: Optional[torch.Tensor] = None  # int32 [V]
     vsm_clipmap_count: int = 0
+    wide_triangle_index: bool = False  # extension: (id << 9) | (3t+k), meshlets of up to 128 triangles
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -167,6 +168,7 @@ class CullGeometryContext:
         c.vsm_clipmaps_buffer = _buf(self.vsm_clipmaps_buffer)
         c.vsm_clipmap_dirty_flags_buffer = _buf(self.vsm_clipmap_dirty_flags_buffer)
         c.vsm_clipmap_count = self.vsm_clipmap_count
+        c.wide_triangle_index = int(self.wide_triangle_index)
         return c
 
 

@@ -417,3 +417,29 @@ def test_batch_falls_back_for_mixed_or_large_batches(renderer, oracle_lib):
         c = renderer.read_counters(cx)
         assert np.array_equal(fr.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu().numpy(), want["visible"])
         assert np.array_equal(fr.reordered_indices_buffer[: c.draw_index_count].cpu().numpy(), want["indices"])
+
+
+@pytest.mark.parametrize("spec", [SceneSpec(n_mesh_instances=12, meshlets_per_mesh=70, tris_per_meshlet=124, seed=111),
+                                  SceneSpec(n_mesh_instances=5, meshlets_per_mesh=33, tris_per_meshlet=128, seed=112, ragged=True)],
+                         ids=["124tris", "ragged<=128"])
+def test_wide_triangle_index_extension(renderer, oracle_lib, spec):
+    """SURVEY A.7 extension: meshlets of up to 128 triangles with the (id << 9) | (3t+k) index.  No
+    reference behaviour exists for it (the reference's 8-bit corner field stops at 85 triangles); parity is
+    against the oracle's statement of the same rule."""
+    import oracle
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    cpu, gpu = _pair(spec)
+    cam = cpu.cull_camera()
+    want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances)
+    want_idx = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, 0, want_vis.numel(), wide=True)
+    frame = PreparedFrame.create(gpu, max_tris=128)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=True)
+    renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    assert torch.equal(frame.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu(), want_vis)
+    got = frame.reordered_indices_buffer[: c.draw_index_count].cpu()
+    assert torch.equal(got, want_idx)
+    assert int((got & 0x1FF).max()) > 255  # corners beyond the reference's 8-bit field are actually used
