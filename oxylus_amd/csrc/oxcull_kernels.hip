@@ -405,7 +405,7 @@ OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4
     }
     visible = visible && (!need_cone || cone_ok);
   }
-  if (HIZ && OCCL_OR_LATE) {
+  if (HIZ && OCCL_OR_LATE && !(a.ablate & 64u)) {
     if (__any(visible)) {
       float mvp[16];
       unpack_mvp(u.v0, mvp);

@@ -53,7 +53,7 @@ struct HpbTestArgs {
 };
 
 struct MeshletTestArgs {
-  uint32_t ablate;  // timing experiments only (OXC_ABLATE): 1 skip cone, 2 skip frustum, 4 skip bounds load, 8 skip evaluation
+  uint32_t ablate;  // timing experiments only (OXC_ABLATE): 1 skip cone, 2 skip frustum, 4 skip bounds load, 8 skip evaluation, 16 skip row unpack, 32 skip publication, 64 skip occlusion
   uint32_t n_host;  // != 0: the list length is known on the host (seeded lists); skips the dependent load of vis[0]
   const InstCache* cache;
   const GpuMeshletInstance* meshlet_instances;
