@@ -187,23 +187,6 @@ OXC_DEV bool cone_visible(const float* world, const float* nm, float scale_max, 
   return cutoff >= 1.0f || !culled;
 }
 
-// Wave-level variant of test_frustum_planes: identical per-lane result; once no lane of the wave
-// that still matters (`live`) is inside, the remaining planes are skipped.
-OXC_DEV bool test_frustum_planes_wave(const float* pl, float cx, float cy, float cz, float ex, float ey, float ez, bool live) {
-  float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
-  bool inside = live;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    if (!__any(inside)) break;
-    float nx = pl[i * 4 + 0], ny = pl[i * 4 + 1], nz = pl[i * 4 + 2], nw = pl[i * 4 + 3];
-    float qx = cx + asf(asu(hx) ^ (asu(nx) & 0x80000000u));
-    float qy = cy + asf(asu(hy) ^ (asu(ny) & 0x80000000u));
-    float qz = cz + asf(asu(hz) ^ (asu(nz) & 0x80000000u));
-    inside = inside && !(dot3(qx, qy, qz, nx, ny, nz) <= -nw);
-  }
-  return inside;
-}
-
 // Two-tier cone test (cull_meshlets.slang:49-52, cull.slang:173-175).  Tier 1 evaluates
 //   L = dot(d, n) / |n|   and   R = cutoff * |d| + |h| * scale
 // with the 1-ulp hardware v_rsq_f32 / v_sqrt_f32 (quarter-rate single instructions) instead of three
