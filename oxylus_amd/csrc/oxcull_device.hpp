@@ -57,15 +57,16 @@ OXC_DEV uint4 load_global_u4(uint64_t base, uint32_t index) {
 OXC_DEV float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx + ay * by) + az * bz; }
 OXC_DEV float len3(float x, float y, float z) { return __builtin_sqrtf(dot3(x, y, z, x, y, z)); }
 
-// com::dequantize_half, common/math.slang:193-201 (h in the low 16 bits): denormals flush to
-// signed zero, everything else is the IEEE value.  v_cvt_f32_f16 gives the IEEE value (4 VALU ops
-// instead of the shader's 10 integer ops); the flush is the |f| < 2^-14 select.  Only signalling
-// NaN inputs differ from the shader's bit formula (the hardware quiets them: payload bit 22 set);
-// no decision can depend on a NaN payload.
-OXC_DEV float dequantize_half(uint32_t h) {
-  const float f = (float)__builtin_bit_cast(_Float16, (unsigned short)h);
-  return __builtin_fabsf(f) < 6.103515625e-05f ? asf(asu(f) & 0x80000000u) : f;
-}
+// com::dequantize_half, common/math.slang:193-201 (h in the low 16 bits): denormals flush to signed
+// zero, everything else is the IEEE value.  One instruction: v_cvt_f32_f16 with the wave's FP16/FP64
+// denormal mode set to flush (set_half_denorm_flush() below, MODE.FP_DENORM[3:2] = 0) -- the hardware
+// then reads a denormal half as +-0, which is exactly the shader's rule.  f32 denormal handling
+// (MODE.FP_DENORM[1:0]) is untouched.  Only signalling-NaN inputs differ from the shader's bit
+// formula (the conversion quiets them); no decision can depend on a NaN payload.
+// tests/test_gpu_parity.py::test_decode_known_answers_all_halfs_and_s8 sweeps all 65536 inputs.
+OXC_DEV float dequantize_half(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+// hwreg(HW_REG_MODE = 1, offset 6, width 2) = ((2 - 1) << 11) | (6 << 6) | 1
+OXC_DEV void set_half_denorm_flush() { __builtin_amdgcn_s_setreg(((2 - 1) << 11) | (6 << 6) | 1, 0); }
 
 // i32(s8) / 127.0 (scene.slang:408-418), correctly rounded.  x * (1/127) alone is wrong for 16
 // of the 256 inputs; one Markstein refinement step is exact for all 256 (checked exhaustively
@@ -77,6 +78,20 @@ OXC_DEV float s8_over_127(int32_t x) {
   float q = xf * r;
   float e = __builtin_fmaf(-q, 127.0f, xf);
   return __builtin_fmaf(e, r, q);
+}
+
+// Two binary32 values side by side: arithmetic on f2 is one packed VALU instruction (v_pk_mul_f32,
+// v_pk_add_f32, v_pk_fma_f32) performing two independent IEEE operations -- the same roundings as the
+// scalar spelling, half the issue slots.  A scalar broadcast {x, x} costs nothing (op_sel).
+typedef float f2 __attribute__((ext_vector_type(2)));
+OXC_DEV f2 splat(float x) { return f2{x, x}; }
+// s8_over_127 for two values at once
+OXC_DEV f2 s8_over_127_x2(int32_t x, int32_t y) {
+  const f2 r = splat(1.0f / 127.0f);
+  const f2 xf = {(float)x, (float)y};
+  const f2 q = xf * r;
+  const f2 e = __builtin_elementwise_fma(-q, splat(127.0f), xf);
+  return __builtin_elementwise_fma(e, r, q);
 }
 
 // float -> u32 / i32 with v_cvt semantics (saturating, NaN -> 0), spelled out so that the
@@ -133,19 +148,25 @@ OXC_DEV void frustum_planes(const float* mvp, float* pl /*24*/) {
   }
 }
 
-// cull.slang:73-83 with pre-normalised planes.  (An fma(h, copysign(1,n), c) p-vertex would be
-// bit-identical and one op shorter, but the 18 extra sign SGPRs per instance push the kernel
-// into SGPR spilling -- measured: 48 -> 124 VGPRs -- so the xor form stays.)
-OXC_DEV bool test_frustum_planes(const float* pl, float cx, float cy, float cz, float ex, float ey, float ez) {
-  float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
+// cull.slang:73-83 with pre-normalised planes, two planes per packed instruction.
+// pl2[p*8 + c*2 + k] = component c of plane 2p+k; sg2[p*6 + c*2 + k] = +-1.0 carrying that component's
+// sign bit.  The p-vertex component  c + asfloat(asuint(h) ^ signbit(n))  is  c + h * (+-1.0): the
+// product is exact (also for -0, denormals, Inf; a NaN stays a NaN and fails every comparison either
+// way), so the sum rounds once, exactly like the shader's.  Per plane pair: 3 pk_mul + 3 pk_add for the
+// p-vertex, 3 pk_mul + 2 pk_add for the dot (left to right, no contraction), 2 compares.
+OXC_DEV bool test_frustum_planes(const float* pl2, const float* sg2, float cx, float cy, float cz, float ex, float ey, float ez) {
+  const f2 hxy = f2{ex, ey} * splat(0.5f);
+  const float hz = ez * 0.5f;
   bool inside = true;
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    float nx = pl[i * 4 + 0], ny = pl[i * 4 + 1], nz = pl[i * 4 + 2], nw = pl[i * 4 + 3];
-    float qx = cx + asf(asu(hx) ^ (asu(nx) & 0x80000000u));
-    float qy = cy + asf(asu(hy) ^ (asu(ny) & 0x80000000u));
-    float qz = cz + asf(asu(hz) ^ (asu(nz) & 0x80000000u));
-    inside = inside && !(dot3(qx, qy, qz, nx, ny, nz) <= -nw);
+  for (int p = 0; p < 3; p++) {
+    const float* n = pl2 + p * 8;
+    const float* sg = sg2 + p * 6;
+    const f2 qx = splat(cx) + splat(hxy.x) * f2{sg[0], sg[1]};
+    const f2 qy = splat(cy) + splat(hxy.y) * f2{sg[2], sg[3]};
+    const f2 qz = splat(cz) + splat(hz) * f2{sg[4], sg[5]};
+    const f2 d = (qx * f2{n[0], n[1]} + qy * f2{n[2], n[3]}) + qz * f2{n[4], n[5]};
+    inside = inside & !(d.x <= -n[6]) & !(d.y <= -n[7]);
   }
   return inside;
 }
@@ -168,20 +189,28 @@ OXC_DEV void normal_matrix(const float* w, float* nm) {
   }
 }
 
-// cull_meshlets.slang:49-52 + cull.slang:173-175.  Returns cone_visible.
-// world: rows 0..2 (world[r*4+c]); nm column-major 3x3.
-OXC_DEV bool cone_visible(const float* world, const float* nm, float scale_max, float camx, float camy, float camz,
-                          float cx, float cy, float cz, float ex, float ey, float ez, float ax, float ay, float az,
-                          float cutoff) {
+// Wave-uniform cone operands of one mesh instance (InstCache dwords 60, 64..85).
+struct ConeU {
+  float nm[9];       // normal matrix, column-major
+  float w2[3][2];    // w2[c][k] = world(row k, col c), k = 0,1
+  float wt2[2];      // world(row 0..1, col 3)
+  float wr2[4];      // world row 2
+  float scale_max;
+};
+
+// cull_meshlets.slang:49-52 + cull.slang:173-175.  Returns cone_visible.  Canonical (tier 2) arithmetic.
+OXC_DEV bool cone_visible(const ConeU& u, float camx, float camy, float camz, float cx, float cy, float cz, float ex, float ey, float ez,
+                          float ax, float ay, float az, float cutoff) {
+  const float* nm = u.nm;
   float nx = (nm[0] * ax + nm[3] * ay) + nm[6] * az;
   float ny = (nm[1] * ax + nm[4] * ay) + nm[7] * az;
   float nz = (nm[2] * ax + nm[5] * ay) + nm[8] * az;
   float l = len3(nx, ny, nz);
   float kx = nx / l, ky = ny / l, kz = nz / l;
-  float wx = ((world[0] * cx + world[1] * cy) + world[2] * cz) + world[3];
-  float wy = ((world[4] * cx + world[5] * cy) + world[6] * cz) + world[7];
-  float wz = ((world[8] * cx + world[9] * cy) + world[10] * cz) + world[11];
-  float radius = len3(ex * 0.5f, ey * 0.5f, ez * 0.5f) * scale_max;
+  float wx = ((u.w2[0][0] * cx + u.w2[1][0] * cy) + u.w2[2][0] * cz) + u.wt2[0];
+  float wy = ((u.w2[0][1] * cx + u.w2[1][1] * cy) + u.w2[2][1] * cz) + u.wt2[1];
+  float wz = ((u.wr2[0] * cx + u.wr2[1] * cy) + u.wr2[2] * cz) + u.wr2[3];
+  float radius = len3(ex * 0.5f, ey * 0.5f, ez * 0.5f) * u.scale_max;
   float dx = wx - camx, dy = wy - camy, dz = wz - camz;
   bool culled = dot3(dx, dy, dz, kx, ky, kz) >= cutoff * len3(dx, dy, dz) + radius;
   return cutoff >= 1.0f || !culled;
@@ -190,28 +219,31 @@ OXC_DEV bool cone_visible(const float* world, const float* nm, float scale_max, 
 // Two-tier cone test (cull_meshlets.slang:49-52, cull.slang:173-175).  Tier 1 evaluates
 //   L = dot(d, n) / |n|   and   R = cutoff * |d| + |h| * scale
 // with the 1-ulp hardware v_rsq_f32 / v_sqrt_f32 (quarter-rate single instructions) instead of three
-// IEEE divisions and three correctly rounded square roots.  Both tiers approximate the same real
-// numbers with a relative error of a few 2^-23 of (|d| + radius) -- at most ~12 roundings of
+// IEEE divisions and three correctly rounded square roots.  n, d and h are formed with the canonical
+// roundings (x/y components as packed pairs -- same operations); from there both tiers approximate the
+// same real numbers with a relative error of a few 2^-23 of (|d| + radius) -- at most ~12 roundings of
 // magnitude <= |d| + radius on either side, i.e. < 3e-6 * (|d| + radius) -- so when |L - R| exceeds
 // kConeMargin * (|d| + radius) = 1.6e-5 * (...) the canonical (tier 2) comparison is already decided.
 // Lanes inside the margin are undecided; the caller runs the exact path when any lane of the wave is.
 // Returns: 0 = culled, 1 = cone-visible, 2 = undecided.
 constexpr float kConeMargin = 1.6e-5f;
-OXC_DEV int cone_visible_fast(const float* world, const float* nm, float scale_max, float camx, float camy, float camz,
-                              float cx, float cy, float cz, float ex, float ey, float ez, float ax, float ay, float az,
-                              float cutoff) {
-  float nx = (nm[0] * ax + nm[3] * ay) + nm[6] * az;
-  float ny = (nm[1] * ax + nm[4] * ay) + nm[7] * az;
-  float nz = (nm[2] * ax + nm[5] * ay) + nm[8] * az;
-  float wx = ((world[0] * cx + world[1] * cy) + world[2] * cz) + world[3];
-  float wy = ((world[4] * cx + world[5] * cy) + world[6] * cz) + world[7];
-  float wz = ((world[8] * cx + world[9] * cy) + world[10] * cz) + world[11];
-  float dx = wx - camx, dy = wy - camy, dz = wz - camz;
-  float hx = ex * 0.5f, hy = ey * 0.5f, hz = ez * 0.5f;
-  float inv_l = __builtin_amdgcn_rsqf(dot3(nx, ny, nz, nx, ny, nz));
-  float dlen = __builtin_amdgcn_sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-  float radius = __builtin_amdgcn_sqrtf(dot3(hx, hy, hz, hx, hy, hz)) * scale_max;
-  float L = dot3(dx, dy, dz, nx, ny, nz) * inv_l;
+OXC_DEV int cone_visible_fast(const ConeU& u, float camx, float camy, float camz, float cx, float cy, float cz, float ex, float ey, float ez,
+                              float ax, float ay, float az, float cutoff) {
+  const float* nm = u.nm;
+  const f2 nxy = (f2{nm[0], nm[1]} * splat(ax) + f2{nm[3], nm[4]} * splat(ay)) + f2{nm[6], nm[7]} * splat(az);
+  const float nz = (nm[2] * ax + nm[5] * ay) + nm[8] * az;
+  const f2 wxy = ((f2{u.w2[0][0], u.w2[0][1]} * splat(cx) + f2{u.w2[1][0], u.w2[1][1]} * splat(cy)) + f2{u.w2[2][0], u.w2[2][1]} * splat(cz)) +
+                 f2{u.wt2[0], u.wt2[1]};
+  const float wz = ((u.wr2[0] * cx + u.wr2[1] * cy) + u.wr2[2] * cz) + u.wr2[3];
+  const f2 dxy = wxy - f2{camx, camy};
+  const float dz = wz - camz;
+  const f2 hxy = f2{ex, ey} * splat(0.5f);
+  const float hz = ez * 0.5f;
+  const f2 nn = nxy * nxy, dd = dxy * dxy, dn = dxy * nxy, hh = hxy * hxy;
+  float inv_l = __builtin_amdgcn_rsqf((nn.x + nn.y) + nz * nz);
+  float dlen = __builtin_amdgcn_sqrtf((dd.x + dd.y) + dz * dz);
+  float radius = __builtin_amdgcn_sqrtf((hh.x + hh.y) + hz * hz) * u.scale_max;
+  float L = ((dn.x + dn.y) + dz * nz) * inv_l;
   float R = cutoff * dlen + radius;
   float T = kConeMargin * (dlen + radius);
   float diff = L - R;

@@ -149,7 +149,12 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       for (int c = 0; c < 4; c++) pl[c] = pl[c] / l;
     }
     InstCache* out = rows + mi;
-    if (valid && sub < 6) *reinterpret_cast<float4*>(&out->planes[sub * 4]) = make_float4(pl[0], pl[1], pl[2], pl[3]);
+    if (valid && sub < 6) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) out->planes2[sub >> 1][c][sub & 1u] = pl[c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) out->signs2[sub >> 1][c][sub & 1u] = (asu(pl[c]) & 0x80000000u) ? -1.0f : 1.0f;
+    }
 
     // cull_meshes frustum test of the mesh AABB (cull_meshes.slang:34): lane k tests plane k
     bool outside = false;
@@ -168,8 +173,14 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       for (int k = 0; k < 4; k++)
         *reinterpret_cast<float4*>(&out->mvp[k * 4]) = make_float4(mvp[k * 4], mvp[k * 4 + 1], mvp[k * 4 + 2], mvp[k * 4 + 3]);
 #pragma unroll
-      for (int r = 0; r < 3; r++)
-        *reinterpret_cast<float4*>(&out->world[r * 4]) = make_float4(OXC_M(w, r, 0), OXC_M(w, r, 1), OXC_M(w, r, 2), OXC_M(w, r, 3));
+      for (int c = 0; c < 3; c++) {
+        out->world2[c][0] = OXC_M(w, 0, c);
+        out->world2[c][1] = OXC_M(w, 1, c);
+      }
+      out->world_t2[0] = OXC_M(w, 0, 3);
+      out->world_t2[1] = OXC_M(w, 1, 3);
+#pragma unroll
+      for (int c = 0; c < 4; c++) out->world_r2[c] = OXC_M(w, 2, c);
     }
     if (valid && sub == 7) {
       float nm[9];
@@ -295,38 +306,40 @@ OXC_DEV void expand_body(const ExpandArgs& a) {
 // mvp are pulled out of the still-resident row dwords `v0` inside the wave-uniform branches that use
 // them.  Fewer live SGPRs = more resident waves (the kernel's throughput is residency / chain latency).
 struct InstU {
-  float pl[24];
+  float pl[24];  // planes2
+  float sg[18];  // signs2
   uint32_t vis_offset;
   uint64_t bounds;
-  uint32_t v0;  // VGPR: dword `lane` of the InstCache row
+  uint32_t v0, v1;  // VGPRs: dword `lane` / dword 64 + (lane & 31) of the InstCache row
 };
-struct ConeU {
-  float world[12];
-  float nm[9];
-  float scale_max;
-};
-OXC_DEV void unpack_cone(uint32_t v0, ConeU& c) {
+OXC_DEV void unpack_cone(uint32_t v0, uint32_t v1, ConeU& c) {
 #pragma unroll
-  for (int k = 0; k < 12; k++) c.world[k] = readlane_f(v0, 40 + k);
+  for (int k = 0; k < 9; k++) c.nm[k] = readlane_f(v1, kRowNm - 64 + k);
 #pragma unroll
-  for (int k = 0; k < 9; k++) c.nm[k] = readlane_f(v0, 52 + k);
-  c.scale_max = readlane_f(v0, 61);
+  for (int k = 0; k < 6; k++) c.w2[k >> 1][k & 1] = readlane_f(v1, kRowWorld2 - 64 + k);
+#pragma unroll
+  for (int k = 0; k < 2; k++) c.wt2[k] = readlane_f(v1, kRowWorldT2 - 64 + k);
+#pragma unroll
+  for (int k = 0; k < 4; k++) c.wr2[k] = readlane_f(v1, kRowWorldR2 - 64 + k);
+  c.scale_max = readlane_f(v0, kRowScale);
 }
 OXC_DEV void unpack_mvp(uint32_t v0, float* mvp) {
 #pragma unroll
-  for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, 24 + k);
+  for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, kRowMvp + k);
 }
 
-template <bool NEED_MVP>
 OXC_DEV void load_inst_uniform(const InstCache* __restrict__ cache, uint32_t mi, int lane, InstU& u) {
   const uint64_t p = reinterpret_cast<uint64_t>(cache + mi);
   uint32_t v0 = load_global_u32(p, lane);
-  uint32_t v1 = load_global_u32(p, 64 + (lane & 15));
+  uint32_t v1 = load_global_u32(p, 64 + (lane & 31));
 #pragma unroll
-  for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, k);
-  u.vis_offset = readlane_u(v0, 62);
-  u.bounds = (uint64_t)readlane_u(v1, 0) | ((uint64_t)readlane_u(v1, 1) << 32);
+  for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, kRowPlanes + k);
+#pragma unroll
+  for (int k = 0; k < 18; k++) u.sg[k] = readlane_f(v0, kRowSigns + k);
+  u.vis_offset = readlane_u(v0, kRowVisOffset);
+  u.bounds = (uint64_t)readlane_u(v1, kRowBounds - 64) | ((uint64_t)readlane_u(v1, kRowBounds - 64 + 1) << 32);
   u.v0 = v0;
+  u.v1 = v1;
 }
 
 // Set/clear bits of the persistent visibility mask for the lanes in `active`.
@@ -375,8 +388,8 @@ struct LaneResult {
 // Frustum first (cheap, rejects most), cone only when some lane of the wave still needs it:
 // visible = cone && frustum is order-independent, so the skip changes no result.
 template <bool HIZ, bool OCCL, bool LATE>
-OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4 b, uint32_t meshlet_index, bool mine,
-                           const HizView& hiz, const uint32_t* s_level_off, LaneResult& out) {
+OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, ConeU& cu, bool& cone_ready, const uint4 b, uint32_t meshlet_index,
+                           bool mine, const HizView& hiz, const uint32_t* s_level_off, LaneResult& out) {
   constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
   const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16);
   const float cz = dequantize_half(b.y & 0xFFFFu);
@@ -391,20 +404,21 @@ OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, const uint4
   bool visible = mine && ((HIZ && !LATE) ? was_visible : true);
   // straight-line six-plane test: per-plane wave-level early-outs were measured 3 % slower (the kernel is
   // issue-bound; 24 extra branches per wave step cost more than the skipped planes save)
-  if (!(a.ablate & 2u)) visible = visible && test_frustum_planes(u.pl, cx, cy, cz, ex, ey, ez);
+  if (!(a.ablate & 2u)) visible = visible & test_frustum_planes(u.pl, u.sg, cx, cy, cz, ex, ey, ez);
   const int32_t cutoff_s8 = (int32_t)b.w >> 24;
   const bool need_cone = visible && cutoff_s8 != 127 && !(a.ablate & 1u);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
   if (__any(need_cone)) {
-    const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
-    const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127(cutoff_s8);
-    ConeU cu;
-    unpack_cone(u.v0, cu);
-    int tier1 = cone_visible_fast(cu.world, cu.nm, cu.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az,
-                                  cutoff);
+    const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
+    const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, cutoff_s8);
+    const float ax = axy.x, ay = axy.y, az = azc.x, cutoff = azc.y;
+    if (!cone_ready) {  // once per instance round, not per 64-meshlet group (wave-uniform)
+      unpack_cone(u.v0, u.v1, cu);
+      cone_ready = true;
+    }
+    int tier1 = cone_visible_fast(cu, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az, cutoff);
     bool cone_ok = tier1 == 1;
     if (__any(need_cone && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-      const bool exact = cone_visible(cu.world, cu.nm, cu.scale_max, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay,
-                                      az, cutoff);
+      const bool exact = cone_visible(cu, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az, cutoff);
       cone_ok = tier1 == 2 ? exact : cone_ok;
     }
     visible = visible && (!need_cone || cone_ok);
@@ -439,6 +453,7 @@ constexpr uint32_t kMaxSpins = 1u << 20;  // bounded: a broken hand-off sets syn
 // G = 64-meshlet groups per wave per chunk; the block has 16/G waves so a chunk is always 1024 meshlets.
 template <bool HIZ, bool OCCL, bool LATE, bool FUSED, int G>
 OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
+  set_half_denorm_flush();
   constexpr int kWaves = 16 / G;
   __shared__ uint32_t s_red[kWaves];
   __shared__ uint32_t s_fused[4];  // [0] epoch, [1] base, [2] last-arriver flag
@@ -526,7 +541,9 @@ OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
         u.bounds = reinterpret_cast<uint64_t>(a.cache);
         u.v0 = 0;
       } else
-        load_inst_uniform<HIZ>(a.cache, mi_u, lane, u);
+        load_inst_uniform(a.cache, mi_u, lane, u);
+      ConeU cu;
+      bool cone_ready = false;
       bool mine[G];
       uint4 bnd[G];
 #pragma unroll
@@ -542,7 +559,7 @@ OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
           if (a.ablate & 8u) {
             if (mine[j]) res[j].emit = (rec[j].y & 3u) == 0u;
           } else
-            eval_meshlets<HIZ, OCCL, LATE>(a, u, bnd[j], rec[j].y, mine[j], hiz, s_level_off, res[j]);
+            eval_meshlets<HIZ, OCCL, LATE>(a, u, cu, cone_ready, bnd[j], rec[j].y, mine[j], hiz, s_level_off, res[j]);
           pending[j] &= ~m;
         }
       }
@@ -687,6 +704,7 @@ OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
 // by k_cull_meshlets_emit<false,false> like the plain meshlet stage.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
+  set_half_denorm_flush();
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_level_off[13];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -719,16 +737,18 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
         const uint32_t mi_u = readlane_u(rec.x, __ffsll((unsigned long long)pending) - 1);
         const bool mine = in && rec.x == mi_u;
         // camera row: planes + normal matrix + bounds pointer
-        float pl[24], nm[9];
+        float pl[24], sg[18], nm[9];
         uint64_t bounds;
         {
           const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + mi_u);
-          uint32_t v0 = p[lane], v1 = p[64 + (lane & 15)];
+          uint32_t v0 = p[lane], v1 = p[64 + (lane & 31)];
 #pragma unroll
-          for (int k = 0; k < 24; k++) pl[k] = readlane_f(v0, k);
+          for (int k = 0; k < 24; k++) pl[k] = readlane_f(v0, kRowPlanes + k);
 #pragma unroll
-          for (int k = 0; k < 9; k++) nm[k] = readlane_f(v0, 52 + k);
-          bounds = (uint64_t)readlane_u(v1, 0) | ((uint64_t)readlane_u(v1, 1) << 32);
+          for (int k = 0; k < 18; k++) sg[k] = readlane_f(v0, kRowSigns + k);
+#pragma unroll
+          for (int k = 0; k < 9; k++) nm[k] = readlane_f(v1, kRowNm - 64 + k);
+          bounds = (uint64_t)readlane_u(v1, kRowBounds - 64) | ((uint64_t)readlane_u(v1, kRowBounds - 64 + 1) << 32);
         }
         uint4 b = make_uint4(0, 0, 0, 0);
         if (mine) b = load_global_u4(bounds, rec.y);
@@ -736,26 +756,28 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
         const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16), ez = dequantize_half(b.w & 0xFFFFu);
         const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
         const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127((int32_t)b.w >> 24);
-        bool cand = mine && test_frustum_planes(pl, cx, cy, cz, ex, ey, ez);
+        bool cand = mine && test_frustum_planes(pl, sg, cx, cy, cz, ex, ey, ez);
         cand = cand && cone_visible_directional(nm, a.light_dir[0], a.light_dir[1], a.light_dir[2], ax, ay, az, cutoff);
         bool vis = false;
         for (uint32_t v = 0; v < a.clipmap_count; v++) {
           if (a.dirty[v] == 0u) continue;          // uniform
           if (!__any(cand && !vis)) break;         // nobody in the wave still needs a view
-          float vpl[24], vmvp[16];
+          float vpl[24], vsg[18], vmvp[16];
           {
             const uint32_t* p = reinterpret_cast<const uint32_t*>(a.view_cache + (size_t)v * a.mesh_instance_count + mi_u);
             uint32_t v0 = p[lane];
 #pragma unroll
-            for (int k = 0; k < 24; k++) vpl[k] = readlane_f(v0, k);
+            for (int k = 0; k < 24; k++) vpl[k] = readlane_f(v0, kRowPlanes + k);
 #pragma unroll
-            for (int k = 0; k < 16; k++) vmvp[k] = readlane_f(v0, 24 + k);
+            for (int k = 0; k < 18; k++) vsg[k] = readlane_f(v0, kRowSigns + k);
+#pragma unroll
+            for (int k = 0; k < 16; k++) vmvp[k] = readlane_f(v0, kRowMvp + k);
           }
           const oxc_virtual_clipmap* cm = a.clipmaps + v;
           const float z_near = cm->z_near;
           const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
           const bool need = cand && !vis;
-          if (need && test_frustum_planes(vpl, cx, cy, cz, ex, ey, ez)) {
+          if (need && test_frustum_planes(vpl, vsg, cx, cy, cz, ex, ey, ez)) {
             float sa[6];
             if (project_aabb(vmvp, z_near, cx, cy, cz, ex, ey, ez, sa))
               vis = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
@@ -837,6 +859,7 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 // 64-bit pass masks per slot (tri_masks[2*slot + half]).
 template <bool LATE, bool WIDE>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
+  set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
   __shared__ uint32_t s_red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -924,7 +947,7 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + mi);
         uint32_t v0 = p[lane];
 #pragma unroll
-        for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, 24 + k);
+        for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, kRowMvp + k);
         cur_mi = mi;
       }
       // vertex phase: lane = vertex
@@ -1220,6 +1243,7 @@ __global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ p
 }
 
 __global__ __launch_bounds__(256) void k_debug_decode_bounds(const uint4* __restrict__ bounds, uint32_t n, float* __restrict__ out10) {
+  set_half_denorm_flush();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint4 b = bounds[i];
     float* o = out10 + (size_t)i * 10;

@@ -1,6 +1,7 @@
 // oxcull_types.hpp -- device-side mirrors of the reference GPU structs and the per-instance
 // cache the kernels stream against.  Layouts: Oxylus/include/Scene/SceneGPU.hpp:84-152.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 namespace oxc {
@@ -37,24 +38,43 @@ static_assert(sizeof(GpuMesh) == 64, "layout");
 // k_prepare_instances instead of once per meshlet (the reference re-derives mvp/planes/normal
 // matrix in every thread and chases mesh_instance -> mesh -> lods[lod] -> pointer per meshlet,
 // cull_meshlets.slang:37-52).  Same arithmetic, same order => same bits.
-// The first 64 dwords are exactly one coalesced wave load.
+// The row is two coalesced wave loads (dwords 0..63 and 64..95).  Wave-uniform operands are laid
+// out in PAIRS so that, once in SGPRs, they feed the packed f32 VALU ops (v_pk_mul_f32 /
+// v_pk_add_f32: two IEEE binary32 operations per instruction, no contraction) directly.
 struct alignas(64) InstCache {
-  float planes[24];   // 6 normalised frustum planes of mvp (cull.slang:58-71), xyzw each
-  float mvp[16];      // projection_view * world, column-major
-  float world[12];    // rows 0..2 of world: world[r*4+c]
-  float nm[9];        // TransformWorld::normal_matrix(), column-major (scene.slang:292-299)
-  float scale_max;    // max row length of world's 3x3 (scene.slang:305-310)
-  uint32_t vis_offset;     // MeshInstance::meshlet_instance_visibility_offset
-  uint32_t meshlet_count;  // of the selected LOD
-  // dwords 64..73
-  uint64_t bounds;     // MeshLOD::meshlet_bounds
+  // dwords 0..23: the 6 normalised frustum planes of mvp (cull.slang:58-71), two planes side by side:
+  // planes2[p][c][k] = component c (x,y,z,w) of plane 2p+k
+  float planes2[3][4][2];
+  // dwords 24..41: signs2[p][c][k] = -1.0 if the sign bit of planes2[p][c][k] is set, else +1.0 (c = x,y,z)
+  float signs2[3][3][2];
+  uint32_t vis_offset;     // 42: MeshInstance::meshlet_instance_visibility_offset
+  uint32_t meshlet_count;  // 43: of the selected LOD
+  float mvp[16];           // 44..59: projection_view * world, column-major
+  float scale_max;         // 60: max row length of world's 3x3 (scene.slang:305-310)
+  uint32_t _pad0[3];
+  // dwords 64..95 (second load)
+  float nm[9];             // 64..72: TransformWorld::normal_matrix(), column-major (scene.slang:292-299)
+  float _pad1;             // 73
+  float world2[3][2];      // 74..79: world2[c][k] = world(row k, col c), rows 0 and 1 side by side
+  float world_t2[2];       // 80..81: world(row 0, col 3), world(row 1, col 3)
+  float world_r2[4];       // 82..85: row 2 of world
+  uint64_t bounds;     // 86: MeshLOD::meshlet_bounds
   uint64_t meshlets;   // MeshLOD::meshlets
   uint64_t micro;      // MeshLOD::local_triangle_indices
   uint64_t vidx;       // MeshLOD::indirect_vertex_indices
   uint64_t positions;  // Mesh::vertex_positions
-  uint32_t _pad[6];
 };
-static_assert(sizeof(InstCache) == 320, "layout");
+static_assert(sizeof(InstCache) == 384, "layout");
+// dword offsets used by the v_readlane unpackers (lane l of load 0 holds dword l, of load 1 dword 64 + l)
+enum : int {
+  kRowPlanes = 0, kRowSigns = 24, kRowVisOffset = 42, kRowMeshletCount = 43, kRowMvp = 44, kRowScale = 60,
+  kRowNm = 64, kRowWorld2 = 74, kRowWorldT2 = 80, kRowWorldR2 = 82, kRowBounds = 86,
+};
+static_assert(offsetof(InstCache, signs2) == kRowSigns * 4 && offsetof(InstCache, vis_offset) == kRowVisOffset * 4 &&
+              offsetof(InstCache, mvp) == kRowMvp * 4 && offsetof(InstCache, scale_max) == kRowScale * 4 &&
+              offsetof(InstCache, nm) == kRowNm * 4 && offsetof(InstCache, world2) == kRowWorld2 * 4 &&
+              offsetof(InstCache, world_t2) == kRowWorldT2 * 4 && offsetof(InstCache, world_r2) == kRowWorldR2 * 4 &&
+              offsetof(InstCache, bounds) == kRowBounds * 4, "layout");
 
 // Counter slot handed out per cull_geometry call (u32 indices).
 enum : uint32_t {
