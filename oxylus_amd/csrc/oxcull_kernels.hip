@@ -697,6 +697,134 @@ OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Meshlet stage, plain variant (passes/cull_meshlets.slang:23-73): the configs[1] kernel.
+// Same decisions and outputs as meshlets_test_body<false,...>; organised around the two scarce
+// resources measured on gfx950: VALU issue slots and SGPRs.
+//  * Instance-constant operands reach the SGPRs by SCALAR loads (s_load_dwordx16 from the InstCache row
+//    through the constant address space): zero VALU instructions, where a vector load + v_readlane
+//    unpack costs one VALU slot per dword.
+//  * Two phases per instance round, so that the 42 frustum operands and the 26 cone operands are never
+//    live together (the one-phase kernel spills ~65 SGPRs to VGPR lanes and pays a v_readlane per use):
+//    phase 1 decodes the bounds and runs the packed frustum test for all G groups, phase 2 loads the cone
+//    operands and runs the cone test for the groups where a frustum survivor still needs it.
+//  * Per-lane state lives in VGPRs (plentiful: 512 per SIMD lane, the kernel needs < 128), not in lane masks.
+// ------------------------------------------------------------------------------------------
+typedef const uint32_t __attribute__((address_space(4))) * kconst32p;
+OXC_DEV kconst32p const_row(const InstCache* cache, uint32_t mi) { return (kconst32p)(reinterpret_cast<uint64_t>(cache + mi)); }
+
+template <int G>
+OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
+  set_half_denorm_flush();
+  constexpr int kWaves = 16 / G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
+  const uint32_t nwords = (N + 63u) / 64u;
+  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
+  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
+  const uint32_t last_index = N ? N - 1u : 0u;
+  const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
+
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // ---- stage A: all MeshletInstance loads of this wave (unconditional, clamped: see meshlets_test_body)
+    const uint32_t group0 = chunk * 16 + wave * G;
+    uint2 rec[G];
+    uint32_t st[G];  // bit 0: still to be decided, bit 1: visible
+#pragma unroll
+    for (int j = 0; j < G; j++) rec[j] = load_global_u2(mlis, min((group0 + j) * 64 + lane, last_index));
+#pragma unroll
+    for (int j = 0; j < G; j++) st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
+
+    for (;;) {
+      // leader = first undecided lane of the first group that has one (wave-uniform)
+      uint32_t mi_u = 0;
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t p = __builtin_amdgcn_ballot_w64((st[j] & 1u) != 0u);
+        if (!found && p) {
+          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)p) - 1);
+          found = true;
+        }
+      }
+      if (!found) break;
+      const kconst32p row = const_row(a.cache, mi_u);
+      const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
+      uint4 bnd[G];
+      bool mine[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
+        bnd[j] = load_global_u4(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
+      }
+      // ---- phase 1: bounds decode + frustum
+      float cx[G], cy[G], cz[G], ex[G], ey[G], ez[G];
+      uint32_t need[G];
+      uint64_t any_need = 0;
+      {
+        float pl[24], sg[18];
+#pragma unroll
+        for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+#pragma unroll
+        for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          const uint4 b = bnd[j];
+          cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
+          ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
+          const bool vis = mine[j] & test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j]);
+          // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
+          const bool nc = vis & (((int32_t)b.w >> 24) != 127);
+          need[j] = nc ? 1u : 0u;
+          any_need |= __builtin_amdgcn_ballot_w64(nc);
+          st[j] = mine[j] ? (vis ? 2u : 0u) : st[j];
+        }
+      }
+      // ---- phase 2: normal cone, only when some frustum survivor of this instance needs it
+      if (any_need) {
+        ConeU cu;
+#pragma unroll
+        for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
+        cu.scale_max = asf(row[kRowScale]);
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
+          const uint4 b = bnd[j];
+          const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
+          const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
+          const int tier1 = cone_visible_fast(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+          bool cone_ok = tier1 == 1;
+          if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
+            const bool exact = cone_visible(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+            cone_ok = tier1 == 2 ? exact : cone_ok;
+          }
+          st[j] = (need[j] != 0u && !cone_ok) ? 0u : st[j];
+        }
+      }
+    }
+    // ---- ballots + per-wave survivor count (see meshlets_test_body for the no-barrier publication)
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      if (group0 + j >= nwords) continue;  // wave-uniform
+      const uint64_t bits = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u);
+      if (lane == 0) gptr(a.bits)[group0 + j] = bits;
+      cnt += (uint32_t)__popcll((unsigned long long)bits);
+    }
+    if (lane == 0 && group0 < nwords) {
+      const uint32_t wchunk = chunk * kWaves + wave;  // counts are per 64*G meshlets
+      gptr(a.chunk_counts)[wchunk] = cnt;
+      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // VSM multi-view meshlet test (passes/cull_meshlets_hpb.slang:25-99): directional cone +
 // camera frustum, then "visible if ANY dirty clipmap view passes frustum + page-pyramid test".
 // The reference's `break` on the first visible view has no side effect, so the result is the OR
@@ -1270,7 +1398,10 @@ __global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) 
 // plain kernel 36.7 -> 38.8 us per 4M meshlets, HiZ variant 183 -> 175 us; not kept.)
 template <bool HIZ, bool OCCL, bool LATE, bool FUSED = false, int G = (int)kGroupsPerWave>
 __global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
-  meshlets_test_body<HIZ, OCCL, LATE, FUSED, G>(a);
+  if constexpr (!HIZ && !FUSED)
+    meshlets_plain_body<G>(a);
+  else
+    meshlets_test_body<HIZ, OCCL, LATE, FUSED, G>(a);
 }
 template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
@@ -1304,7 +1435,7 @@ __global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchBlob
 __global__ __launch_bounds__(1024) void k_scan_batch(const BatchBlob* __restrict__ dev) { scan_body(dev->scan[blockIdx.y]); }
 __global__ __launch_bounds__(256) void k_expand_batch(const BatchBlob* __restrict__ dev) { expand_body(dev->expand[blockIdx.y]); }
 __global__ __launch_bounds__(256) void k_cull_meshlets_test_batch(const BatchBlob* __restrict__ dev) {
-  meshlets_test_body<false, false, false, false, (int)kGroupsPerWave>(dev->test[blockIdx.y]);
+  meshlets_plain_body<(int)kGroupsPerWave>(dev->test[blockIdx.y]);
 }
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlob* __restrict__ dev) {
   meshlets_emit_body<false, false>(dev->emit[blockIdx.y]);
