@@ -102,7 +102,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint32_t Vw = std::max(views, L->cap_views);
   uint32_t M = std::max(std::max(mesh_instances, L->cap_mesh_instances), 1u);
   uint32_t N = std::max(std::max(meshlets, L->cap_meshlets), 1u);
-  const uint32_t m_chunks = cdiv(N, 128u), t_chunks = cdiv(N, kTriChunk);  // meshlet counts: per wave step, >= 128 meshlets
+  const uint32_t m_chunks = cdiv(N, 64u), t_chunks = cdiv(N, kTriChunk);  // meshlet counts: per wave step, >= 64 meshlets
   uint64_t off = 0;
   auto carve = [&](uint64_t bytes) {
     uint64_t o = off;
@@ -405,7 +405,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.meshlets_cmd = meshlets_cmd;
   pa.supers_meshlets = ctx->lane[0].m_supers;
   pa.supers_tris = ctx->lane[0].t_supers;
-  pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 128u), kChunksPerSuper);
+  pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
   pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
   pa.mesh_instance_count = M;
   pa.cull_flags = c->cull_flags;
@@ -524,7 +524,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       }
       MeshletEmitArgs ea;
       ea.n_host = n_host;
-      ea.count_meshlets = c->use_hiz ? 128u : 256u;  // one count per wave step: 64 * groups per wave
+      ea.count_meshlets = c->use_hiz ? 128u : 64u * kPlainGroups;  // one count per wave step: 64 * groups per wave
       ea.bits = ctx->lane[0].bits;
       ea.chunk_counts = ctx->lane[0].m_chunk_counts;
       ea.supers = ctx->lane[0].m_supers;
@@ -641,7 +641,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     pa.meshlets_cmd = meshlets_cmd;
     pa.supers_meshlets = L.m_supers;
     pa.supers_tris = L.t_supers;
-    pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 128u), kChunksPerSuper);
+    pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
     pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
     pa.mesh_instance_count = M;
     pa.cull_flags = c->cull_flags;
@@ -673,7 +673,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
 
     MeshletEmitArgs& ea = blob.emit[e];
     ea.n_host = n_host;
-    ea.count_meshlets = 256u;
+    ea.count_meshlets = 64u * kPlainGroups;
     ea.bits = L.bits;
     ea.chunk_counts = L.m_chunk_counts;
     ea.supers = L.m_supers;
@@ -721,7 +721,12 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   if (do_meshlets) {
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
-      launch_meshlets_test_batch(ctx->batch_dev, count, std::min(g_test, cap), s);
+      // OXC_TEST_GRID (experiment knob): blocks per batch element for the meshlet test kernel
+      static const uint32_t grid_env = [] {
+        const char* e = std::getenv("OXC_TEST_GRID");
+        return e ? (uint32_t)std::atoi(e) : 0u;
+      }();
+      launch_meshlets_test_batch(ctx->batch_dev, count, std::min(g_test, grid_env ? grid_env : cap), s);
     }
     KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
     launch_meshlets_emit_batch(ctx->batch_dev, count, std::min(g_emit, cap), s);

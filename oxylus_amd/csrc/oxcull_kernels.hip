@@ -747,7 +747,11 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         }
       }
       if (!found) break;
+#ifdef OXC_ABL_FIXEDROW  // timing experiment: the row address does not depend on the MeshletInstance load
+      const kconst32p row = const_row(a.cache, chunk & 255u);
+#else
       const kconst32p row = const_row(a.cache, mi_u);
+#endif
       const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
       uint4 bnd[G];
       bool mine[G];
@@ -780,6 +784,9 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         }
       }
       // ---- phase 2: normal cone, only when some frustum survivor of this instance needs it
+#ifdef OXC_ABL_NOCONE
+      any_need = 0;
+#endif
       if (any_need) {
         ConeU cu;
 #pragma unroll

@@ -87,6 +87,10 @@ enum : uint32_t {
 
 // Work decomposition constants (see DESIGN.md "ordered compaction").
 constexpr uint32_t kGroupsPerWave = 4;       // 64-meshlet groups each wave keeps in flight per block iteration
+#ifndef OXC_PLAIN_G
+#define OXC_PLAIN_G 4
+#endif
+constexpr uint32_t kPlainGroups = OXC_PLAIN_G;  // groups per wave of the plain (non-HiZ) test kernel; block = 16 / kPlainGroups waves
 constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block iteration of the test kernel
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
