@@ -832,6 +832,179 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Meshlet stage, HiZ variants (passes/cull_meshlets_hiz.slang:19-88), same organisation as
+// meshlets_plain_body plus a third phase: occlusion (mvp operands, project_aabb + HiZ fetch) for the
+// groups that still have a visible lane.  OCCL = TestOcclusion, LATE = LatePass.
+// ------------------------------------------------------------------------------------------
+template <bool OCCL, bool LATE, int G>
+OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
+  set_half_denorm_flush();
+  constexpr int kWaves = 16 / G;
+  constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
+  __shared__ uint32_t s_level_off[13];
+  __shared__ uint32_t s_lds_off[13];
+  __shared__ float s_hiz_top[kHizLdsTexels];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
+  const uint32_t nwords = (N + 63u) / 64u;
+  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
+  if (threadIdx.x < 13) {
+    s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
+    s_lds_off[threadIdx.x] = a.hiz_lds_off[threadIdx.x];
+  }
+  // stage the top of the pyramid (levels >= hiz_lds_first) once per block
+  for (uint32_t k = a.hiz_lds_first; k < a.hiz_levels; k++) {
+    const uint32_t n = mip_dim(a.hiz_w, k) * mip_dim(a.hiz_h, k);
+    const float* src = a.hiz_data + a.hiz_level_off[k];
+    float* dst = s_hiz_top + a.hiz_lds_off[k];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  HizView hiz;
+  hiz.data = a.hiz_data;
+  hiz.width = a.hiz_w;
+  hiz.height = a.hiz_h;
+  hiz.levels = a.hiz_levels;
+  hiz.lds = s_hiz_top;
+  hiz.lds_off = s_lds_off;
+  hiz.lds_first = a.hiz_lds_first;
+  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
+  const uint32_t last_index = N ? N - 1u : 0u;
+  const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
+
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint32_t group0 = chunk * 16 + wave * G;
+    uint2 rec[G];
+    uint32_t st[G];        // bit 0: still to be decided, bit 1: visible, bit 2: was_visible
+    uint32_t mask_idx[G];  // bit index into the persistent visibility mask
+#pragma unroll
+    for (int j = 0; j < G; j++) rec[j] = load_global_u2(mlis, min((group0 + j) * 64 + lane, last_index));
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
+      mask_idx[j] = 0;
+    }
+    for (;;) {
+      uint32_t mi_u = 0;
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t p = __builtin_amdgcn_ballot_w64((st[j] & 1u) != 0u);
+        if (!found && p) {
+          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)p) - 1);
+          found = true;
+        }
+      }
+      if (!found) break;
+      const kconst32p row = const_row(a.cache, mi_u);
+      const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
+      const uint32_t vis_offset = row[kRowVisOffset];
+      uint4 bnd[G];
+      bool mine[G];
+      uint32_t mword[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
+        bnd[j] = load_global_u4(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
+        mword[j] = 0xFFFFFFFFu;
+        if (OCCL) {  // cull_meshlets_hiz.slang:45-51 (unconditional load: lanes of other instances re-read this instance's first word)
+          const uint32_t mi_bit = vis_offset + (mine[j] ? rec[j].y : 0u);
+          mask_idx[j] = mine[j] ? mi_bit : mask_idx[j];
+          mword[j] = load_global_u32(reinterpret_cast<uint64_t>(a.mask), mi_bit >> 5) >> (mi_bit & 31u);
+        }
+      }
+      // ---- phase 1: bounds decode + frustum
+      float cx[G], cy[G], cz[G], ex[G], ey[G], ez[G];
+      uint32_t need[G];
+      uint64_t any_need = 0, any_vis = 0;
+      {
+        float pl[24], sg[18];
+#pragma unroll
+        for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+#pragma unroll
+        for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          const uint4 b = bnd[j];
+          cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
+          ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
+          const bool was_visible = (mword[j] & 1u) != 0u;
+          bool vis = mine[j] & (LATE ? true : was_visible);
+          vis = vis & test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j]);
+          const bool nc = vis & (((int32_t)b.w >> 24) != 127);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
+          need[j] = nc ? 1u : 0u;
+          any_need |= __builtin_amdgcn_ballot_w64(nc);
+          st[j] = mine[j] ? ((vis ? 2u : 0u) | (was_visible ? 4u : 0u)) : st[j];
+        }
+      }
+      // ---- phase 2: normal cone
+      if (any_need) {
+        ConeU cu;
+#pragma unroll
+        for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
+        cu.scale_max = asf(row[kRowScale]);
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
+          const uint4 b = bnd[j];
+          const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
+          const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
+          const int tier1 = cone_visible_fast(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+          bool cone_ok = tier1 == 1;
+          if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
+            const bool exact = cone_visible(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+            cone_ok = tier1 == 2 ? exact : cone_ok;
+          }
+          st[j] = (need[j] != 0u && !cone_ok) ? (st[j] & ~2u) : st[j];
+        }
+      }
+      // ---- phase 3: occlusion against the pyramid (cull_meshlets_hiz.slang:56-66)
+      if (OCCL_OR_LATE) {
+#pragma unroll
+        for (int j = 0; j < G; j++) any_vis |= __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
+        if (any_vis) {
+          float mvp[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) mvp[k] = asf(row[kRowMvp + k]);
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            const bool vis = mine[j] && (st[j] & 2u) != 0u;
+            if (__builtin_amdgcn_ballot_w64(vis) == 0) continue;  // wave-uniform
+            const bool occluded = aabb_occluded(mvp, a.near_clip, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], hiz, s_level_off, vis);
+            st[j] = (vis && occluded) ? (st[j] & ~2u) : st[j];
+          }
+        }
+      }
+    }
+    // ---- mask update, ballots, per-wave survivor count
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      if (group0 + j >= nwords) continue;  // wave-uniform
+      const bool visible = (st[j] & 2u) != 0u;
+      // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
+      // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
+      if (OCCL) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N, lane);
+      const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
+      const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
+      if (lane == 0) gptr(a.bits)[group0 + j] = bits;
+      cnt += (uint32_t)__popcll((unsigned long long)bits);
+    }
+    if (lane == 0 && group0 < nwords) {
+      const uint32_t wchunk = chunk * kWaves + wave;
+      gptr(a.chunk_counts)[wchunk] = cnt;
+      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // VSM multi-view meshlet test (passes/cull_meshlets_hpb.slang:25-99): directional cone +
 // camera frustum, then "visible if ANY dirty clipmap view passes frustum + page-pyramid test".
 // The reference's `break` on the first visible view has no side effect, so the result is the OR
@@ -1407,6 +1580,8 @@ template <bool HIZ, bool OCCL, bool LATE, bool FUSED = false, int G = (int)kGrou
 __global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
   if constexpr (!HIZ && !FUSED)
     meshlets_plain_body<G>(a);
+  else if constexpr (HIZ && !FUSED)
+    meshlets_hiz_body<OCCL, LATE, G>(a);
   else
     meshlets_test_body<HIZ, OCCL, LATE, FUSED, G>(a);
 }
