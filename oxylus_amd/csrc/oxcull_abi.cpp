@@ -524,7 +524,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       }
       MeshletEmitArgs ea;
       ea.n_host = n_host;
-      ea.count_meshlets = c->use_hiz ? 128u : 64u * kPlainGroups;  // one count per wave step: 64 * groups per wave
+      ea.count_meshlets = c->use_hiz ? 64u * kHizGroupsPerWave : 64u * kPlainGroups;  // one count per wave step: 64 * groups per wave
       ea.bits = ctx->lane[0].bits;
       ea.chunk_counts = ctx->lane[0].m_chunk_counts;
       ea.supers = ctx->lane[0].m_supers;

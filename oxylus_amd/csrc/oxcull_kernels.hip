@@ -844,6 +844,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   __shared__ uint32_t s_level_off[13];
   __shared__ uint32_t s_lds_off[13];
   __shared__ float s_hiz_top[kHizLdsTexels];
+  __shared__ uint4 s_strip[OCCL_OR_LATE ? kWaves : 1][G * 64];  // occlusion candidates of one round, per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
   const uint32_t nwords = (N + 63u) / 64u;
@@ -916,7 +917,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       // ---- phase 1: bounds decode + frustum
       float cx[G], cy[G], cz[G], ex[G], ey[G], ez[G];
       uint32_t need[G];
-      uint64_t any_need = 0, any_vis = 0;
+      uint64_t any_need = 0;
       {
         float pl[24], sg[18];
 #pragma unroll
@@ -964,21 +965,54 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
           st[j] = (need[j] != 0u && !cone_ok) ? (st[j] & ~2u) : st[j];
         }
       }
-      // ---- phase 3: occlusion against the pyramid (cull_meshlets_hiz.slang:56-66)
+      // ---- phase 3: occlusion against the pyramid (cull_meshlets_hiz.slang:56-66).  Only the survivors
+      // of phases 1-2 need it (typically 5-25 % of the lanes), and it is by far the longest piece of
+      // straight-line code (8 projected corners, 24 IEEE divisions), so the survivors of the round's G
+      // groups are first compacted into dense lanes through a per-wave LDS strip: the occlusion code
+      // then runs ceil(survivors / 64) times instead of once per group with mostly idle lanes.  All
+      // lanes of a round share the instance, hence the mvp operands.
       if (OCCL_OR_LATE) {
+        uint64_t vb[G];
+        uint32_t base[G + 1];
+        base[0] = 0;
 #pragma unroll
-        for (int j = 0; j < G; j++) any_vis |= __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
-        if (any_vis) {
+        for (int j = 0; j < G; j++) {
+          vb[j] = __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
+          base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)vb[j]);
+        }
+#ifdef OXC_ABL_NOOCCL
+        const uint32_t total = 0;
+#else
+        const uint32_t total = base[G];
+#endif
+        if (total) {
           float mvp[16];
 #pragma unroll
           for (int k = 0; k < 16; k++) mvp[k] = asf(row[kRowMvp + k]);
+          uint4* strip = s_strip[wave];
+          uint32_t slot[G];
 #pragma unroll
           for (int j = 0; j < G; j++) {
-            const bool vis = mine[j] && (st[j] & 2u) != 0u;
-            if (__builtin_amdgcn_ballot_w64(vis) == 0) continue;  // wave-uniform
-            const bool occluded = aabb_occluded(mvp, a.near_clip, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], hiz, s_level_off, vis);
-            st[j] = (vis && occluded) ? (st[j] & ~2u) : st[j];
+            slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb[j], 0u));
+            if ((vb[j] >> lane) & 1ull) strip[slot[j]] = bnd[j];
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
+          for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const bool act = t < total;
+            const uint4 b = strip[act ? t : total - 1u];
+            const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
+            const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
+            const bool occluded = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, act);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (act) strip[t].x = occluded ? 1u : 0u;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            if ((vb[j] >> lane) & 1ull) st[j] = strip[slot[j]].x ? (st[j] & ~2u) : st[j];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next round
         }
       }
     }
@@ -990,7 +1024,9 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       const bool visible = (st[j] & 2u) != 0u;
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
+#ifndef OXC_ABL_NOMASKUPDATE
       if (OCCL) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N, lane);
+#endif
       const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
       const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
       if (lane == 0) gptr(a.bits)[group0 + j] = bits;
@@ -1669,7 +1705,7 @@ void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid,
   hipLaunchKernelGGL(k_cull_triangles_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
 
-constexpr int kHizGroups = 2;  // occlusion variants: 2 groups per wave, 8-wave blocks (register pressure)
+constexpr int kHizGroups = (int)kHizGroupsPerWave;  // occlusion variants: 2 groups per wave, 8-wave blocks (register pressure)
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   if (!hiz) {

@@ -91,6 +91,10 @@ constexpr uint32_t kGroupsPerWave = 4;       // 64-meshlet groups each wave keep
 #define OXC_PLAIN_G 4
 #endif
 constexpr uint32_t kPlainGroups = OXC_PLAIN_G;  // groups per wave of the plain (non-HiZ) test kernel; block = 16 / kPlainGroups waves
+#ifndef OXC_HIZ_G
+#define OXC_HIZ_G 4
+#endif
+constexpr uint32_t kHizGroupsPerWave = OXC_HIZ_G;  // groups per wave of the HiZ test kernels
 constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block iteration of the test kernel
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
