@@ -192,6 +192,7 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       float sz = len3(OXC_M(w, 2, 0), OXC_M(w, 2, 1), OXC_M(w, 2, 2));
       out->scale_max = fmaxf(sx, fmaxf(sy, sz));
       out->vis_offset = inst.meshlet_instance_visibility_offset;
+      out->_pad0[0] = out->_pad0[1] = out->_pad0[2] = 0u;  // zero dwords: dummy index source for degenerate meshlets (tris_test_body)
 
       const GpuMeshLOD* lods = reinterpret_cast<const GpuMeshLOD*>(mesh.lods);
       uint32_t lod_index = inst.lod_index;
@@ -1345,6 +1346,158 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Triangle stage, test kernel, straight-line version.  Same decisions and outputs as
+// tris_test_body; what changed is how the 16 slots of a wave are sequenced:
+//  * the slot loop is fully unrolled and software-pipelined kIdxAhead / kPosAhead slots ahead, so a
+//    wave keeps the index dwords of kIdxAhead and the position gathers of kPosAhead meshlets in
+//    flight (bytes in flight are what bounds this gather-heavy kernel) and every wait is a counted
+//    vmcnt(N) instead of the vmcnt(0) a loop back-edge or an exec-masked load block forces;
+//  * no conditional loads: lanes beyond a meshlet's vertex / triangle count re-read its last element,
+//    slots beyond the visible count re-do the last visible slot (their result is dropped), and a
+//    meshlet with no vertices or triangles reads zero dwords of its own InstCache row;
+//  * projection_view * world comes from the InstCache row by scalar loads and feeds packed f32
+//    operations: clip = ((m0*x + m1*y) + m2*z) + m3 as two v_pk pairs (xy, zw), same roundings;
+//  * the 16 pass masks are collected in lanes 0..15 (v_writelane) and stored once.
+// ------------------------------------------------------------------------------------------
+template <bool LATE, bool WIDE>
+OXC_DEV void tris_test_body2(const TriTestArgs& a) {
+  set_half_denorm_flush();
+  constexpr int H = WIDE ? 2 : 1;
+  constexpr int S = 16;  // slots per wave per chunk
+#ifndef OXC_TRI_IDX_AHEAD
+#define OXC_TRI_IDX_AHEAD 2  // measured on config 3 (us per launch): 2/1 -> 123, 3/2 -> 125 (SGPR spills), 6 waves/SIMD with 3/2 or 4/3 -> 139-143; the loop version: 160
+#define OXC_TRI_POS_AHEAD 1
+#endif
+  constexpr int kPosAhead = OXC_TRI_POS_AHEAD;  // position gathers (need the vertex ids) run this many slots ahead of the decision
+  constexpr int kIdxAhead = OXC_TRI_IDX_AHEAD;  // vertex / micro index loads
+  constexpr int kRecAhead = kIdxAhead + 1;      // scalar: Meshlet record
+  constexpr int kRowAhead = kIdxAhead + 2;      // scalar: LOD pointers out of the InstCache row
+  typedef const uint32_t __attribute__((address_space(4))) * k32;
+  __shared__ uint32_t s_red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t V = a.tri_cmd[0];
+  const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
+  const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // ---- lanes 0..15 fetch the MeshletInstance of this wave's 16 slots; everything that is uniform per
+    // slot from there on (LOD pointers, Meshlet record, mvp) travels through scalar loads into SGPRs
+    uint2 h_rec;
+    {
+      const uint32_t slot = min(chunk * kTriChunk + (uint32_t)(lane & 15) * 4 + wave, V - 1u);
+      const uint32_t mli = a.visible[first + slot];
+      h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
+    }
+    uint32_t s_mi[S];
+    uint64_t s_meshlets[S], s_micro[S], s_vidx[S], s_pos[S];
+    uint32_t s_vbase[S], s_tbase[S], s_vmax[S], s_tcount[S];
+    uint32_t vid[S], d0[S][H], d1[S][H];
+    uint2 q[S];
+    auto stage_row = [&](int j) {
+      s_mi[j] = readlane_u(h_rec.x, j);
+      const kconst32p row = const_row(a.cache, s_mi[j]);
+      s_meshlets[j] = (uint64_t)row[kRowBounds + 2] | ((uint64_t)row[kRowBounds + 3] << 32);
+      s_micro[j] = (uint64_t)row[kRowBounds + 4] | ((uint64_t)row[kRowBounds + 5] << 32);
+      s_vidx[j] = (uint64_t)row[kRowBounds + 6] | ((uint64_t)row[kRowBounds + 7] << 32);
+      s_pos[j] = (uint64_t)row[kRowBounds + 8] | ((uint64_t)row[kRowBounds + 9] << 32);
+    };
+    auto stage_rec = [&](int j) {  // Meshlet {vertex_offset, tri_offset(bytes), vertex_count, tri_count} (SceneGPU.hpp, 16 B)
+      const k32 m = (k32)(s_meshlets[j] + (uint64_t)readlane_u(h_rec.y, j) * 16u);
+      const uint32_t vcount = min(m[2], 64u);  // one lane per vertex / triangle (defines.slang:9-23)
+      const uint32_t tcount = min(m[3], 64u * (uint32_t)H);
+      const bool empty = vcount == 0u || tcount == 0u;  // nothing to test: read the zero dwords of the row instead of the mesh
+      const uint64_t zeros = reinterpret_cast<uint64_t>(a.cache + s_mi[j]) + kRowScale * 4 + 4;
+      s_vbase[j] = empty ? 0u : m[0];
+      s_tbase[j] = empty ? 0u : m[1];
+      s_vmax[j] = max(vcount, 1u) - 1u;
+      s_tcount[j] = empty ? 0u : tcount;
+      s_micro[j] = empty ? zeros : s_micro[j];
+      s_vidx[j] = empty ? zeros : s_vidx[j];
+      s_pos[j] = empty ? reinterpret_cast<uint64_t>(a.cache + s_mi[j]) : s_pos[j];
+    };
+    auto stage_idx = [&](int j) {
+      vid[j] = load_global_u32(s_vidx[j], s_vbase[j] + min((uint32_t)lane, s_vmax[j]));
+      const uint32_t tmax = max(s_tcount[j], 1u) - 1u;
+#pragma unroll
+      for (int h = 0; h < H; h++) {  // scene.slang:336-342,365-372 via aligned dword loads
+        const uint32_t boff = s_tbase[j] + min((uint32_t)lane + 64u * (uint32_t)h, tmax) * 3u;
+        d0[j][h] = load_global_u32(s_micro[j], boff >> 2);
+        d1[j][h] = load_global_u32(s_micro[j], (boff + 2u) >> 2);
+      }
+    };
+    auto stage_pos = [&](int j) { q[j] = load_global_u2(s_pos[j], vid[j]); };  // u16x4, stride 8
+#pragma unroll
+    for (int j = 0; j < kRowAhead; j++) stage_row(j);
+#pragma unroll
+    for (int j = 0; j < kRecAhead; j++) stage_rec(j);
+#pragma unroll
+    for (int j = 0; j < kIdxAhead; j++) stage_idx(j);
+#pragma unroll
+    for (int j = 0; j < kPosAhead; j++) stage_pos(j);
+    uint32_t cnt = 0;
+    uint32_t mlo[H], mhi[H];  // lane j: pass mask(s) of slot j
+#pragma unroll
+    for (int h = 0; h < H; h++) mlo[h] = mhi[h] = 0;
+#pragma unroll
+    for (int j = 0; j < S; j++) {
+      if (j + kRowAhead < S) stage_row(j + kRowAhead);
+      if (j + kRecAhead < S) stage_rec(j + kRecAhead);
+      if (j + kIdxAhead < S) stage_idx(j + kIdxAhead);
+      if (j + kPosAhead < S) stage_pos(j + kPosAhead);
+      const bool valid = chunk * kTriChunk + (uint32_t)j * 4 + wave < V;  // wave-uniform
+      const uint32_t vertex_count = s_vmax[j] + 1u;  // (>= 1; the lanes of an empty meshlet are masked by tri_count == 0)
+      const uint32_t tri_count = s_tcount[j];
+      const kconst32p row = const_row(a.cache, s_mi[j]);
+      f2 m_xy[4], m_zw[4];  // column c of projection_view * world: rows (0,1) and (2,3)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        m_xy[c] = f2{asf(row[kRowMvp + c * 4 + 0]), asf(row[kRowMvp + c * 4 + 1])};
+        m_zw[c] = f2{asf(row[kRowMvp + c * 4 + 2]), asf(row[kRowMvp + c * 4 + 3])};
+      }
+      // vertex phase: lane = vertex
+      const float px = dequantize_half(q[j].x & 0xFFFFu), py = dequantize_half(q[j].x >> 16), pz = dequantize_half(q[j].y & 0xFFFFu);
+      const f2 cxy = ((m_xy[0] * splat(px) + m_xy[1] * splat(py)) + m_xy[2] * splat(pz)) + m_xy[3];
+      const f2 czw = ((m_zw[0] * splat(px) + m_zw[1] * splat(py)) + m_zw[2] * splat(pz)) + m_zw[3];
+      const float clx = cxy.x, cly = cxy.y, clw = czw.y;
+      const uint64_t zok = __builtin_amdgcn_ballot_w64((uint32_t)lane < vertex_count && czw.x >= 0.0f);
+      // triangle phase: lane = triangle (two passes of 64 when WIDE)
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const uint32_t t = (uint32_t)lane + 64u * (uint32_t)h;
+        const uint32_t tl = min(t, max(tri_count, 1u) - 1u);
+        const uint32_t tri = __builtin_amdgcn_alignbyte(d1[j][h], d0[j][h], (s_tbase[j] + tl * 3u) & 3u);
+        const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
+        const float ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
+        const float bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
+        const float cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
+        const bool z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
+        // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
+        const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
+        const bool passed = t < tri_count && z_all && !(det >= 0.0001f);
+        const uint64_t mask = valid ? __builtin_amdgcn_ballot_w64(passed) : 0ull;
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mlo[h]) : "s"(readfirst_u((uint32_t)mask)), "n"(j));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mhi[h]) : "s"(readfirst_u((uint32_t)(mask >> 32))), "n"(j));
+        cnt += (uint32_t)__popcll((unsigned long long)mask);
+      }
+    }
+    {
+      const uint32_t slot = chunk * kTriChunk + (uint32_t)lane * 4 + wave;
+      if (lane < S && slot < V) {
+#pragma unroll
+        for (int h = 0; h < H; h++) a.tri_masks[(size_t)slot * H + h] = (uint64_t)mlo[h] | ((uint64_t)mhi[h] << 32);
+      }
+    }
+    __syncthreads();
+    if (lane == 0) s_red[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      a.chunk_counts[chunk] = c;
+      if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Triangle stage, emit kernel: ordered expansion of the pass masks into packed indices
 // (visbuffer.slang:13-14, cull_triangles.slang:82-88) and DrawIndexedIndirect.index_count.
 // ------------------------------------------------------------------------------------------
@@ -1625,9 +1778,16 @@ template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
   meshlets_emit_body<HIZ, LATE>(a);
 }
+#ifndef OXC_TRI_WAVES
+#define OXC_TRI_WAVES 8
+#endif
 template <bool LATE, bool WIDE>
-__global__ __launch_bounds__(256, WIDE ? 6 : 8) void k_cull_triangles_test(TriTestArgs a) {
+__global__ __launch_bounds__(256, WIDE ? 6 : OXC_TRI_WAVES) void k_cull_triangles_test(TriTestArgs a) {
+#ifdef OXC_TRIS_V1
   tris_test_body<LATE, WIDE>(a);
+#else
+  tris_test_body2<LATE, WIDE>(a);
+#endif
 }
 template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
@@ -1659,7 +1819,11 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlo
   meshlets_emit_body<false, false>(dev->emit[blockIdx.y]);
 }
 __global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchBlob* __restrict__ dev) {
+#ifdef OXC_TRIS_V1
   tris_test_body<false, false>(dev->ttest[blockIdx.y]);
+#else
+  tris_test_body2<false, false>(dev->ttest[blockIdx.y]);
+#endif
 }
 __global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchBlob* __restrict__ dev) {
   tris_emit_body<false, false>(dev->temit[blockIdx.y]);
