@@ -361,14 +361,15 @@ def main():
     probe = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
     probe.random_(0, 255)
     with torch.cuda.stream(stream):
-        r.stream_read_probe(probe, stream)
+        for _ in range(30):  # the memory clock needs tens of ms of sustained streaming before the rate settles
+            r.stream_read_probe(probe, stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for _ in range(5):
+        for _ in range(30):
             r.stream_read_probe(probe, stream)
         e1.record(stream)
     torch.cuda.synchronize()
-    stream_read_gbps = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    stream_read_gbps = 30 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del probe
 
     # ---- roofline of the dominant kernel ----
