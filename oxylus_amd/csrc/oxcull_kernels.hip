@@ -716,18 +716,19 @@ OXC_DEV kconst32p const_row(const InstCache* cache, uint32_t mi) { return (kcons
 template <int G>
 OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
   set_half_denorm_flush();
-  constexpr int kWaves = 16 / G;
+  constexpr uint32_t kWaves = kPlainBlockWaves;
+  constexpr uint32_t kStep = kWaves * G * 64;  // meshlets per block iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
   const uint32_t nwords = (N + 63u) / 64u;
-  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
+  const uint32_t nchunks = (N + kStep - 1) / kStep;
   const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
   const uint32_t last_index = N ? N - 1u : 0u;
   const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     // ---- stage A: all MeshletInstance loads of this wave (unconditional, clamped: see meshlets_test_body)
-    const uint32_t group0 = chunk * 16 + wave * G;
+    const uint32_t group0 = (chunk * kWaves + wave) * G;
     uint2 rec[G];
     uint32_t st[G];  // bit 0: still to be decided, bit 1: visible
 #pragma unroll
@@ -1812,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchBlob
 }
 __global__ __launch_bounds__(1024) void k_scan_batch(const BatchBlob* __restrict__ dev) { scan_body(dev->scan[blockIdx.y]); }
 __global__ __launch_bounds__(256) void k_expand_batch(const BatchBlob* __restrict__ dev) { expand_body(dev->expand[blockIdx.y]); }
-__global__ __launch_bounds__(256) void k_cull_meshlets_test_batch(const BatchBlob* __restrict__ dev) {
+__global__ __launch_bounds__(64 * kPlainBlockWaves) void k_cull_meshlets_test_batch(const BatchBlob* __restrict__ dev) {
   meshlets_plain_body<(int)kGroupsPerWave>(dev->test[blockIdx.y]);
 }
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlob* __restrict__ dev) {
@@ -1857,7 +1858,7 @@ void launch_meshlets_test_batch(const BatchBlob* dev, uint32_t count, uint32_t g
     const char* e = std::getenv("OXC_LDS_PAD");
     return e ? (uint32_t)std::atoi(e) : 0u;
   }();
-  hipLaunchKernelGGL(k_cull_meshlets_test_batch, dim3(grid, count), dim3(256), lds_pad, s, dev);
+  hipLaunchKernelGGL(k_cull_meshlets_test_batch, dim3(grid * (4 / kPlainBlockWaves), count), dim3(64 * kPlainBlockWaves), lds_pad, s, dev);
 }
 void launch_meshlets_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_cull_meshlets_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
@@ -1873,7 +1874,7 @@ constexpr int kHizGroups = (int)kHizGroupsPerWave;  // occlusion variants: 2 gro
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   if (!hiz) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), g, b, 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
   } else if (occl && late) {
     hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else if (occl) {

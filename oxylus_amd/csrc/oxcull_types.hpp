@@ -95,6 +95,10 @@ constexpr uint32_t kPlainGroups = OXC_PLAIN_G;  // groups per wave of the plain 
 #define OXC_HIZ_G 4
 #endif
 constexpr uint32_t kHizGroupsPerWave = OXC_HIZ_G;  // groups per wave of the HiZ test kernels
+#ifndef OXC_PLAIN_BLOCK_WAVES
+#define OXC_PLAIN_BLOCK_WAVES 4
+#endif
+constexpr uint32_t kPlainBlockWaves = OXC_PLAIN_BLOCK_WAVES;  // the plain test kernel's waves are independent: block size is a scheduling knob
 constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block iteration of the test kernel
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
