@@ -1870,9 +1870,9 @@ void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid,
   hipLaunchKernelGGL(k_cull_triangles_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
 
-constexpr int kHizGroups = (int)kHizGroupsPerWave;  // occlusion variants: 2 groups per wave, 8-wave blocks (register pressure)
+constexpr int kHizGroups = (int)kHizGroupsPerWave;  // groups per wave of the HiZ variants (block = 16 / kHizGroups waves)
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s) {
-  dim3 g(grid), b(256);
+  dim3 g(grid);
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
   } else if (occl && late) {
