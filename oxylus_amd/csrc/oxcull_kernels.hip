@@ -1409,7 +1409,7 @@ OXC_DEV void tris_test_body2(const TriTestArgs& a) {
       const uint64_t zeros = reinterpret_cast<uint64_t>(a.cache + s_mi[j]) + kRowScale * 4 + 4;
       s_vbase[j] = empty ? 0u : m[0];
       s_tbase[j] = empty ? 0u : m[1];
-      s_vmax[j] = max(vcount, 1u) - 1u;
+      s_vmax[j] = empty ? 0u : vcount - 1u;  // an empty meshlet reads one zero dword (vertex id 0) and the row's first 8 bytes
       s_tcount[j] = empty ? 0u : tcount;
       s_micro[j] = empty ? zeros : s_micro[j];
       s_vidx[j] = empty ? zeros : s_vidx[j];

@@ -443,3 +443,32 @@ def test_wide_triangle_index_extension(renderer, oracle_lib, spec):
     got = frame.reordered_indices_buffer[: c.draw_index_count].cpu()
     assert torch.equal(got, want_idx)
     assert int((got & 0x1FF).max()) > 255  # corners beyond the reference's 8-bit field are actually used
+
+
+def test_triangle_stage_empty_and_oversized_meshlets(renderer, oracle_lib):
+    """Meshlets with triangle_count == 0 emit nothing and must not make the straight-line triangle kernel read the
+    mesh through their (possibly dangling) offsets; triangle_count > 64 is cut to the kernel's 64 threads
+    (defines.slang:9-11, cull_triangles.slang:44).  Also an all-empty visible set and a visible count that is not a
+    multiple of the 64-slot block."""
+    spec = SceneSpec(n_mesh_instances=9, meshlets_per_mesh=75, seed=321)
+    cpu = make_scene(spec, "cpu")
+    g = torch.Generator().manual_seed(5)
+    r = torch.rand(cpu.meshlets.shape[0], generator=g)
+    cpu.meshlets[r < 0.2, 3] = 0
+    cpu.meshlets[(r >= 0.2) & (r < 0.3), 3] = 200
+    # a dangling offset on an empty meshlet: nothing may be read through it
+    empty = torch.nonzero(r < 0.2).flatten()
+    cpu.meshlets[empty[0], 0] = 0x3FFFFFFF
+    cpu.meshlets[empty[0], 1] = 0x3FFFFFFC
+    gpu = cpu.to("cuda")
+    want = oracle_frame(cpu)
+    got = gpu_frame(renderer, gpu)
+    assert_same(want, got, ["total", "visible", "indices"])
+    assert len(want["indices"]) > 0
+    # every meshlet empty
+    cpu.meshlets[:, 3] = 0
+    gpu = cpu.to("cuda")
+    want = oracle_frame(cpu)
+    got = gpu_frame(renderer, gpu)
+    assert_same(want, got, ["total", "visible", "indices"])
+    assert len(want["indices"]) == 0 and len(want["visible"]) > 0
