@@ -51,17 +51,9 @@ struct oxc_ctx {
     uint64_t* tri_masks = nullptr;
     uint32_t* t_chunk_counts = nullptr;
     uint32_t* t_supers = nullptr;
-    // fused-emit hand-off state (zeroed at allocation; self-resetting afterwards)
-    uint64_t* chunk_gran = nullptr;
-    uint64_t* super_gran = nullptr;
-    uint32_t* super_arrive = nullptr;
-    uint32_t* super_done = nullptr;
-    uint32_t* fsync = nullptr;
   };
   Lane lane[kMaxBatch];
   BatchBlob* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call
-  uint32_t ablate = 0;      // OXC_ABLATE: timing experiments only, results are wrong when set
-  bool fused_emit = false;  // experiment, off by default: measured 38 us/step vs 26 us/step unfused
   // counter slots
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
@@ -119,12 +111,6 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
-  const uint64_t o_sync0 = off;
-  const uint64_t o_cgran = carve((uint64_t)m_chunks * 8);
-  const uint64_t o_sgran = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 8);
-  const uint64_t o_sarr = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
-  const uint64_t o_sdone = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4);
-  const uint64_t o_fsync = carve(64);
   OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old arena
   if (L->arena) OXC_HIP(ctx, hipFree(L->arena));
   L->arena = nullptr;
@@ -146,12 +132,6 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
   L->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
-  L->chunk_gran = reinterpret_cast<uint64_t*>(b + o_cgran);
-  L->super_gran = reinterpret_cast<uint64_t*>(b + o_sgran);
-  L->super_arrive = reinterpret_cast<uint32_t*>(b + o_sarr);
-  L->super_done = reinterpret_cast<uint32_t*>(b + o_sdone);
-  L->fsync = reinterpret_cast<uint32_t*>(b + o_fsync);
-  OXC_HIP(ctx, hipMemset(b + o_sync0, 0, off - o_sync0));
   L->cap_mesh_instances = M;
   L->cap_meshlets = N;
   return OXC_OK;
@@ -282,8 +262,6 @@ oxc_status oxc_create(int device, oxc_ctx** out) {
   }
   (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
   ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
-  if (const char* e = std::getenv("OXC_FUSED_EMIT")) ctx->fused_emit = e[0] != '0';
-  if (const char* e = std::getenv("OXC_ABLATE")) ctx->ablate = (uint32_t)std::atoi(e);
   *out = ctx;
   return OXC_OK;
 }
@@ -470,7 +448,6 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   } else if (do_meshlets) {
     MeshletTestArgs ta;
     std::memset(&ta, 0, sizeof ta);
-    ta.ablate = ctx->ablate;
     ta.n_host = n_host;
     ta.cache = ctx->lane[0].cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
@@ -503,21 +480,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
-    // Experimental single-launch variant (ordered emit fused into the test kernel, OXC_FUSED_EMIT=1): needs the
-    // list length on the host, one chunk per block within the resident grid, and the plain pipeline.
-    const uint32_t exact_chunks = n_host ? cdiv(n_host, kMeshletChunk) : 0u;
-    const bool fused = ctx->fused_emit && !c->use_hiz && n_host != 0 && exact_chunks <= ctx->num_cus * 4u;
-    if (fused) {
-      ta.chunk_gran = ctx->lane[0].chunk_gran;
-      ta.super_gran = ctx->lane[0].super_gran;
-      ta.super_arrive = ctx->lane[0].super_arrive;
-      ta.super_done = ctx->lane[0].super_done;
-      ta.sync = ctx->lane[0].fsync;
-      ta.tri_cmd = tri_cmd;
-      ta.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
-      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
-      launch_meshlets_fused(ta, exact_chunks, s);
-    } else {
+    {
       {
         KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
         launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
@@ -658,7 +621,6 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     g_expand = std::max(g_expand, std::max(std::min(cdiv(M, 4), max_grid), 1u));
 
     MeshletTestArgs& ta = blob.test[e];
-    ta.ablate = ctx->ablate;
     ta.n_host = n_host;
     ta.cache = L.cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
@@ -753,13 +715,7 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   if (c->cull_meshlets_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(mc, c->cull_meshlets_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
   if (c->cull_triangles_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(tc, c->cull_triangles_cmd_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
   if (c->draw_geometry_cmd_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(dc, c->draw_geometry_cmd_buffer.dptr, 20, hipMemcpyDeviceToHost, s));
-  uint32_t ferr = 0;
-  if (ctx->lane[0].fsync) OXC_HIP(ctx, hipMemcpyAsync(&ferr, ctx->lane[0].fsync + 2, 4, hipMemcpyDeviceToHost, s));
   OXC_HIP(ctx, hipStreamSynchronize(s));
-  if (ferr) {
-    (void)hipMemset(ctx->lane[0].chunk_gran, 0, reinterpret_cast<char*>(ctx->lane[0].fsync) + 64 - reinterpret_cast<char*>(ctx->lane[0].chunk_gran));
-    return fail(ctx, OXC_HIP_ERROR, "in-kernel hand-off of the fused meshlet emit timed out (state reset)");
-  }
   out->total_visible_meshlet_instances = vis[0];
   out->early_visible_meshlet_instances = vis[1];
   out->late_visible_meshlet_instances = vis[2];

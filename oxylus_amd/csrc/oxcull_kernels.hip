@@ -295,54 +295,11 @@ OXC_DEV void expand_body(const ExpandArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Meshlet stage, test kernel.  passes/cull_meshlets.slang:23-73 (HIZ=false) and
-// passes/cull_meshlets_hiz.slang:19-88 (HIZ=true).
-// One lane per meshlet instance, 64 consecutive instances per wave step.  Instance-constant
-// data comes from the InstCache into SGPRs (one coalesced wave load + v_readlane), so the VALU
-// only touches per-meshlet values.  A wave whose 64 meshlets span several mesh instances runs
-// the body once per distinct instance under the exec mask.
+// Meshlet stage, test kernels.  passes/cull_meshlets.slang:23-73 (plain) and
+// passes/cull_meshlets_hiz.slang:19-88 (HiZ variants).
+// One lane per meshlet instance, 64 consecutive instances per group, G groups per wave step.
+// A wave whose meshlets span several mesh instances runs one round per distinct instance.
 // ------------------------------------------------------------------------------------------
-// Wave-uniform instance data.  Only what every wave needs is unpacked into SGPRs eagerly (the six
-// planes, the bounds pointer, the mask offset); the cone data (world rows, normal matrix, scale) and
-// mvp are pulled out of the still-resident row dwords `v0` inside the wave-uniform branches that use
-// them.  Fewer live SGPRs = more resident waves (the kernel's throughput is residency / chain latency).
-struct InstU {
-  float pl[24];  // planes2
-  float sg[18];  // signs2
-  uint32_t vis_offset;
-  uint64_t bounds;
-  uint32_t v0, v1;  // VGPRs: dword `lane` / dword 64 + (lane & 31) of the InstCache row
-};
-OXC_DEV void unpack_cone(uint32_t v0, uint32_t v1, ConeU& c) {
-#pragma unroll
-  for (int k = 0; k < 9; k++) c.nm[k] = readlane_f(v1, kRowNm - 64 + k);
-#pragma unroll
-  for (int k = 0; k < 6; k++) c.w2[k >> 1][k & 1] = readlane_f(v1, kRowWorld2 - 64 + k);
-#pragma unroll
-  for (int k = 0; k < 2; k++) c.wt2[k] = readlane_f(v1, kRowWorldT2 - 64 + k);
-#pragma unroll
-  for (int k = 0; k < 4; k++) c.wr2[k] = readlane_f(v1, kRowWorldR2 - 64 + k);
-  c.scale_max = readlane_f(v0, kRowScale);
-}
-OXC_DEV void unpack_mvp(uint32_t v0, float* mvp) {
-#pragma unroll
-  for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, kRowMvp + k);
-}
-
-OXC_DEV void load_inst_uniform(const InstCache* __restrict__ cache, uint32_t mi, int lane, InstU& u) {
-  const uint64_t p = reinterpret_cast<uint64_t>(cache + mi);
-  uint32_t v0 = load_global_u32(p, lane);
-  uint32_t v1 = load_global_u32(p, 64 + (lane & 31));
-#pragma unroll
-  for (int k = 0; k < 24; k++) u.pl[k] = readlane_f(v0, kRowPlanes + k);
-#pragma unroll
-  for (int k = 0; k < 18; k++) u.sg[k] = readlane_f(v0, kRowSigns + k);
-  u.vis_offset = readlane_u(v0, kRowVisOffset);
-  u.bounds = (uint64_t)readlane_u(v1, kRowBounds - 64) | ((uint64_t)readlane_u(v1, kRowBounds - 64 + 1) << 32);
-  u.v0 = v0;
-  u.v1 = v1;
-}
-
 // Set/clear bits of the persistent visibility mask for the lanes in `active`.
 // Lanes whose (idx - lane) agree form a "run": lane l owns global bit (d + l), so a run is a
 // 64-bit window at bit offset d and touches at most three mask words.  Whole words are stored,
@@ -379,328 +336,9 @@ OXC_DEV void update_visibility_mask(uint32_t* __restrict__ mask, uint32_t idx, b
   }
 }
 
-struct LaneResult {
-  bool emit;
-  bool visible;
-  uint32_t mask_idx;
-};
-
-// The per-meshlet decision for the lanes in `mine` (all of the same mesh instance `u`).
-// Frustum first (cheap, rejects most), cone only when some lane of the wave still needs it:
-// visible = cone && frustum is order-independent, so the skip changes no result.
-template <bool HIZ, bool OCCL, bool LATE>
-OXC_DEV void eval_meshlets(const MeshletTestArgs& a, const InstU& u, ConeU& cu, bool& cone_ready, const uint4 b, uint32_t meshlet_index,
-                           bool mine, const HizView& hiz, const uint32_t* s_level_off, LaneResult& out) {
-  constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
-  const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16);
-  const float cz = dequantize_half(b.y & 0xFFFFu);
-  const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16);
-  const float ez = dequantize_half(b.w & 0xFFFFu);
-  uint32_t mask_idx = 0;
-  bool was_visible = true;
-  if (HIZ && OCCL && mine) {  // cull_meshlets_hiz.slang:45-51
-    mask_idx = u.vis_offset + meshlet_index;
-    was_visible = ((a.mask[mask_idx >> 5] >> (mask_idx & 31u)) & 1u) != 0u;
-  }
-  bool visible = mine && ((HIZ && !LATE) ? was_visible : true);
-  // straight-line six-plane test: per-plane wave-level early-outs were measured 3 % slower (the kernel is
-  // issue-bound; 24 extra branches per wave step cost more than the skipped planes save)
-  if (!(a.ablate & 2u)) visible = visible & test_frustum_planes(u.pl, u.sg, cx, cy, cz, ex, ey, ez);
-  const int32_t cutoff_s8 = (int32_t)b.w >> 24;
-  const bool need_cone = visible && cutoff_s8 != 127 && !(a.ablate & 1u);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
-  if (__any(need_cone)) {
-    const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
-    const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, cutoff_s8);
-    const float ax = axy.x, ay = axy.y, az = azc.x, cutoff = azc.y;
-    if (!cone_ready) {  // once per instance round, not per 64-meshlet group (wave-uniform)
-      unpack_cone(u.v0, u.v1, cu);
-      cone_ready = true;
-    }
-    int tier1 = cone_visible_fast(cu, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az, cutoff);
-    bool cone_ok = tier1 == 1;
-    if (__any(need_cone && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-      const bool exact = cone_visible(cu, a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], cx, cy, cz, ex, ey, ez, ax, ay, az, cutoff);
-      cone_ok = tier1 == 2 ? exact : cone_ok;
-    }
-    visible = visible && (!need_cone || cone_ok);
-  }
-  if (HIZ && OCCL_OR_LATE && !(a.ablate & 64u)) {
-    if (__any(visible)) {
-      float mvp[16];
-      unpack_mvp(u.v0, mvp);
-      const bool occluded = aabb_occluded(mvp, a.near_clip, cx, cy, cz, ex, ey, ez, hiz, s_level_off, visible);
-      visible = visible && !occluded;
-    }
-  }
-  if (mine) {
-    out.emit = HIZ ? (visible && (!LATE || !was_visible)) : visible;
-    out.visible = visible;
-    out.mask_idx = mask_idx;
-  }
-}
-
-// ---- in-kernel hand-off helpers (MI355X: per-XCD L2s are not coherent; every shared word is an
-// agent-scope atomic access = global_load/store ... sc1, never a plain access) ----
-typedef unsigned long long __attribute__((address_space(1))) * gu64p;
-typedef unsigned int __attribute__((address_space(1))) * gu32p;
-OXC_DEV void st_gran(uint64_t* p, uint32_t epoch, uint32_t value) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-OXC_DEV uint64_t ld_gran(const uint64_t* p) {
-  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-constexpr uint32_t kMaxSpins = 1u << 20;  // bounded: a broken hand-off sets sync[2] instead of hanging the GPU
-
-// G = 64-meshlet groups per wave per chunk; the block has 16/G waves so a chunk is always 1024 meshlets.
-template <bool HIZ, bool OCCL, bool LATE, bool FUSED, int G>
-OXC_DEV void meshlets_test_body(const MeshletTestArgs& a) {
-  set_half_denorm_flush();
-  constexpr int kWaves = 16 / G;
-  __shared__ uint32_t s_red[kWaves];
-  __shared__ uint32_t s_fused[4];  // [0] epoch, [1] base, [2] last-arriver flag
-  __shared__ uint32_t s_level_off[13];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
-  const uint32_t nwords = (N + 63u) / 64u;
-  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
-  __shared__ uint32_t s_lds_off[13];
-  __shared__ float s_hiz_top[HIZ ? kHizLdsTexels : 1];
-  if (HIZ) {
-    if (threadIdx.x < 13) {
-      s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
-      s_lds_off[threadIdx.x] = a.hiz_lds_off[threadIdx.x];
-    }
-    // stage the top of the pyramid (levels >= hiz_lds_first) once per block
-    for (uint32_t k = a.hiz_lds_first; k < a.hiz_levels; k++) {
-      const uint32_t n = mip_dim(a.hiz_w, k) * mip_dim(a.hiz_h, k);
-      const float* src = a.hiz_data + a.hiz_level_off[k];
-      float* dst = s_hiz_top + a.hiz_lds_off[k];
-      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-  }
-  HizView hiz;
-  hiz.data = a.hiz_data;
-  hiz.width = a.hiz_w;
-  hiz.height = a.hiz_h;
-  hiz.levels = a.hiz_levels;
-  hiz.lds = s_hiz_top;
-  hiz.lds_off = s_lds_off;
-  hiz.lds_first = HIZ ? a.hiz_lds_first : 0u;
-  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
-  const uint32_t last_index = N ? N - 1u : 0u;
-  if (FUSED && threadIdx.x == 0) {
-    s_fused[0] = __hip_atomic_load(&a.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;  // this launch's epoch (never 0)
-  }
-
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // ---- stage A: all MeshletInstance loads of this wave (G consecutive 64-meshlet groups)
-    uint32_t group[G], idx[G];
-    bool in[G];
-    uint2 rec[G];
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      group[j] = chunk * 16 + wave * G + j;
-      idx[j] = group[j] * 64 + lane;
-      in[j] = idx[j] < N;
-      // unconditional load at a clamped index: a `cond ? load : x` is lowered to an exec-masked block
-      // with s_waitcnt vmcnt(0) inside, which serialises the G loads (one HBM round trip each)
-      rec[j] = load_global_u2(mlis, min(idx[j], last_index));
-    }
-#pragma unroll
-    for (int j = 0; j < G; j++)
-      if (!in[j]) rec[j] = make_uint2(0xFFFFFFFFu, 0u);
-    // ---- stages B-D: one round per distinct mesh instance among the wave's G*64 meshlets
-    // (usually one; two when the wave straddles an instance boundary).  Per round: cache row ->
-    // SGPRs, all bounds loads of the round issued together, then the decisions.
-    LaneResult res[G];
-    uint64_t pending[G];
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      res[j].emit = false;
-      res[j].visible = false;
-      res[j].mask_idx = 0;
-      pending[j] = __ballot(in[j]);
-    }
-    for (;;) {
-      // leader = first pending lane of the first pending group (wave-uniform)
-      uint32_t mi_u = 0xFFFFFFFFu;
-      bool found = false;
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        if (!found && pending[j]) {
-          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)pending[j]) - 1);
-          found = true;
-        }
-      }
-      if (!found) break;
-      InstU u;
-      if (a.ablate & 16u) {  // timing experiment: no cache-row load / SGPR unpack
-#pragma unroll
-        for (int k = 0; k < 24; k++) u.pl[k] = a.cam_pos[k % 3];
-        u.vis_offset = 0;
-        u.bounds = reinterpret_cast<uint64_t>(a.cache);
-        u.v0 = 0;
-      } else
-        load_inst_uniform(a.cache, mi_u, lane, u);
-      ConeU cu;
-      bool cone_ready = false;
-      bool mine[G];
-      uint4 bnd[G];
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        mine[j] = in[j] && rec[j].x == mi_u;
-        // unconditional (see above); lanes of other instances read element 0 of this instance's bounds
-        bnd[j] = load_global_u4(u.bounds, (mine[j] && !(a.ablate & 4u)) ? rec[j].y : 0u);
-      }
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        const uint64_t m = __ballot(mine[j]);
-        if (m) {  // wave-uniform
-          if (a.ablate & 8u) {
-            if (mine[j]) res[j].emit = (rec[j].y & 3u) == 0u;
-          } else
-            eval_meshlets<HIZ, OCCL, LATE>(a, u, cu, cone_ready, bnd[j], rec[j].y, mine[j], hiz, s_level_off, res[j]);
-          pending[j] &= ~m;
-        }
-      }
-    }
-    uint32_t cnt = 0;
-    uint64_t wbits[G];
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      wbits[j] = 0;
-      if (group[j] >= nwords) continue;  // wave-uniform
-      // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
-      // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
-      if (HIZ && OCCL) update_visibility_mask(a.mask, res[j].mask_idx, res[j].visible, in[j], lane);
-      const uint64_t bits = __ballot(res[j].emit);
-      wbits[j] = bits;
-      if (!FUSED && lane == 0) gptr(a.bits)[group[j]] = bits;
-      cnt += (uint32_t)__popcll((unsigned long long)bits);
-    }
-    if (FUSED) {
-      // ---- ordered emit inside the same launch (one chunk per block; grid == nchunks) ----
-      __syncthreads();
-      if (lane == 0) s_red[wave] = cnt;
-      __syncthreads();
-      uint32_t block_count = 0;
-#pragma unroll
-      for (int k = 0; k < kWaves; k++) block_count += s_red[k];
-      uint32_t wave_prefix = 0;
-      for (int k = 0; k < wave; k++) wave_prefix += s_red[k];
-      const uint32_t epoch = s_fused[0];
-      const uint32_t sup = chunk / kChunksPerSuper;
-      if (wave == 0) {
-        uint32_t last = 0;
-        if (lane == 0) {
-          st_gran(&a.chunk_gran[chunk], epoch, block_count);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const uint32_t in_super = min(kChunksPerSuper, nchunks - sup * kChunksPerSuper);
-          const uint32_t old = atomicAdd(&a.super_arrive[sup], 1u);
-          last = (old + 1u == in_super) ? 1u : 0u;
-        }
-        last = readfirst_u(last);
-        bool failed = false;
-        if (last) {  // last arriver of this super: publish its total
-          const uint32_t ci = sup * kChunksPerSuper + (uint32_t)lane;
-          uint32_t v = 0;
-          for (uint32_t spin = 0;; spin++) {
-            bool ok = true;
-            v = 0;
-            if (ci < nchunks) {
-              const uint64_t g = ld_gran(&a.chunk_gran[ci]);
-              ok = (uint32_t)(g >> 32) == epoch;
-              v = (uint32_t)g;
-            }
-            if (__all(ok)) break;
-            if (spin > kMaxSpins) {
-              failed = true;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-          }
-          const uint32_t total = wave_sum(v);
-          if (lane == 0) {
-            st_gran(&a.super_gran[sup], epoch, total);
-            __hip_atomic_store(&a.super_arrive[sup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        // exclusive base of this chunk: supers before it + chunks before it inside its super
-        uint32_t acc = 0;
-        for (uint32_t spin = 0;; spin++) {
-          bool ok = true;
-          acc = 0;
-          for (uint32_t i = (uint32_t)lane; i < sup; i += 64) {
-            const uint64_t g = ld_gran(&a.super_gran[i]);
-            ok = ok && (uint32_t)(g >> 32) == epoch;
-            acc += (uint32_t)g;
-          }
-          const uint32_t ci = sup * kChunksPerSuper + (uint32_t)lane;
-          if (ci < chunk) {
-            const uint64_t g = ld_gran(&a.chunk_gran[ci]);
-            ok = ok && (uint32_t)(g >> 32) == epoch;
-            acc += (uint32_t)g;
-          }
-          if (__all(ok)) break;
-          if (spin > kMaxSpins || __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-            failed = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(4);
-        }
-        uint32_t base = wave_sum(acc);
-        if (failed) {
-          base = 0;
-          if (lane == 0) __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) s_fused[1] = base;
-      }
-      __syncthreads();
-      const uint32_t base = s_fused[1];
-      uint32_t off = base + wave_prefix;
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        const uint64_t bits = wbits[j];
-        if ((bits >> lane) & 1ull) {
-          const uint32_t rank = (uint32_t)__popcll((unsigned long long)(bits & ((1ull << lane) - 1ull)));
-          a.out[off + rank] = idx[j];
-        }
-        off += (uint32_t)__popcll((unsigned long long)bits);
-      }
-      if (threadIdx.x == 0) {
-        if (chunk == nchunks - 1) a.tri_cmd[0] = base + block_count;  // cull_triangles_cmd.x
-        // two-level "last block out" ticket (one address would serialise ~1000 atomics at ~88/us)
-        const uint32_t in_super = min(kChunksPerSuper, nchunks - sup * kChunksPerSuper);
-        const uint32_t d1 = atomicAdd(&a.super_done[sup], 1u);
-        if (d1 + 1u == in_super) {
-          __hip_atomic_store(&a.super_done[sup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t nsup = (nchunks + kChunksPerSuper - 1) / kChunksPerSuper;
-          const uint32_t d2 = atomicAdd(&a.sync[1], 1u);
-          if (d2 + 1u == nsup) {  // last block out: arm the next launch
-            __hip_atomic_store(&a.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.sync[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
-      continue;  // one chunk per block in fused mode (grid == nchunks)
-    }
-    // per-WAVE survivor count (+ per-super accumulation), published by lane 0 without a block barrier:
-    // a __syncthreads() here re-couples the block's waves every iteration and costs ~25 % of the
-    // kernel (they can no longer run ahead of each other to overlap loads with arithmetic).
-    if (a.ablate & 32u) continue;
-    if (lane == 0 && group[0] < nwords) {
-      const uint32_t wchunk = chunk * kWaves + wave;  // counts are per 64*G meshlets
-      gptr(a.chunk_counts)[wchunk] = cnt;
-      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // Meshlet stage, plain variant (passes/cull_meshlets.slang:23-73): the configs[1] kernel.
-// Same decisions and outputs as meshlets_test_body<false,...>; organised around the two scarce
-// resources measured on gfx950: VALU issue slots and SGPRs.
+// Organised around the two scarce resources measured on gfx950: VALU issue slots and SGPRs.
 //  * Instance-constant operands reach the SGPRs by SCALAR loads (s_load_dwordx16 from the InstCache row
 //    through the constant address space): zero VALU instructions, where a vector load + v_readlane
 //    unpack costs one VALU slot per dword.
@@ -727,7 +365,9 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
   const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // ---- stage A: all MeshletInstance loads of this wave (unconditional, clamped: see meshlets_test_body)
+    // ---- stage A: all MeshletInstance loads of this wave.  Unconditional at a clamped index: a
+    // `cond ? load : x` is lowered to an exec-masked block with s_waitcnt vmcnt(0) inside, which
+    // serialises the G loads (one HBM round trip each)
     const uint32_t group0 = (chunk * kWaves + wave) * G;
     uint2 rec[G];
     uint32_t st[G];  // bit 0: still to be decided, bit 1: visible
@@ -816,7 +456,8 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         }
       }
     }
-    // ---- ballots + per-wave survivor count (see meshlets_test_body for the no-barrier publication)
+    // ---- ballots + per-WAVE survivor count (+ per-super accumulation), published by lane 0 without a
+    // block barrier: a __syncthreads() here re-couples the block's waves every iteration (measured ~25 %)
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < G; j++) {
@@ -1203,165 +844,21 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 // ------------------------------------------------------------------------------------------
 // WIDE (extension): up to 128 triangles per meshlet -> two 64-lane triangle passes and two
 // 64-bit pass masks per slot (tri_masks[2*slot + half]).
-template <bool LATE, bool WIDE>
-OXC_DEV void tris_test_body(const TriTestArgs& a) {
-  set_half_denorm_flush();
-  constexpr int H = WIDE ? 2 : 1;
-  __shared__ uint32_t s_red[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t V = a.tri_cmd[0];
-  const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
-  const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;
-  constexpr int S = 16;  // slots per wave per chunk
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // ---- headers: lanes 0..15 fetch the records of this wave's 16 slots in parallel ----
-    uint32_t h_mi = 0xFFFFFFFFu;
-    uint4 h_meshlet = make_uint4(0, 0, 0, 0);  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
-    uint64_t h_micro = 0, h_vidx = 0, h_pos = 0;
-    {
-      const uint32_t slot = chunk * kTriChunk + (uint32_t)(lane & 15) * 4 + wave;
-      if (lane < S && slot < V) {
-        const uint32_t mli = a.visible[first + slot];
-        const uint2 r = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
-        h_mi = r.x;
-        const InstCache* row = a.cache + h_mi;
-        const uint64_t meshlets = row->meshlets;
-        h_micro = row->micro;
-        h_vidx = row->vidx;
-        h_pos = row->positions;
-        h_meshlet = load_global_u4(meshlets, r.y);
-        h_meshlet.z = min(h_meshlet.z, 64u);  // one lane per vertex / triangle (defines.slang:9-23)
-        h_meshlet.w = min(h_meshlet.w, 64u * (uint32_t)H);
-      }
-    }
-    // Per-slot uniform parameters out of the header lanes.
-    auto slot_u32 = [&](uint32_t v, int j) { return readlane_u(v, j); };
-    auto slot_u64 = [&](uint64_t v, int j) { return (uint64_t)readlane_u((uint32_t)v, j) | ((uint64_t)readlane_u((uint32_t)(v >> 32), j) << 32); };
-    // Two-deep software pipeline over the 16 slots: while slot j is being decided, slot j+1's
-    // positions and slot j+2's vertex / micro indices are already in flight (bytes in flight are
-    // what bounds this gather-heavy kernel).
-    auto issue_indices = [&](int j, uint32_t& vid, uint32_t (&d0)[H], uint32_t (&d1)[H]) {
-      vid = 0;
-#pragma unroll
-      for (int h = 0; h < H; h++) d0[h] = d1[h] = 0;
-      if (j >= S) return;
-      const uint32_t vcount = slot_u32(h_meshlet.z, j), tcount = slot_u32(h_meshlet.w, j);
-      if ((uint32_t)lane < vcount) vid = load_global_u32(slot_u64(h_vidx, j), slot_u32(h_meshlet.x, j) + lane);
-#pragma unroll
-      for (int h = 0; h < H; h++) {
-        const uint32_t t = (uint32_t)lane + 64u * (uint32_t)h;
-        if (t < tcount) {  // scene.slang:336-342,365-372 via aligned dword loads
-          const uint32_t boff = slot_u32(h_meshlet.y, j) + t * 3u;
-          const uint64_t pm = slot_u64(h_micro, j);
-          d0[h] = load_global_u32(pm, boff >> 2);
-          d1[h] = load_global_u32(pm, (boff + 2u) >> 2);
-        }
-      }
-    };
-    auto issue_positions = [&](int j, uint32_t vid, uint2& q) {
-      q = make_uint2(0, 0);
-      if (j >= S) return;
-      if ((uint32_t)lane < slot_u32(h_meshlet.z, j)) q = load_global_u2(slot_u64(h_pos, j), vid);  // u16x4, stride 8
-    };
-    uint32_t vid1, m0_1[H], m1_1[H];  // slot j+1: vertex ids + micro dwords
-    uint32_t m0_0[H], m1_0[H];        // slot j:   micro dwords
-    uint2 q0;                         // slot j:   positions
-    {
-      uint32_t vid0;
-      issue_indices(0, vid0, m0_0, m1_0);
-      issue_indices(1, vid1, m0_1, m1_1);
-      issue_positions(0, vid0, q0);
-    }
-    uint32_t cnt = 0;
-    uint32_t cur_mi = 0xFFFFFFFFu;
-    float mvp[16];
-#pragma unroll 1
-    for (int j = 0; j < S; j++) {
-      const uint32_t slot = chunk * kTriChunk + (uint32_t)j * 4 + wave;
-      if (slot >= V) break;  // wave-uniform
-      // ---- keep the pipeline full ----
-      uint2 q1;
-      issue_positions(j + 1, vid1, q1);
-      uint32_t vid2, m0_2[H], m1_2[H];
-      issue_indices(j + 2, vid2, m0_2, m1_2);
-      // ---- decide slot j ----
-      const uint32_t mi = slot_u32(h_mi, j);
-      const uint32_t vertex_count = slot_u32(h_meshlet.z, j);
-      const uint32_t tri_count = slot_u32(h_meshlet.w, j);
-      const uint32_t tri_offset = slot_u32(h_meshlet.y, j);
-      if (mi != cur_mi) {  // wave-uniform: projection_view * world of this mesh instance
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + mi);
-        uint32_t v0 = p[lane];
-#pragma unroll
-        for (int k = 0; k < 16; k++) mvp[k] = readlane_f(v0, kRowMvp + k);
-        cur_mi = mi;
-      }
-      // vertex phase: lane = vertex
-      float clx = 0.f, cly = 0.f, clz = -1.f, clw = 0.f;
-      if ((uint32_t)lane < vertex_count) {
-        float px = dequantize_half(q0.x & 0xFFFFu), py = dequantize_half(q0.x >> 16), pz = dequantize_half(q0.y & 0xFFFFu);
-        clx = ((OXC_M(mvp, 0, 0) * px + OXC_M(mvp, 0, 1) * py) + OXC_M(mvp, 0, 2) * pz) + OXC_M(mvp, 0, 3);
-        cly = ((OXC_M(mvp, 1, 0) * px + OXC_M(mvp, 1, 1) * py) + OXC_M(mvp, 1, 2) * pz) + OXC_M(mvp, 1, 3);
-        clz = ((OXC_M(mvp, 2, 0) * px + OXC_M(mvp, 2, 1) * py) + OXC_M(mvp, 2, 2) * pz) + OXC_M(mvp, 2, 3);
-        clw = ((OXC_M(mvp, 3, 0) * px + OXC_M(mvp, 3, 1) * py) + OXC_M(mvp, 3, 2) * pz) + OXC_M(mvp, 3, 3);
-      }
-      const uint64_t zok = __ballot(clz >= 0.0f);
-      // triangle phase: lane = triangle (two passes of 64 when WIDE)
-#pragma unroll
-      for (int h = 0; h < H; h++) {
-        const uint32_t t = (uint32_t)lane + 64u * (uint32_t)h;
-        uint32_t tri = 0;
-        if (t < tri_count) tri = __builtin_amdgcn_alignbyte(m1_0[h], m0_0[h], (tri_offset + t * 3u) & 3u);
-        const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
-        const float ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
-        const float bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
-        const float cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
-        const bool z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
-        // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
-        const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
-        const bool passed = t < tri_count && z_all && !(det >= 0.0001f);
-        const uint64_t mask = __ballot(passed);
-        if (lane == 0) a.tri_masks[(size_t)slot * H + h] = mask;
-        cnt += (uint32_t)__popcll((unsigned long long)mask);
-      }
-      // ---- rotate the pipeline registers ----
-      q0 = q1;
-      vid1 = vid2;
-#pragma unroll
-      for (int h = 0; h < H; h++) {
-        m0_0[h] = m0_1[h];
-        m1_0[h] = m1_1[h];
-        m0_1[h] = m0_2[h];
-        m1_1[h] = m1_2[h];
-      }
-    }
-    __syncthreads();
-    if (lane == 0) s_red[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      a.chunk_counts[chunk] = c;
-      if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Triangle stage, test kernel, straight-line version.  Same decisions and outputs as
-// tris_test_body; what changed is how the 16 slots of a wave are sequenced:
-//  * the slot loop is fully unrolled and software-pipelined kIdxAhead / kPosAhead slots ahead, so a
-//    wave keeps the index dwords of kIdxAhead and the position gathers of kPosAhead meshlets in
-//    flight (bytes in flight are what bounds this gather-heavy kernel) and every wait is a counted
-//    vmcnt(N) instead of the vmcnt(0) a loop back-edge or an exec-masked load block forces;
+// How the 16 slots of a wave are sequenced:
+//  * the slot loop is fully unrolled and software-pipelined, so a wave keeps the index dwords of
+//    kIdxAhead and the position gathers of kPosAhead meshlets in flight (bytes in flight are what bounds
+//    this gather-heavy kernel) and every wait is a counted vmcnt(N) instead of the vmcnt(0) that a loop
+//    back-edge or an exec-masked load block forces (the loop version of this kernel took 160 us where
+//    this one takes 123 us on config 3);
+//  * everything that is uniform per slot -- LOD pointers, the Meshlet record, projection_view * world --
+//    travels through scalar loads into SGPRs (no v_readlane unpacking);
 //  * no conditional loads: lanes beyond a meshlet's vertex / triangle count re-read its last element,
 //    slots beyond the visible count re-do the last visible slot (their result is dropped), and a
 //    meshlet with no vertices or triangles reads zero dwords of its own InstCache row;
-//  * projection_view * world comes from the InstCache row by scalar loads and feeds packed f32
-//    operations: clip = ((m0*x + m1*y) + m2*z) + m3 as two v_pk pairs (xy, zw), same roundings;
+//  * clip = ((m0*x + m1*y) + m2*z) + m3 as two packed pairs (xy, zw): same roundings, half the slots;
 //  * the 16 pass masks are collected in lanes 0..15 (v_writelane) and stored once.
-// ------------------------------------------------------------------------------------------
 template <bool LATE, bool WIDE>
-OXC_DEV void tris_test_body2(const TriTestArgs& a) {
+OXC_DEV void tris_test_body(const TriTestArgs& a) {
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
   constexpr int S = 16;  // slots per wave per chunk
@@ -1766,14 +1263,12 @@ __global__ __launch_bounds__(1024) void k_scan_mesh_counts(ScanArgs a) { scan_bo
 __global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) { expand_body(a); }
 // (Capping SGPRs at 80 for 8 waves/SIMD -- the compiler otherwise keeps ~106 live -- was measured:
 // plain kernel 36.7 -> 38.8 us per 4M meshlets, HiZ variant 183 -> 175 us; not kept.)
-template <bool HIZ, bool OCCL, bool LATE, bool FUSED = false, int G = (int)kGroupsPerWave>
+template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
 __global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
-  if constexpr (!HIZ && !FUSED)
+  if constexpr (!HIZ)
     meshlets_plain_body<G>(a);
-  else if constexpr (HIZ && !FUSED)
-    meshlets_hiz_body<OCCL, LATE, G>(a);
   else
-    meshlets_test_body<HIZ, OCCL, LATE, FUSED, G>(a);
+    meshlets_hiz_body<OCCL, LATE, G>(a);
 }
 template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
@@ -1784,11 +1279,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
 #endif
 template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256, WIDE ? 6 : OXC_TRI_WAVES) void k_cull_triangles_test(TriTestArgs a) {
-#ifdef OXC_TRIS_V1
   tris_test_body<LATE, WIDE>(a);
-#else
-  tris_test_body2<LATE, WIDE>(a);
-#endif
 }
 template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
@@ -1820,11 +1311,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlo
   meshlets_emit_body<false, false>(dev->emit[blockIdx.y]);
 }
 __global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchBlob* __restrict__ dev) {
-#ifdef OXC_TRIS_V1
   tris_test_body<false, false>(dev->ttest[blockIdx.y]);
-#else
-  tris_test_body2<false, false>(dev->ttest[blockIdx.y]);
-#endif
 }
 __global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchBlob* __restrict__ dev) {
   tris_emit_body<false, false>(dev->temit[blockIdx.y]);
@@ -1876,19 +1363,16 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
   } else if (occl && late) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else if (occl) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, false, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else if (late) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, true, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
   }
 }
 void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_cull_meshlets_hpb_test, dim3(grid), dim3(256), 0, s, a); }
-void launch_meshlets_fused(const MeshletTestArgs& a, uint32_t grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false, true>), dim3(grid), dim3(256), 0, s, a);
-}
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   if (!hiz)

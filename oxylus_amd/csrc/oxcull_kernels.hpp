@@ -53,7 +53,6 @@ struct HpbTestArgs {
 };
 
 struct MeshletTestArgs {
-  uint32_t ablate;  // timing experiments only (OXC_ABLATE): 1 skip cone, 2 skip frustum, 4 skip bounds load, 8 skip evaluation, 16 skip row unpack, 32 skip publication, 64 skip occlusion
   uint32_t n_host;  // != 0: the list length is known on the host (seeded lists); skips the dependent load of vis[0]
   const InstCache* cache;
   const GpuMeshletInstance* meshlet_instances;
@@ -69,14 +68,6 @@ struct MeshletTestArgs {
   uint32_t hiz_lds_off[13];   // float offset of each staged level inside the LDS tile
   float near_clip;
   float cam_pos[3];
-  // fused ordered emit (plain mode, one chunk per block): see k_cull_meshlets_test<..., FUSED>
-  uint64_t* chunk_gran;     // {epoch:32 | count:32} per chunk
-  uint64_t* super_gran;     // {epoch:32 | total:32} per 64 chunks
-  uint32_t* super_arrive;   // arrivals per super (self-resetting)
-  uint32_t* super_done;     // blocks finished per super (self-resetting)
-  uint32_t* sync;           // [0] epoch of the last completed launch, [1] done ticket, [2] error flag
-  uint32_t* tri_cmd;
-  uint32_t* out;            // visible_meshlet_instances_indices
 };
 
 struct MeshletEmitArgs {
@@ -157,7 +148,6 @@ void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s);
 void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s);
 void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, void* out, uint32_t grid, hipStream_t s);
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s);
-void launch_meshlets_fused(const MeshletTestArgs& a, uint32_t grid, hipStream_t s);
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
 void launch_tris_test(const TriTestArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
