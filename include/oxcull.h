@@ -240,6 +240,28 @@ oxc_status oxc_profile_end(oxc_ctx* ctx, oxc_kernel_times* out);
 oxc_status oxc_debug_decode_bounds(oxc_ctx* ctx, const void* bounds_dptr, uint32_t n, float* out10_dptr,
                                    void* hip_stream);
 
+/* ---- meshlet bounds producer (asset side) ---------------------------------------
+ * Replaces the per-meshlet loop of Oxylus/src/Asset/AssetManager_GLTF.cpp:683-744 (AABB of the referenced
+ * vertices -> meshopt_quantizeHalf, normal cone of meshopt_computeMeshletBounds -> cone_axis_s8 /
+ * cone_cutoff_s8, running mesh AABB) and the position quantisation of :573-578.  meshopt_buildMeshlets itself
+ * (the greedy clusteriser that produces `meshlets`, `indirect_vertex_indices`, `local_triangle_indices`) stays
+ * on the host, as in the reference.  All pointers are device pointers. */
+typedef struct oxc_meshlet_bounds_desc {
+  uint32_t struct_size;
+  uint32_t vertex_count;
+  uint32_t meshlet_count;
+  uint32_t _pad;
+  oxc_buffer positions;               /* in:  glm::vec3[vertex_count] (float3, stride 12)             */
+  oxc_buffer meshlets;                /* in:  GPU::Meshlet[meshlet_count] (SceneGPU.hpp:97-103)       */
+  oxc_buffer indirect_vertex_indices; /* in:  u32, indexed by Meshlet::indirect_vertex_index_offset   */
+  oxc_buffer local_triangle_indices;  /* in:  u8,  indexed by Meshlet::local_triangle_index_offset    */
+  oxc_buffer meshlet_bounds;          /* out: GPU::MeshletBounds[meshlet_count] (SceneGPU.hpp:84-90)  */
+  oxc_buffer mesh_bounds;             /* out: GPU::MeshBounds {vec3 aabb_center; vec3 aabb_extent} (SceneGPU.hpp:92-95) */
+  oxc_buffer quantized_positions;     /* out, optional (dptr may be NULL): u16x4[vertex_count]        */
+} oxc_meshlet_bounds_desc;
+
+oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc* desc, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,12 @@ def lib() -> C.CDLL:
         l.orc_cull_triangles_mt.restype = u32
         l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
         l.orc_entities_update_and_cull.restype = u32
+        l.orc_quantize_half.argtypes = [f32]
+        l.orc_quantize_half.restype = C.c_uint16
+        l.orc_quantize_snorm.argtypes = [f32, C.c_int]
+        l.orc_quantize_snorm.restype = C.c_int
+        l.orc_build_meshlet_bounds.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp]
+        l.orc_build_meshlet_bounds.restype = None
         _lib = l
     return _lib
 
@@ -252,3 +258,22 @@ def cull_meshlets_hpb(scene, cam, meshlet_instances: torch.Tensor, clipmaps: tor
     cnt = lib().orc_cull_meshlets_hpb(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), n, _p(cam),
                                       _p(clipmaps), _p(dirty), dirty.numel(), C.byref(hpb), _p(out))
     return out[:cnt].clone()
+
+
+def quantize_half(v: float) -> int:
+    return int(lib().orc_quantize_half(float(np.float32(v))))
+
+
+def quantize_snorm(v: float, bits: int) -> int:
+    return int(lib().orc_quantize_snorm(float(np.float32(v)), bits))
+
+
+def build_meshlet_bounds(positions: torch.Tensor, meshlets: torch.Tensor, vidx: torch.Tensor, micro: torch.Tensor):
+    """positions f32 [V,3], meshlets i32 [M,4], vidx i32, micro u8 -> (bounds i16 [M,8], mesh6 f32 [6], qpos i16 [V,4])."""
+    V, M = positions.shape[0], meshlets.shape[0]
+    bounds = torch.zeros((M, 8), dtype=torch.int16)
+    mesh6 = torch.zeros(6, dtype=torch.float32)
+    qpos = torch.zeros((V, 4), dtype=torch.int16)
+    lib().orc_build_meshlet_bounds(_p(positions.contiguous()), V, _p(meshlets.contiguous()), M, _p(vidx.contiguous()), _p(micro.contiguous()),
+                                   _p(bounds), _p(mesh6), _p(qpos))
+    return bounds, mesh6, qpos

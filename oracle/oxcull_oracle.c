@@ -817,3 +817,178 @@ uint32_t orc_entities_update_and_cull(uint32_t n, const float* trs10, const int3
   }
   return nvis;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * meshlet bounds producer.  See the header for provenance (meshoptimizer v1.2 is a
+ * third-party dependency absent from /root/reference; its published algorithm is restated).
+ * ------------------------------------------------------------------------------------------ */
+/* meshoptimizer.h meshopt_quantizeHalf: round to nearest (ties away from zero in magnitude), flush
+ * results below 2^-14 to zero, >= 65536 to infinity, every NaN to a quiet NaN. */
+uint16_t orc_quantize_half(float v) {
+  uint32_t ui = f2u(v);
+  int s = (int)((ui >> 16) & 0x8000u);
+  int em = (int)(ui & 0x7fffffffu);
+  int h = (em - (112 << 23) + (1 << 12)) >> 13;
+  h = (em < (113 << 23)) ? 0 : h;
+  h = (em >= (143 << 23)) ? 0x7c00 : h;
+  h = (em > (255 << 23)) ? 0x7e00 : h;
+  return (uint16_t)(s | h);
+}
+
+/* meshoptimizer.h meshopt_quantizeSnorm */
+int orc_quantize_snorm(float v, int bits) {
+  const float scale = (float)((1 << (bits - 1)) - 1);
+  float round = (v >= 0 ? 0.5f : -0.5f);
+  v = (v >= -1) ? v : -1;
+  v = (v <= +1) ? v : +1;
+  return (int)(v * scale + round);
+}
+
+/* clusterizer.cpp computeBoundingSphere with all radii 0 and axis_count = 3 (the call that fits the normal
+ * cone): seed with the most distant pair among the per-axis extrema, then one sweep growing the sphere. */
+static void bounding_sphere_axes3(float result[4], const float (*points)[3], uint32_t count) {
+  uint32_t pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+  float tmin[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+  float tmax[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (uint32_t i = 0; i < count; i++) {
+    for (int axis = 0; axis < 3; axis++) {
+      /* tp = ax[0]*p[0] + ax[1]*p[1] + ax[2]*p[2] with a unit axis: the other products are exact zeros */
+      float tp = points[i][axis];
+      pmin[axis] = (tp < tmin[axis]) ? i : pmin[axis];
+      pmax[axis] = (tp > tmax[axis]) ? i : pmax[axis];
+      tmin[axis] = (tp < tmin[axis]) ? tp : tmin[axis];
+      tmax[axis] = (tp > tmax[axis]) ? tp : tmax[axis];
+    }
+  }
+  int paxis = 0;
+  float paxisdr = 0.0f;
+  for (int axis = 0; axis < 3; axis++) {
+    const float* p1 = points[pmin[axis]];
+    const float* p2 = points[pmax[axis]];
+    float d2 = ((p2[0] - p1[0]) * (p2[0] - p1[0]) + (p2[1] - p1[1]) * (p2[1] - p1[1])) + (p2[2] - p1[2]) * (p2[2] - p1[2]);
+    float dr = sqrtf(d2);
+    if (dr > paxisdr) {
+      paxisdr = dr;
+      paxis = axis;
+    }
+  }
+  const float* p1 = points[pmin[paxis]];
+  const float* p2 = points[pmax[paxis]];
+  float paxisd = sqrtf(((p2[0] - p1[0]) * (p2[0] - p1[0]) + (p2[1] - p1[1]) * (p2[1] - p1[1])) + (p2[2] - p1[2]) * (p2[2] - p1[2]));
+  float paxisk = paxisd > 0.0f ? paxisd / (2.0f * paxisd) : 0.0f;
+  float center[3] = {p1[0] + (p2[0] - p1[0]) * paxisk, p1[1] + (p2[1] - p1[1]) * paxisk, p1[2] + (p2[2] - p1[2]) * paxisk};
+  float radius = paxisdr / 2.0f;
+  for (uint32_t i = 0; i < count; i++) {
+    const float* p = points[i];
+    float d2 = ((p[0] - center[0]) * (p[0] - center[0]) + (p[1] - center[1]) * (p[1] - center[1])) + (p[2] - center[2]) * (p[2] - center[2]);
+    float d = sqrtf(d2);
+    if (d > radius) {
+      float k = d > 0.0f ? (d - radius) / (2.0f * d) : 0.0f;
+      center[0] += k * (p[0] - center[0]);
+      center[1] += k * (p[1] - center[1]);
+      center[2] += k * (p[2] - center[2]);
+      radius = (radius + d) / 2.0f;
+    }
+  }
+  result[0] = center[0];
+  result[1] = center[1];
+  result[2] = center[2];
+  result[3] = radius;
+}
+
+void orc_build_meshlet_bounds(const float* positions, uint32_t vertex_count, const orc_meshlet* meshlets, uint32_t meshlet_count,
+                              const uint32_t* indirect_vertex_indices, const uint8_t* local_triangle_indices,
+                              orc_meshlet_bounds* out_bounds, float* out_mesh6, uint16_t* out_qpos) {
+  /* AssetManager_GLTF.cpp:573-578 */
+  if (out_qpos) {
+    for (uint32_t v = 0; v < vertex_count; v++) {
+      out_qpos[v * 4 + 0] = orc_quantize_half(positions[v * 3 + 0]);
+      out_qpos[v * 4 + 1] = orc_quantize_half(positions[v * 3 + 1]);
+      out_qpos[v * 4 + 2] = orc_quantize_half(positions[v * 3 + 2]);
+      out_qpos[v * 4 + 3] = 0;
+    }
+  }
+  const float fmax_ = 3.402823466e+38f;
+  float mesh_min[3] = {fmax_, fmax_, fmax_}, mesh_max[3] = {-fmax_, -fmax_, -fmax_};
+  for (uint32_t m = 0; m < meshlet_count; m++) {
+    const orc_meshlet* ml = &meshlets[m];
+    const uint32_t* mv = indirect_vertex_indices + ml->indirect_vertex_index_offset;
+    const uint8_t* mt = local_triangle_indices + ml->local_triangle_index_offset;
+    /* AssetManager_GLTF.cpp:690-706: AABB over every referenced corner (glm::min(a,b) = b < a ? b : a) */
+    float bb_min[3] = {fmax_, fmax_, fmax_}, bb_max[3] = {-fmax_, -fmax_, -fmax_};
+    for (uint32_t i = 0; i < ml->triangle_count * 3u; i++) {
+      const float* p = positions + (size_t)mv[mt[i]] * 3;
+      for (int k = 0; k < 3; k++) {
+        bb_min[k] = (p[k] < bb_min[k]) ? p[k] : bb_min[k];
+        bb_max[k] = (bb_max[k] < p[k]) ? p[k] : bb_max[k];
+      }
+    }
+    /* meshopt_computeMeshletBounds -> meshopt_computeClusterBounds */
+    float normals[256][3];
+    uint32_t triangles = 0;
+    uint32_t tcount = ml->triangle_count < 256u ? ml->triangle_count : 256u;
+    for (uint32_t t = 0; t < tcount; t++) {
+      const float* p0 = positions + (size_t)mv[mt[t * 3 + 0]] * 3;
+      const float* p1 = positions + (size_t)mv[mt[t * 3 + 1]] * 3;
+      const float* p2 = positions + (size_t)mv[mt[t * 3 + 2]] * 3;
+      float p10[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+      float p20[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+      float nx = p10[1] * p20[2] - p10[2] * p20[1];
+      float ny = p10[2] * p20[0] - p10[0] * p20[2];
+      float nz = p10[0] * p20[1] - p10[1] * p20[0];
+      float area = sqrtf((nx * nx + ny * ny) + nz * nz);
+      if (area == 0.0f) continue; /* degenerate triangles are left out */
+      normals[triangles][0] = nx / area;
+      normals[triangles][1] = ny / area;
+      normals[triangles][2] = nz / area;
+      triangles++;
+    }
+    int8_t axis_s8[3] = {0, 0, 0};
+    int8_t cutoff_s8 = 0; /* no valid triangle: cone data stays 0 */
+    if (triangles > 0) {
+      float nsphere[4];
+      bounding_sphere_axes3(nsphere, normals, triangles);
+      float axis[3] = {nsphere[0], nsphere[1], nsphere[2]};
+      float axislength = sqrtf((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+      float invaxislength = axislength == 0.0f ? 0.0f : 1.0f / axislength;
+      axis[0] *= invaxislength;
+      axis[1] *= invaxislength;
+      axis[2] *= invaxislength;
+      float mindp = 1.0f;
+      for (uint32_t i = 0; i < triangles; i++) {
+        float dp = (normals[i][0] * axis[0] + normals[i][1] * axis[1]) + normals[i][2] * axis[2];
+        mindp = (dp < mindp) ? dp : mindp;
+      }
+      if (mindp <= 0.1f) {
+        cutoff_s8 = 127; /* cone wider than ~168 degrees: never culls; the axis stays 0 */
+      } else {
+        float cone_cutoff = sqrtf(1.0f - mindp * mindp);
+        for (int k = 0; k < 3; k++) axis_s8[k] = (int8_t)orc_quantize_snorm(axis[k], 8);
+        float e0 = fabsf((float)axis_s8[0] / 127.0f - axis[0]);
+        float e1 = fabsf((float)axis_s8[1] / 127.0f - axis[1]);
+        float e2 = fabsf((float)axis_s8[2] / 127.0f - axis[2]);
+        int c = (int)(127.0f * (((cone_cutoff + e0) + e1) + e2) + 1.0f); /* rounded up, not to nearest */
+        cutoff_s8 = (c > 127) ? 127 : (int8_t)c;
+      }
+    }
+    /* AssetManager_GLTF.cpp:717-735 */
+    orc_meshlet_bounds* b = &out_bounds[m];
+    for (int k = 0; k < 3; k++) {
+      float center = (bb_max[k] + bb_min[k]) * 0.5f;
+      float extent = bb_max[k] - bb_min[k];
+      b->aabb_center[k] = orc_quantize_half(center);
+      b->aabb_extent[k] = orc_quantize_half(extent);
+      mesh_min[k] = (bb_min[k] < mesh_min[k]) ? bb_min[k] : mesh_min[k];
+      mesh_max[k] = (mesh_max[k] < bb_max[k]) ? bb_max[k] : mesh_max[k];
+    }
+    b->cone_axis_xy[0] = axis_s8[0];
+    b->cone_axis_xy[1] = axis_s8[1];
+    b->cone_axis_z = axis_s8[2];
+    b->cone_cutoff = cutoff_s8;
+  }
+  /* AssetManager_GLTF.cpp:741-744 */
+  for (int k = 0; k < 3; k++) {
+    out_mesh6[k] = (mesh_max[k] + mesh_min[k]) * 0.5f;
+    out_mesh6[3 + k] = mesh_max[k] - mesh_min[k];
+  }
+}

@@ -220,6 +220,24 @@ uint32_t orc_entities_update_and_cull(uint32_t n, const float* trs10 /* t3 q4 s3
                                       const float* aabb_min_max6, const float* frustum_planes24, float* world_out16,
                                       uint8_t* visible_out);
 
+/* ---- meshlet bounds producer (asset side) --------------------------------------
+ * Restates the loop body of Oxylus/src/Asset/AssetManager_GLTF.cpp:573-578 (position quantisation) and
+ * :683-744 (per-meshlet AABB -> half, normal cone -> s8, mesh AABB).  The cone comes from a third-party
+ * dependency that is NOT under /root/reference: meshoptimizer v1.2 (xmake/packages.lua:9), functions
+ * meshopt_computeMeshletBounds -> meshopt_computeClusterBounds -> computeBoundingSphere (src/clusterizer.cpp)
+ * and meshopt_quantizeHalf / meshopt_quantizeSnorm (src/meshoptimizer.h).  Its published algorithm is
+ * restated here from the public sources (the bounding-sphere routine with per-axis extremum seeding and one
+ * refinement sweep, as published since v0.22); v1.2 itself is not available in this image to diff against,
+ * so this row is PARITY UNPINNED twice over.  Only the quantities the engine keeps (cone_axis_s8,
+ * cone_cutoff_s8) are produced; the cluster sphere / apex, which the engine discards, are not. */
+uint16_t orc_quantize_half(float v);
+int orc_quantize_snorm(float v, int bits);
+/* positions: float3 (stride 12).  out_bounds[meshlet_count]; out_mesh6 = {center xyz, extent xyz};
+ * out_qpos (may be NULL) = u16x4 per vertex. */
+void orc_build_meshlet_bounds(const float* positions, uint32_t vertex_count, const orc_meshlet* meshlets, uint32_t meshlet_count,
+                              const uint32_t* indirect_vertex_indices, const uint8_t* local_triangle_indices,
+                              orc_meshlet_bounds* out_bounds, float* out_mesh6, uint16_t* out_qpos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ struct oxc_ctx {
   };
   Lane lane[kMaxBatch];
   BatchBlob* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call
+  float* bounds_scratch = nullptr;  // oxc_build_meshlet_bounds: per-meshlet {min xyz, max xyz}
+  uint32_t bounds_scratch_cap = 0;
   // counter slots
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
@@ -273,6 +275,7 @@ void oxc_destroy(oxc_ctx* ctx) {
   for (auto& ln : ctx->lane)
     if (ln.arena) (void)hipFree(ln.arena);
   if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
+  if (ctx->bounds_scratch) (void)hipFree(ctx->bounds_scratch);
   if (ctx->slots) (void)hipFree(ctx->slots);
   delete ctx;
 }
@@ -783,6 +786,37 @@ oxc_status oxc_debug_decode_bounds(oxc_ctx* ctx, const void* bounds_dptr, uint32
   if (!bounds_dptr || !out10_dptr) return fail(ctx, OXC_INVALID_ARG, "debug_decode_bounds: null pointer");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   if (n) launch_debug_decode_bounds(bounds_dptr, n, out10_dptr, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc* d, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!d || d->struct_size != sizeof(oxc_meshlet_bounds_desc)) return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: bad desc / struct_size");
+  if (!d->mesh_bounds.dptr || d->mesh_bounds.bytes < 24) return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: mesh_bounds must hold 6 floats");
+  if (d->meshlet_count) {
+    if (!d->positions.dptr || !d->meshlets.dptr || !d->indirect_vertex_indices.dptr || !d->local_triangle_indices.dptr || !d->meshlet_bounds.dptr)
+      return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: null input / output buffer");
+    if (d->meshlets.bytes < (uint64_t)d->meshlet_count * sizeof(GpuMeshlet) || d->meshlet_bounds.bytes < (uint64_t)d->meshlet_count * 16u)
+      return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: meshlets / meshlet_bounds smaller than meshlet_count records");
+  }
+  if (d->positions.dptr && d->positions.bytes < (uint64_t)d->vertex_count * 12u) return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: positions smaller than vertex_count float3");
+  if (d->quantized_positions.dptr && (!d->positions.dptr || d->quantized_positions.bytes < (uint64_t)d->vertex_count * 8u))
+    return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: quantized_positions smaller than vertex_count u16x4");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  if (d->meshlet_count > ctx->bounds_scratch_cap) {
+    OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old scratch
+    if (ctx->bounds_scratch) OXC_HIP(ctx, hipFree(ctx->bounds_scratch));
+    ctx->bounds_scratch = nullptr;
+    ctx->bounds_scratch_cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->bounds_scratch), (size_t)d->meshlet_count * 24u);
+    if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(bounds scratch)", e);
+    ctx->bounds_scratch_cap = d->meshlet_count;
+  }
+  launch_build_meshlet_bounds(static_cast<const float*>(d->positions.dptr), d->vertex_count, d->meshlets.dptr, d->meshlet_count,
+                              static_cast<const uint32_t*>(d->indirect_vertex_indices.dptr), static_cast<const uint8_t*>(d->local_triangle_indices.dptr),
+                              d->meshlet_bounds.dptr, static_cast<float*>(d->mesh_bounds.dptr), d->quantized_positions.dptr, ctx->bounds_scratch,
+                              ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }

@@ -124,6 +124,22 @@ class Counters(C.Structure):
     ]
 
 
+class MeshletBoundsDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("vertex_count", C.c_uint32),
+        ("meshlet_count", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("positions", Buffer),
+        ("meshlets", Buffer),
+        ("indirect_vertex_indices", Buffer),
+        ("local_triangle_indices", Buffer),
+        ("meshlet_bounds", Buffer),
+        ("mesh_bounds", Buffer),
+        ("quantized_positions", Buffer),
+    ]
+
+
 # every symbol include/oxcull.h declares
 EXPORTS = [
     "oxc_abi_version",
@@ -140,6 +156,7 @@ EXPORTS = [
     "oxc_debug_decode_bounds",
     "oxc_profile_begin",
     "oxc_profile_end",
+    "oxc_build_meshlet_bounds",
 ]
 
 
@@ -181,6 +198,7 @@ def load() -> C.CDLL:
     lib.oxc_debug_decode_bounds.argtypes = [vp, vp, C.c_uint32, vp, vp]
     lib.oxc_profile_begin.argtypes = [vp]
     lib.oxc_profile_end.argtypes = [vp, C.POINTER(KernelTimes)]
+    lib.oxc_build_meshlet_bounds.argtypes = [vp, C.POINTER(MeshletBoundsDesc), vp]
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
             getattr(lib, name).restype = C.c_int

@@ -257,6 +257,29 @@ class RendererInstance:
         self._check(self._lib.oxc_debug_decode_bounds(self._ctx, C.c_void_p(bounds.data_ptr()), n, C.c_void_p(out.data_ptr()), self._stream(None)))
         return out
 
+    def build_meshlet_bounds(self, positions: torch.Tensor, meshlets: torch.Tensor, vidx: torch.Tensor, micro: torch.Tensor,
+                             quantize_positions: bool = True, stream=None):
+        """SURVEY 8(f)-1, AssetManager_GLTF.cpp:573-578,683-744: positions f32 [V,3], meshlets i32 [M,4] (GPU::Meshlet),
+        vidx i32, micro u8 -> (MeshletBounds as i16 [M,8], mesh bounds f32 [6] = center xyz + extent xyz, u16x4 positions as i16 [V,4])."""
+        dev = positions.device
+        V, M = positions.shape[0], meshlets.shape[0]
+        bounds = torch.empty((M, 8), dtype=torch.int16, device=dev)
+        mesh6 = torch.empty(6, dtype=torch.float32, device=dev)
+        qpos = torch.empty((V, 4), dtype=torch.int16, device=dev) if quantize_positions else None
+
+        def buf(t):
+            return L.Buffer(C.c_void_p(t.data_ptr()), t.numel() * t.element_size()) if t is not None and t.numel() else L.Buffer(None, 0)
+
+        d = L.MeshletBoundsDesc()
+        d.struct_size = C.sizeof(L.MeshletBoundsDesc)
+        d.vertex_count, d.meshlet_count = V, M
+        d.positions, d.meshlets = buf(positions), buf(meshlets)
+        d.indirect_vertex_indices, d.local_triangle_indices = buf(vidx), buf(micro)
+        d.meshlet_bounds, d.mesh_bounds, d.quantized_positions = buf(bounds), buf(mesh6), buf(qpos)
+        self._keep = (positions, meshlets, vidx, micro)
+        self._check(self._lib.oxc_build_meshlet_bounds(self._ctx, C.byref(d), self._stream(stream)))
+        return bounds, mesh6, qpos
+
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))
 

@@ -415,3 +415,86 @@ def pack_clipmaps(mats, offs, z_near: float) -> torch.Tensor:
     rec.view(np.int32)[:, 16:18] = offs
     rec[:, 18] = z_near
     return torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
+
+
+# ------------------------------------------------------------------------------------------
+# Raw triangle meshes + a simple clusteriser: inputs for the meshlet bounds producer.
+# The reference clusters with meshopt_buildMeshlets (AssetManager_GLTF.cpp:657-681); what the producer
+# consumes is only that routine's OUTPUT FORMAT, restated here: per meshlet {vertex_offset, triangle_offset,
+# vertex_count, triangle_count}, a u32 list of mesh vertex ids per meshlet and a u8 list of local corner
+# indices whose per-meshlet start is 4-byte aligned.
+# ------------------------------------------------------------------------------------------
+def make_mesh(kind: str, n: int = 24, seed: int = 1):
+    """Returns (positions f32 [V,3], triangles i64 [T,3]) on the CPU."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    if kind == "sphere":  # UV sphere: smooth normals, narrow cones
+        lat, lon = np.meshgrid(np.linspace(0.05, np.pi - 0.05, n), np.linspace(0, 2 * np.pi, 2 * n, endpoint=False), indexing="ij")
+        pos = np.stack([np.sin(lat) * np.cos(lon), np.cos(lat), np.sin(lat) * np.sin(lon)], -1).reshape(-1, 3) * 3.0 + np.array([1.0, -2.0, 0.5])
+        rows, cols = n, 2 * n
+        wrap = True
+    elif kind in ("terrain", "plane0"):  # height field; "plane0": the x = +-0.0 plane (signed-zero folding)
+        u, v = np.meshgrid(np.linspace(-4, 4, n), np.linspace(-4, 4, 2 * n), indexing="ij")
+        if kind == "terrain":
+            h = 0.6 * np.sin(1.7 * u) * np.cos(1.3 * v) + 0.15 * rng.standard_normal(u.shape)
+            pos = np.stack([u, h, v], -1).reshape(-1, 3)
+        else:
+            zero = np.where(rng.random(u.shape) < 0.5, 0.0, -0.0)
+            pos = np.stack([zero, u, v], -1).reshape(-1, 3)
+        rows, cols = n, 2 * n
+        wrap = False
+    elif kind == "soup":  # unrelated triangles: cones wider than a hemisphere
+        pos = rng.standard_normal((3 * n * n, 3)) * 2.0
+        tris = np.arange(3 * n * n).reshape(-1, 3)
+        return torch.from_numpy(pos.astype(np.float32)), torch.from_numpy(tris.astype(np.int64))
+    else:
+        raise ValueError(kind)
+    tris = []
+    for r in range(rows - 1):
+        for c in range(cols - (0 if wrap else 1)):
+            a, b = r * cols + c, r * cols + (c + 1) % cols
+            d, e = (r + 1) * cols + c, (r + 1) * cols + (c + 1) % cols
+            tris.append((a, d, b))
+            tris.append((b, d, e))
+    tris = np.asarray(tris, dtype=np.int64)
+    if kind == "terrain":  # sprinkle degenerate triangles (repeated corner): left out of the cone, kept in the AABB
+        k = rng.integers(0, len(tris), size=max(1, len(tris) // 40))
+        tris[k, 2] = tris[k, 1]
+    return torch.from_numpy(pos.astype(np.float32)), torch.from_numpy(tris)
+
+
+def build_meshlets_simple(triangles: torch.Tensor, max_vertices: int = 64, max_triangles: int = 64):
+    """Greedy in-order clusteriser.  Returns (meshlets i32 [M,4], vidx i32 [..], micro u8 [..])."""
+    import numpy as np
+
+    tris = triangles.numpy()
+    meshlets, vidx, micro = [], [], []
+    local, verts, corners = {}, [], []
+
+    def flush():
+        nonlocal local, verts, corners
+        if not corners:
+            return
+        while len(micro) % 4:
+            micro.append(0)
+        meshlets.append((len(vidx), len(micro), len(verts), len(corners) // 3))
+        vidx.extend(verts)
+        micro.extend(corners)
+        local, verts, corners = {}, [], []
+
+    for t in tris:
+        new = len({int(v) for v in t if int(v) not in local})
+        if len(verts) + new > max_vertices or len(corners) // 3 + 1 > max_triangles:
+            flush()
+        for v in t:
+            v = int(v)
+            if v not in local:
+                local[v] = len(verts)
+                verts.append(v)
+            corners.append(local[v])
+    flush()
+    while len(micro) % 4:
+        micro.append(0)
+    return (torch.tensor(meshlets, dtype=torch.int32).reshape(-1, 4), torch.tensor(vidx, dtype=torch.int32),
+            torch.tensor(micro, dtype=torch.uint8))
