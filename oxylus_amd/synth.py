@@ -498,3 +498,27 @@ def build_meshlets_simple(triangles: torch.Tensor, max_vertices: int = 64, max_t
         micro.append(0)
     return (torch.tensor(meshlets, dtype=torch.int32).reshape(-1, 4), torch.tensor(vidx, dtype=torch.int32),
             torch.tensor(micro, dtype=torch.uint8))
+
+
+def make_scene_from_mesh(n_mesh_instances: int, bounds: torch.Tensor, meshlets: torch.Tensor, micro: torch.Tensor, vidx: torch.Tensor,
+                         positions_u16x4: torch.Tensor, mesh_bounds6: torch.Tensor, seed: int = 0x0A1DE5, device="cpu", **spec_kw) -> Scene:
+    """A scene of `n_mesh_instances` randomly placed instances of ONE real mesh whose GPU arrays come from the
+    asset path (clusteriser output + oxc_build_meshlet_bounds / its checker): the producer -> cull hand-over."""
+    K = int(meshlets.shape[0])
+    spec = SceneSpec(n_mesh_instances=n_mesh_instances, meshlets_per_mesh=K, share_meshes=1, with_geometry=False, seed=seed, **spec_kw)
+    s = make_scene(spec, device)
+    dev = s.device
+    s.bounds = bounds.to(dev).contiguous().clone()
+    s.meshlets = meshlets.to(dev).contiguous().clone()
+    s.micro = micro.to(dev).contiguous().clone()
+    s.vidx = vidx.to(dev).contiguous().clone()
+    s.positions = positions_u16x4.to(dev).contiguous().clone()
+    m32 = s.meshes.view(torch.int32)
+    m32[0, 6] = int(positions_u16x4.shape[0])
+    m32[0, 10:16] = mesh_bounds6.to(dev).to(torch.float32).view(torch.int32)
+    z = torch.zeros(1, dtype=torch.int64)
+    s._lod_tables = {"meshlet_start": z, "vidx_start": z, "micro_start": z, "mesh_vertex_start": z}
+    s.spec = SceneSpec(**{**spec.__dict__, "with_geometry": True,
+                          "tris_per_meshlet": int(meshlets[:, 3].max().item()) if K else 0,
+                          "verts_per_meshlet": int(meshlets[:, 2].max().item()) if K else 0})
+    return s.bind()

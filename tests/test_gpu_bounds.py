@@ -61,3 +61,27 @@ def test_produced_bounds_feed_the_cull_path(renderer, oracle_lib):
         c, e = dec[m, 0:3], dec[m, 3:6]
         tol = 2.0 ** -10 * (np.abs(c) + e + 1e-3) * 2
         assert np.all(c - e * 0.5 <= lo + tol) and np.all(c + e * 0.5 >= hi - tol)
+
+
+@pytest.mark.parametrize("kind", ["sphere", "terrain"])
+def test_real_mesh_through_producer_and_cull_pipeline(renderer, oracle_lib, kind):
+    """Asset path -> cull path on a real mesh: bounds / positions produced on the GPU (== the checker's, asserted
+    above) feed cull_meshes + cull_meshlets + cull_triangles; outputs must match the oracle run on the checker's arrays."""
+    import oracle
+    from oxylus_amd.synth import make_scene_from_mesh
+    from util import assert_same, gpu_frame, oracle_frame
+
+    pos, tris = make_mesh(kind, n=28, seed=21)
+    meshlets, vidx, micro = build_meshlets_simple(tris)
+    wb, wm, wq = oracle.build_meshlet_bounds(pos, meshlets, vidx, micro)
+    gb, gm, gq = renderer.build_meshlet_bounds(pos.cuda(), meshlets.cuda(), vidx.cuda(), micro.cuda())
+    cpu = make_scene_from_mesh(40, wb, meshlets, micro, vidx, wq, wm, seed=77, device="cpu", scene_depth=60.0)
+    gpu = cpu.to("cuda")  # same instance placement (the torch CPU and GPU generators differ) ...
+    gpu.bounds, gpu.positions = gb.contiguous().clone(), gq.contiguous().clone()  # ... with the GPU-produced records
+    gpu.meshes.view(torch.int32)[0, 10:16] = gm.view(torch.int32)
+    gpu.bind()
+    want = oracle_frame(cpu, run_cull_meshes=True)
+    got = gpu_frame(renderer, gpu, run_cull_meshes=True)
+    assert_same(want, got, ["total", "visible", "indices"])
+    assert 0 < len(want["visible"]) < want["total"]     # both the frustum and the produced cones reject something
+    assert len(want["indices"]) > 0
