@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=9600)
     ap.add_argument("--warmup", type=int, default=960)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "bounds"])
     ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses the wide packed index extension (<= 8M meshlets)")
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
@@ -76,6 +76,93 @@ class Step:
         self.pf, self.pc = C.byref(self.cframe), C.byref(self.cctx)
 
 
+def bench_bounds(args, r, dev, stream, rank, world, dist):
+    """--workload bounds: the asset-side meshlet bounds producer (oxc_build_meshlet_bounds) over a
+    procedural terrain cut into 8x4-quad patches (64 triangles, 45 vertices per meshlet, vertices not shared
+    between patches).  A step = one call over all meshlets of this GPU."""
+    import math
+
+    P = args.meshlets or 1_000_000
+    steps, warmup = min(args.steps, 50), min(args.warmup, 5)
+    with torch.cuda.stream(stream):
+        side = int(math.ceil(math.sqrt(P)))
+        p = torch.arange(P, device=dev, dtype=torch.int64)
+        pi, pj = (p // side).to(torch.float32), (p % side).to(torch.float32)
+        v = torch.arange(45, device=dev)
+        lu, lv = (v % 9).to(torch.float32), (v // 9).to(torch.float32)
+        x = (pj[:, None] * 8 + lu[None, :]) * 0.05
+        z = (pi[:, None] * 4 + lv[None, :]) * 0.05
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        y = 0.6 * torch.sin(1.7 * x) * torch.cos(1.3 * z) + 0.02 * torch.randn(x.shape, generator=g, device=dev)
+        positions = torch.stack([x, y, z], -1).reshape(-1, 3).contiguous()
+        del x, y, z
+        corners = []
+        for qv in range(4):
+            for qu in range(8):
+                a, b = qv * 9 + qu, qv * 9 + qu + 1
+                d, e = (qv + 1) * 9 + qu, (qv + 1) * 9 + qu + 1
+                corners += [a, d, b, b, d, e]
+        micro = torch.tensor(corners, dtype=torch.uint8, device=dev).repeat(P).contiguous()
+        vidx = torch.arange(45 * P, device=dev, dtype=torch.int32)
+        meshlets = torch.stack([p * 45, p * 192, torch.full_like(p, 45), torch.full_like(p, 64)], 1).to(torch.int32).contiguous()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            out = r.build_meshlet_bounds(positions, meshlets, vidx, micro, stream=stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            out = r.build_meshlet_bounds(positions, meshlets, vidx, micro, stream=stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    value = P * world * steps / dt
+    # algorithmic bytes per meshlet: Meshlet 16 + 45 vertex ids 180 + 192 micro bytes + 45 float3 540 read,
+    # MeshletBounds 16 + {min,max} scratch 24 written and 24 read again by the mesh fold; quantised positions:
+    # 540 read + 45 * 8 written
+    bytes_per_meshlet = (16 + 180 + 192 + 540 + 16 + 24 + 24) + (540 + 360)
+    achieved = bytes_per_meshlet * P * steps / dt / 1e9
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+
+        n = min(P, 20_000)
+        cp, cm, cv, cmi = positions[: 45 * n].cpu(), meshlets[:n].cpu(), vidx[: 45 * n].cpu(), micro[: 192 * n].cpu()
+        tc = time.perf_counter()
+        want = oracle.build_meshlet_bounds(cp, cm, cv, cmi)
+        t_cal = time.perf_counter() - tc
+        reps = int(max(1, min(args.cpu_seconds / max(t_cal, 1e-3), 1000)))
+        tc = time.perf_counter()
+        for _ in range(reps):
+            oracle.build_meshlet_bounds(cp, cm, cv, cmi)
+        dtc = time.perf_counter() - tc
+        ok = bool(torch.equal(want[0], out[0][:n].cpu()) and torch.equal(want[2], out[2][: 45 * n].cpu()))
+        cpu_baseline = {"value": round(n * reps / dtc, 1), "unit": "meshlets/s", "cores": 1, "kind": "port",
+                        "sample": f"{reps} passes over the first {n} meshlets of the same arrays, oracle/oxcull_oracle.c orc_build_meshlet_bounds "
+                                  f"(sequential), {dtc:.1f} s; GPU records of that range byte-identical: {ok}"}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "meshlets/s bounded (asset-side producer)", "value": round(value, 1), "unit": "meshlets/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SURVEY 8f-1: oxc_build_meshlet_bounds over a procedural terrain, 64-triangle / 45-vertex patches",
+                       "meshlets_per_gpu": P, "vertices": 45 * P, "quantize_positions": True},
+            "roofline": {"bound": "hbm", "kernel": "build_meshlet_bounds (quantize_positions + meshlet_bounds + mesh fold)", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_meshlet": bytes_per_meshlet},
+            "cpu_baseline": cpu_baseline}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -95,6 +182,8 @@ def main():
     r = RendererInstance(local_rank)
     lib, ctxp = r._lib, r._ctx
     stream = torch.cuda.Stream(device=dev)
+    if args.workload == "bounds":
+        return bench_bounds(args, r, dev, stream, rank, world, dist)
     sp = C.c_void_p(stream.cuda_stream)
     n_streams = max(1, args.streams) if args.workload == "config2" else 1
     # extra contexts/streams for independent batches in flight (each context owns its scratch)

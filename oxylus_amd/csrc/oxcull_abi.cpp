@@ -54,7 +54,9 @@ struct oxc_ctx {
   };
   Lane lane[kMaxBatch];
   BatchBlob* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call
-  float* bounds_scratch = nullptr;  // oxc_build_meshlet_bounds: per-meshlet {min xyz, max xyz}
+  // oxc_build_meshlet_bounds: per-meshlet {min xyz, max xyz} for all meshlets, then per chunk of kBoundsChunk
+  // meshlets the compacted triangle normals (768 B each) and their counts
+  float* bounds_scratch = nullptr;
   uint32_t bounds_scratch_cap = 0;
   // counter slots
   uint32_t* slots = nullptr;
@@ -790,6 +792,8 @@ oxc_status oxc_debug_decode_bounds(oxc_ctx* ctx, const void* bounds_dptr, uint32
   return OXC_OK;
 }
 
+constexpr uint32_t kBoundsChunk = 1u << 18;  // meshlets per gather/cone launch pair: bounds the normals scratch at 192 MiB
+
 oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc* d, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   if (!d || d->struct_size != sizeof(oxc_meshlet_bounds_desc)) return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: bad desc / struct_size");
@@ -804,19 +808,26 @@ oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc*
   if (d->quantized_positions.dptr && (!d->positions.dptr || d->quantized_positions.bytes < (uint64_t)d->vertex_count * 8u))
     return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: quantized_positions smaller than vertex_count u16x4");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
-  if (d->meshlet_count > ctx->bounds_scratch_cap) {
+  // scratch: [boxes: 24 B per meshlet][fold partials: 256 x 12 words][normals: 768 B per meshlet of one chunk][counts]
+  const uint32_t want = std::max(d->meshlet_count, 1u);
+  if (want > ctx->bounds_scratch_cap) {
     OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old scratch
     if (ctx->bounds_scratch) OXC_HIP(ctx, hipFree(ctx->bounds_scratch));
     ctx->bounds_scratch = nullptr;
     ctx->bounds_scratch_cap = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->bounds_scratch), (size_t)d->meshlet_count * 24u);
+    const size_t bytes = align_up((size_t)want * 24u, 256) + 256u * 48u + (size_t)std::min(kBoundsChunk, want) * (768u + 4u);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->bounds_scratch), bytes);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(bounds scratch)", e);
-    ctx->bounds_scratch_cap = d->meshlet_count;
+    ctx->bounds_scratch_cap = want;
   }
+  const uint32_t chunk = std::min(kBoundsChunk, ctx->bounds_scratch_cap);
+  float* fold = ctx->bounds_scratch + align_up((size_t)ctx->bounds_scratch_cap * 24u, 256) / 4;
+  float* normals = fold + 256 * 12;
   launch_build_meshlet_bounds(static_cast<const float*>(d->positions.dptr), d->vertex_count, d->meshlets.dptr, d->meshlet_count,
                               static_cast<const uint32_t*>(d->indirect_vertex_indices.dptr), static_cast<const uint8_t*>(d->local_triangle_indices.dptr),
-                              d->meshlet_bounds.dptr, static_cast<float*>(d->mesh_bounds.dptr), d->quantized_positions.dptr, ctx->bounds_scratch,
-                              ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
+                              d->meshlet_bounds.dptr, static_cast<float*>(d->mesh_bounds.dptr), d->quantized_positions.dptr, ctx->bounds_scratch, normals,
+                              reinterpret_cast<uint32_t*>(normals + (size_t)chunk * 192), fold, chunk, ctx->num_cus * 8,
+                              static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }

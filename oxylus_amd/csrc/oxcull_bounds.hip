@@ -97,38 +97,184 @@ __global__ __launch_bounds__(256) void k_quantize_positions(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void k_meshlet_bounds(const float* __restrict__ pos, const uint4* __restrict__ meshlets, uint32_t meshlet_count,
+// meshopt_computeClusterBounds from the compacted normals on: computeBoundingSphere(normals, radii = 0,
+// axis_count = 3) -- per-axis extrema, most distant pair as the seed, one growing sweep --, the axis, the
+// minimum dot and the s8 quantisation.  Strictly sequential, exactly as published; `normal_at(i, q)` fetches
+// normal i.  Run by ONE lane per meshlet (k_meshlet_cone) or, for oversized meshlets, redundantly by a wave.
+template <class F>
+OXC_DEV void cone_sequential(F normals8 /* (i0, float q[8][3]): normals i0 .. i0+7, indices clamped to the last one */, uint32_t triangles,
+                             int32_t (&axis_s8)[3], int32_t& cutoff_s8) {
+  const float fmax_ = 3.402823466e+38f;
+  axis_s8[0] = axis_s8[1] = axis_s8[2] = 0;
+  cutoff_s8 = 0;  // no valid triangle: cone data stays 0
+  if (triangles == 0) return;
+  // The three scans below read the normals in blocks of 8 (six 16-byte loads in flight per lane) so that the
+  // per-point work does not wait for memory once per point; the order of the points is untouched.
+  uint32_t pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+  float tmin[3] = {fmax_, fmax_, fmax_}, tmax[3] = {-fmax_, -fmax_, -fmax_};
+  float pminv[3][3], pmaxv[3][3];  // the extremal points themselves (saves re-fetching them by index)
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) pminv[ax][c] = pmaxv[ax][c] = 0.0f;
+  bool first_point = true;
+  for (uint32_t i0 = 0; i0 < triangles; i0 += 8) {
+    float q[8][3];
+    normals8(i0, q);
+    if (first_point) {  // pmin = pmax = 0 initially: the point the sequential code would fetch if nothing ever improves
+#pragma unroll
+      for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) pminv[ax][c] = pmaxv[ax][c] = q[0][c];
+      first_point = false;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = i0 + (uint32_t)j;
+      if (i < triangles) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+          const float tp = q[j][ax];  // dot with a unit axis: the other products are exact zeros
+          if (tp < tmin[ax]) {
+            tmin[ax] = tp;
+            pmin[ax] = i;
+#pragma unroll
+            for (int c = 0; c < 3; c++) pminv[ax][c] = q[j][c];
+          }
+          if (tp > tmax[ax]) {
+            tmax[ax] = tp;
+            pmax[ax] = i;
+#pragma unroll
+            for (int c = 0; c < 3; c++) pmaxv[ax][c] = q[j][c];
+          }
+        }
+      }
+    }
+  }
+  float p1[3] = {pminv[0][0], pminv[0][1], pminv[0][2]}, p2[3] = {pmaxv[0][0], pmaxv[0][1], pmaxv[0][2]};  // paxis = 0 unless strictly longer
+  float paxisdr = 0.0f;
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++) {
+    const float dr = __builtin_sqrtf(dist2(pmaxv[ax], pminv[ax]));
+    if (dr > paxisdr) {
+      paxisdr = dr;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        p1[c] = pminv[ax][c];
+        p2[c] = pmaxv[ax][c];
+      }
+    }
+  }
+  const float paxisd = __builtin_sqrtf(dist2(p2, p1));
+  const float paxisk = paxisd > 0.0f ? paxisd / (2.0f * paxisd) : 0.0f;
+  float center[3] = {p1[0] + (p2[0] - p1[0]) * paxisk, p1[1] + (p2[1] - p1[1]) * paxisk, p1[2] + (p2[2] - p1[2]) * paxisk};
+  float radius = paxisdr / 2.0f;
+  for (uint32_t i0 = 0; i0 < triangles; i0 += 8) {
+    float q[8][3];
+    normals8(i0, q);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (i0 + (uint32_t)j < triangles) {
+        const float d = __builtin_sqrtf(dist2(q[j], center));
+        if (d > radius) {
+          const float k = d > 0.0f ? (d - radius) / (2.0f * d) : 0.0f;
+          center[0] += k * (q[j][0] - center[0]);
+          center[1] += k * (q[j][1] - center[1]);
+          center[2] += k * (q[j][2] - center[2]);
+          radius = (radius + d) / 2.0f;
+        }
+      }
+    }
+  }
+  float axis[3] = {center[0], center[1], center[2]};
+  const float axislength = __builtin_sqrtf((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+  const float invaxislength = axislength == 0.0f ? 0.0f : 1.0f / axislength;
+  axis[0] *= invaxislength;
+  axis[1] *= invaxislength;
+  axis[2] *= invaxislength;
+  float mindp = 1.0f;
+  for (uint32_t i0 = 0; i0 < triangles; i0 += 8) {
+    float q[8][3];
+    normals8(i0, q);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (i0 + (uint32_t)j < triangles) {
+        const float dp = (q[j][0] * axis[0] + q[j][1] * axis[1]) + q[j][2] * axis[2];
+        mindp = (dp < mindp) ? dp : mindp;
+      }
+    }
+  }
+  if (mindp <= 0.1f) {
+    cutoff_s8 = 127;  // cone wider than ~168 degrees: never culls; the axis stays 0
+    return;
+  }
+  const float cone_cutoff = __builtin_sqrtf(1.0f - mindp * mindp);
+#pragma unroll
+  for (int k = 0; k < 3; k++) axis_s8[k] = quantize_snorm8(axis[k]);
+  const float e0 = __builtin_fabsf((float)axis_s8[0] / 127.0f - axis[0]);
+  const float e1 = __builtin_fabsf((float)axis_s8[1] / 127.0f - axis[1]);
+  const float e2 = __builtin_fabsf((float)axis_s8[2] / 127.0f - axis[2]);
+  const int32_t c = (int32_t)(127.0f * (((cone_cutoff + e0) + e1) + e2) + 1.0f);  // rounded up, not to nearest
+  cutoff_s8 = c > 127 ? 127 : c;
+}
+
+// GPU::MeshletBounds: center.xyz u16, cone_axis.xy s8, extent.xyz u16, cone_axis.z s8, cutoff s8 (AssetManager_GLTF.cpp:717-735)
+OXC_DEV uint4 pack_bounds(const float* bmin, const float* bmax, const int32_t* axis_s8, int32_t cutoff_s8) {
+  uint32_t ch[3], eh[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    ch[c] = quantize_half((bmax[c] + bmin[c]) * 0.5f);
+    eh[c] = quantize_half(bmax[c] - bmin[c]);
+  }
+  uint4 b;
+  b.x = ch[0] | (ch[1] << 16);
+  b.y = ch[2] | (((uint32_t)axis_s8[0] & 0xFFu) << 16) | (((uint32_t)axis_s8[1] & 0xFFu) << 24);
+  b.z = eh[0] | (eh[1] << 16);
+  b.w = eh[2] | (((uint32_t)axis_s8[2] & 0xFFu) << 16) | (((uint32_t)cutoff_s8 & 0xFFu) << 24);
+  return b;
+}
+
+constexpr uint32_t kConeDone = 0xFFFFFFFFu;  // normal_counts[] sentinel: the gather kernel already wrote the record
+
+// Kernel 1, one wave per meshlet, lane = triangle: gather the corners, fold the AABB, form the triangle normals
+// and write the non-degenerate ones IN TRIANGLE ORDER to normals[m][0..count) (768 B per meshlet, coalesced).
+// Meshlets of more than 64 triangles (not produced by the engine) are finished here through an LDS strip.
+__global__ __launch_bounds__(256) void k_meshlet_gather(const float* __restrict__ pos, const uint4* __restrict__ meshlets, uint32_t first, uint32_t count,
                                                         const uint32_t* __restrict__ vidx, const uint8_t* __restrict__ micro, uint4* __restrict__ out,
-                                                        float* __restrict__ meshlet_minmax) {
+                                                        float* __restrict__ meshlet_minmax, float* __restrict__ normals_out,
+                                                        uint32_t* __restrict__ normal_counts) {
   __shared__ float s_normals[4][kMaxBoundsTris][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float(*normals)[3] = s_normals[wave];
+  float(*lds_normals)[3] = s_normals[wave];
   const float fmax_ = 3.402823466e+38f;
-  for (uint32_t m = blockIdx.x * 4 + wave; m < meshlet_count; m += gridDim.x * 4) {
+  for (uint32_t k = blockIdx.x * 4 + wave; k < count; k += gridDim.x * 4) {
+    const uint32_t m = first + k;
     const uint4 ml = meshlets[m];  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
     const uint32_t tcount = min(ml.w, kMaxBoundsTris);
+    const bool big = ml.w > 64u;  // wave-uniform
+    float* gnormals = normals_out + (size_t)k * 192;
     float bmin[3] = {fmax_, fmax_, fmax_}, bmax[3] = {-fmax_, -fmax_, -fmax_};
     uint32_t bmin_i[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bmax_i[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     uint32_t triangles = 0;
     for (uint32_t t0 = 0; t0 < ml.w; t0 += 64) {
       const uint32_t t = t0 + (uint32_t)lane;
       float p[3][3];
-      bool have = t < ml.w;
+      const bool have = t < ml.w;
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
+      for (int c3 = 0; c3 < 3; c3++) {
         uint32_t vi = 0;
-        if (have) vi = vidx[ml.x + micro[ml.y + t * 3u + (uint32_t)k]];
+        if (have) vi = vidx[ml.x + micro[ml.y + t * 3u + (uint32_t)c3]];
 #pragma unroll
-        for (int c = 0; c < 3; c++) p[k][c] = have ? pos[(size_t)vi * 3 + c] : 0.0f;
+        for (int c = 0; c < 3; c++) p[c3][c] = have ? pos[(size_t)vi * 3 + c] : 0.0f;
       }
       if (have) {  // AssetManager_GLTF.cpp:690-706 (glm::min(a, b) = b < a ? b : a)
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int c3 = 0; c3 < 3; c3++) {
 #pragma unroll
           for (int c = 0; c < 3; c++) {
-            const uint32_t corner = t * 3u + (uint32_t)k;
-            if (p[k][c] < bmin[c]) { bmin[c] = p[k][c]; bmin_i[c] = corner; }
-            if (bmax[c] < p[k][c]) { bmax[c] = p[k][c]; bmax_i[c] = corner; }
+            const uint32_t corner = t * 3u + (uint32_t)c3;
+            if (p[c3][c] < bmin[c]) { bmin[c] = p[c3][c]; bmin_i[c] = corner; }
+            if (bmax[c] < p[c3][c]) { bmax[c] = p[c3][c]; bmax_i[c] = corner; }
           }
         }
       }
@@ -143,110 +289,64 @@ __global__ __launch_bounds__(256) void k_meshlet_bounds(const float* __restrict_
       const uint64_t vb = __builtin_amdgcn_ballot_w64(valid);
       if (valid) {
         const uint32_t r = triangles + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb, 0u));
-        normals[r][0] = nx / area;
-        normals[r][1] = ny / area;
-        normals[r][2] = nz / area;
+        const float n0 = nx / area, n1 = ny / area, n2 = nz / area;
+        if (big) {
+          lds_normals[r][0] = n0;
+          lds_normals[r][1] = n1;
+          lds_normals[r][2] = n2;
+        } else {
+          typedef float f3 __attribute__((ext_vector_type(3)));
+          *reinterpret_cast<f3 __attribute__((aligned(4)))*>(gnormals + r * 3) = f3{n0, n1, n2};  // one 12-byte store
+        }
       }
       triangles += (uint32_t)__popcll((unsigned long long)vb);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+    // Two distinct bit patterns compare equal only for +0.0 / -0.0, so a plain value reduction already gives
+    // the sequential fold's result unless a result is a zero; only then the (value, corner index) form runs.
+    {
+      float fmin_[3], fmax2_[3];
+      bool zero = false;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      wave_argmin(bmin[c], bmin_i[c]);
-      wave_argmax(bmax[c], bmax_i[c]);
-    }
-    int32_t axis_s8[3] = {0, 0, 0};
-    int32_t cutoff_s8 = 0;  // no valid triangle: cone data stays 0
-    if (triangles > 0) {    // wave-uniform
-      // ---- computeBoundingSphere(normals, axis_count = 3, radii = 0): per-axis extrema ...
-      uint32_t pmin[3], pmax[3];
+      for (int c = 0; c < 3; c++) {
+        fmin_[c] = wave_min_f(bmin[c]);
+        fmax2_[c] = wave_max_f(bmax[c]);
+        zero = zero || fmin_[c] == 0.0f || fmax2_[c] == 0.0f;
+      }
+      if (zero) {  // wave-uniform
 #pragma unroll
-      for (int ax = 0; ax < 3; ax++) {
-        float vmin = fmax_, vmax = -fmax_;
-        uint32_t imin = 0xFFFFFFFFu, imax = 0xFFFFFFFFu;
-        for (uint32_t i = (uint32_t)lane; i < triangles; i += 64) {
-          const float tp = normals[i][ax];
-          if (tp < vmin) { vmin = tp; imin = i; }
-          if (tp > vmax) { vmax = tp; imax = i; }
+        for (int c = 0; c < 3; c++) {
+          wave_argmin(bmin[c], bmin_i[c]);
+          wave_argmax(bmax[c], bmax_i[c]);
         }
-        wave_argmin(vmin, imin);
-        wave_argmax(vmax, imax);
-        // the sequential scan starts from index 0 with +-FLT_MAX and only moves on a strict improvement
-        pmin[ax] = (vmin < fmax_) ? imin : 0u;
-        pmax[ax] = (vmax > -fmax_) ? imax : 0u;
-      }
-      // ... the most distant pair seeds the sphere ...
-      int paxis = 0;
-      float paxisdr = 0.0f;
-#pragma unroll
-      for (int ax = 0; ax < 3; ax++) {
-        const float dr = __builtin_sqrtf(dist2(normals[pmax[ax]], normals[pmin[ax]]));
-        if (dr > paxisdr) {
-          paxisdr = dr;
-          paxis = ax;
-        }
-      }
-      const uint32_t i1 = paxis == 0 ? pmin[0] : (paxis == 1 ? pmin[1] : pmin[2]);
-      const uint32_t i2 = paxis == 0 ? pmax[0] : (paxis == 1 ? pmax[1] : pmax[2]);
-      const float p1[3] = {normals[i1][0], normals[i1][1], normals[i1][2]};
-      const float p2[3] = {normals[i2][0], normals[i2][1], normals[i2][2]};
-      const float paxisd = __builtin_sqrtf(dist2(p2, p1));
-      const float paxisk = paxisd > 0.0f ? paxisd / (2.0f * paxisd) : 0.0f;
-      float center[3] = {p1[0] + (p2[0] - p1[0]) * paxisk, p1[1] + (p2[1] - p1[1]) * paxisk, p1[2] + (p2[2] - p1[2]) * paxisk};
-      float radius = paxisdr / 2.0f;
-      // ... and one order-dependent sweep grows it (every lane runs the same uniform loop)
-      for (uint32_t i = 0; i < triangles; i++) {
-        const float q[3] = {normals[i][0], normals[i][1], normals[i][2]};
-        const float d = __builtin_sqrtf(dist2(q, center));
-        if (d > radius) {
-          const float k = d > 0.0f ? (d - radius) / (2.0f * d) : 0.0f;
-          center[0] += k * (q[0] - center[0]);
-          center[1] += k * (q[1] - center[1]);
-          center[2] += k * (q[2] - center[2]);
-          radius = (radius + d) / 2.0f;
-        }
-      }
-      float axis[3] = {center[0], center[1], center[2]};
-      const float axislength = __builtin_sqrtf((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
-      const float invaxislength = axislength == 0.0f ? 0.0f : 1.0f / axislength;
-      axis[0] *= invaxislength;
-      axis[1] *= invaxislength;
-      axis[2] *= invaxislength;
-      float mindp = 1.0f;
-      for (uint32_t i = (uint32_t)lane; i < triangles; i += 64) {
-        const float dp = (normals[i][0] * axis[0] + normals[i][1] * axis[1]) + normals[i][2] * axis[2];
-        mindp = (dp < mindp) ? dp : mindp;
-      }
-      mindp = wave_min_f(mindp);
-      if (mindp <= 0.1f) {
-        cutoff_s8 = 127;  // cone wider than ~168 degrees: never culls; the axis stays 0
       } else {
-        const float cone_cutoff = __builtin_sqrtf(1.0f - mindp * mindp);
 #pragma unroll
-        for (int k = 0; k < 3; k++) axis_s8[k] = quantize_snorm8(axis[k]);
-        const float e0 = __builtin_fabsf((float)axis_s8[0] / 127.0f - axis[0]);
-        const float e1 = __builtin_fabsf((float)axis_s8[1] / 127.0f - axis[1]);
-        const float e2 = __builtin_fabsf((float)axis_s8[2] / 127.0f - axis[2]);
-        const int32_t c = (int32_t)(127.0f * (((cone_cutoff + e0) + e1) + e2) + 1.0f);  // rounded up, not to nearest
-        cutoff_s8 = c > 127 ? 127 : c;
+        for (int c = 0; c < 3; c++) {
+          bmin[c] = fmin_[c];
+          bmax[c] = fmax2_[c];
+        }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next meshlet
+    if (big) {  // finish here: every lane runs the sequential cone code over the LDS strip (wave-uniform)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+      int32_t axis_s8[3], cutoff_s8;
+      cone_sequential(
+          [&](uint32_t i0, float(*q)[3]) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const uint32_t i = min(i0 + (uint32_t)j, triangles - 1u);
+              q[j][0] = lds_normals[i][0];
+              q[j][1] = lds_normals[i][1];
+              q[j][2] = lds_normals[i][2];
+            }
+          },
+          triangles, axis_s8, cutoff_s8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next meshlet
+      if (lane == 0) out[m] = pack_bounds(bmin, bmax, axis_s8, cutoff_s8);
+    }
     if (lane == 0) {
-      uint32_t ch[3], eh[3];
+      normal_counts[k] = big ? kConeDone : triangles;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {  // AssetManager_GLTF.cpp:717-727
-        ch[c] = quantize_half((bmax[c] + bmin[c]) * 0.5f);
-        eh[c] = quantize_half(bmax[c] - bmin[c]);
-      }
-      uint4 b;  // GPU::MeshletBounds: center.xyz u16, cone_axis.xy s8, extent.xyz u16, cone_axis.z s8, cutoff s8
-      b.x = ch[0] | (ch[1] << 16);
-      b.y = ch[2] | (((uint32_t)axis_s8[0] & 0xFFu) << 16) | (((uint32_t)axis_s8[1] & 0xFFu) << 24);
-      b.z = eh[0] | (eh[1] << 16);
-      b.w = eh[2] | (((uint32_t)axis_s8[2] & 0xFFu) << 16) | (((uint32_t)cutoff_s8 & 0xFFu) << 24);
-      out[m] = b;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {  // reduced in meshlet order by k_mesh_bounds_reduce (AssetManager_GLTF.cpp:736-737)
+      for (int c = 0; c < 3; c++) {  // folded in meshlet order by k_mesh_bounds_reduce (AssetManager_GLTF.cpp:736-737)
         meshlet_minmax[(size_t)m * 6 + c] = bmin[c];
         meshlet_minmax[(size_t)m * 6 + 3 + c] = bmax[c];
       }
@@ -254,23 +354,56 @@ __global__ __launch_bounds__(256) void k_meshlet_bounds(const float* __restrict_
   }
 }
 
-// Mesh AABB = the sequential `b < a ? b : a` fold over the meshlets' boxes in meshlet order
-// (AssetManager_GLTF.cpp:736-737,741-744): one block, lexicographic (value, meshlet index) reduction.
-__global__ __launch_bounds__(1024) void k_mesh_bounds_reduce(const float* __restrict__ meshlet_minmax, uint32_t meshlet_count, float* __restrict__ out6) {
-  __shared__ float s_v[16][6];
-  __shared__ uint32_t s_i[16][6];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float fmax_ = 3.402823466e+38f;
-  float v[6] = {fmax_, fmax_, fmax_, -fmax_, -fmax_, -fmax_};
-  uint32_t idx[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-  for (uint32_t m = threadIdx.x; m < meshlet_count; m += blockDim.x) {
+// Kernel 2, one LANE per meshlet: the order-dependent cone code (64 lanes = 64 meshlets instead of 64 copies of one).
+__global__ __launch_bounds__(256) void k_meshlet_cone(uint32_t first, uint32_t count, const float* __restrict__ meshlet_minmax,
+                                                      const float* __restrict__ normals_in, const uint32_t* __restrict__ normal_counts,
+                                                      uint4* __restrict__ out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const uint32_t triangles = normal_counts[k];
+  if (triangles == kConeDone) return;
+  const float* n = normals_in + (size_t)k * 192;
+  int32_t axis_s8[3], cutoff_s8;
+  cone_sequential(
+      [&](uint32_t i0, float(*q)[3]) {  // 8 normals = 96 contiguous bytes = six 16-byte loads; i0 + 7 <= 63 stays inside the 64-normal row
+        const float4* src = reinterpret_cast<const float4*>(n + i0 * 3);
+        float f[24];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float lo = meshlet_minmax[(size_t)m * 6 + c], hi = meshlet_minmax[(size_t)m * 6 + 3 + c];
-      if (lo < v[c]) { v[c] = lo; idx[c] = m; }
-      if (v[3 + c] < hi) { v[3 + c] = hi; idx[3 + c] = m; }
-    }
+        for (int v = 0; v < 6; v++) {
+          const float4 t = src[v];
+          f[v * 4 + 0] = t.x;
+          f[v * 4 + 1] = t.y;
+          f[v * 4 + 2] = t.z;
+          f[v * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          q[j][0] = f[j * 3 + 0];
+          q[j][1] = f[j * 3 + 1];
+          q[j][2] = f[j * 3 + 2];
+        }
+      },
+      triangles, axis_s8, cutoff_s8);
+  const uint32_t m = first + k;
+  float bmin[3], bmax[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    bmin[c] = meshlet_minmax[(size_t)m * 6 + c];
+    bmax[c] = meshlet_minmax[(size_t)m * 6 + 3 + c];
   }
+  out[m] = pack_bounds(bmin, bmax, axis_s8, cutoff_s8);
+}
+
+// Mesh AABB = the sequential `b < a ? b : a` fold over the meshlets' boxes in meshlet order
+// (AssetManager_GLTF.cpp:736-737,741-744) as a lexicographic (value, meshlet index) reduction, which is
+// associative: kMeshFoldBlocks blocks fold contiguous ranges into partials {6 values, 6 indices}, one block
+// folds the partials and writes centre / extent.
+constexpr uint32_t kMeshFoldBlocks = 256;
+
+OXC_DEV void block_fold6(float (&v)[6], uint32_t (&idx)[6], float (*s_v)[6], uint32_t (*s_i)[6]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = (int)(blockDim.x >> 6);
+  const float fmax_ = 3.402823466e+38f;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     wave_argmin(v[c], idx[c]);
@@ -287,34 +420,85 @@ __global__ __launch_bounds__(1024) void k_mesh_bounds_reduce(const float* __rest
   if (wave == 0) {
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-      v[c] = lane < 16 ? s_v[lane][c] : (c < 3 ? fmax_ : -fmax_);
-      idx[c] = lane < 16 ? s_i[lane][c] : 0xFFFFFFFFu;
+      v[c] = lane < nwaves ? s_v[lane][c] : (c < 3 ? fmax_ : -fmax_);
+      idx[c] = lane < nwaves ? s_i[lane][c] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       wave_argmin(v[c], idx[c]);
       wave_argmax(v[3 + c], idx[3 + c]);
     }
-    if (lane < 3) {
-      // (lane-indexed pick without dynamic register indexing)
-      const float lo = lane == 0 ? v[0] : (lane == 1 ? v[1] : v[2]);
-      const float hi = lane == 0 ? v[3] : (lane == 1 ? v[4] : v[5]);
-      out6[lane] = (hi + lo) * 0.5f;
-      out6[3 + lane] = hi - lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mesh_bounds_partial(const float* __restrict__ meshlet_minmax, uint32_t meshlet_count, float* __restrict__ part_v,
+                                                             uint32_t* __restrict__ part_i) {
+  __shared__ float s_v[4][6];
+  __shared__ uint32_t s_i[4][6];
+  const float fmax_ = 3.402823466e+38f;
+  float v[6] = {fmax_, fmax_, fmax_, -fmax_, -fmax_, -fmax_};
+  uint32_t idx[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < meshlet_count; m += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float lo = meshlet_minmax[(size_t)m * 6 + c], hi = meshlet_minmax[(size_t)m * 6 + 3 + c];
+      if (lo < v[c]) { v[c] = lo; idx[c] = m; }
+      if (v[3 + c] < hi) { v[3 + c] = hi; idx[3 + c] = m; }
+    }
+  }
+  block_fold6(v, idx, s_v, s_i);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      part_v[blockIdx.x * 6 + c] = v[c];
+      part_i[blockIdx.x * 6 + c] = idx[c];
     }
   }
 }
 
+__global__ __launch_bounds__(256) void k_mesh_bounds_final(const float* __restrict__ part_v, const uint32_t* __restrict__ part_i, uint32_t parts,
+                                                           float* __restrict__ out6) {
+  __shared__ float s_v[4][6];
+  __shared__ uint32_t s_i[4][6];
+  const float fmax_ = 3.402823466e+38f;
+  float v[6] = {fmax_, fmax_, fmax_, -fmax_, -fmax_, -fmax_};
+  uint32_t idx[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  if (threadIdx.x < parts) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      v[c] = part_v[threadIdx.x * 6 + c];
+      idx[c] = part_i[threadIdx.x * 6 + c];
+    }
+  }
+  block_fold6(v, idx, s_v, s_i);
+  if (threadIdx.x < 3) {
+    const int lane = (int)threadIdx.x;  // (lane-indexed pick without dynamic register indexing)
+    const float lo = lane == 0 ? v[0] : (lane == 1 ? v[1] : v[2]);
+    const float hi = lane == 0 ? v[3] : (lane == 1 ? v[4] : v[5]);
+    out6[lane] = (hi + lo) * 0.5f;
+    out6[3 + lane] = hi - lo;
+  }
+}
+
 void launch_build_meshlet_bounds(const float* pos, uint32_t vertex_count, const void* meshlets, uint32_t meshlet_count, const uint32_t* vidx,
-                                 const uint8_t* micro, void* out_bounds, float* out_mesh6, void* out_qpos, float* meshlet_minmax, uint32_t max_grid,
-                                 hipStream_t s) {
+                                 const uint8_t* micro, void* out_bounds, float* out_mesh6, void* out_qpos, float* meshlet_minmax, float* normals,
+                                 uint32_t* normal_counts, float* fold_scratch /* 256 * 12 words */, uint32_t chunk, uint32_t max_grid, hipStream_t s) {
   if (out_qpos && vertex_count)
     hipLaunchKernelGGL(k_quantize_positions, dim3(min((vertex_count + 255u) / 256u, max_grid)), dim3(256), 0, s, pos, vertex_count,
                        reinterpret_cast<uint2*>(out_qpos));
-  if (meshlet_count)
-    hipLaunchKernelGGL(k_meshlet_bounds, dim3(min((meshlet_count + 3u) / 4u, max_grid)), dim3(256), 0, s, pos, reinterpret_cast<const uint4*>(meshlets),
-                       meshlet_count, vidx, micro, reinterpret_cast<uint4*>(out_bounds), meshlet_minmax);
-  hipLaunchKernelGGL(k_mesh_bounds_reduce, dim3(1), dim3(1024), 0, s, meshlet_minmax, meshlet_count, out_mesh6);
+  // the normals scratch (768 B per meshlet) is bounded by processing `chunk` meshlets at a time
+  for (uint32_t first = 0; first < meshlet_count; first += chunk) {
+    const uint32_t n = min(chunk, meshlet_count - first);
+    hipLaunchKernelGGL(k_meshlet_gather, dim3(min((n + 3u) / 4u, max_grid * 2u)), dim3(256), 0, s, pos, reinterpret_cast<const uint4*>(meshlets), first, n, vidx,
+                       micro, reinterpret_cast<uint4*>(out_bounds), meshlet_minmax, normals, normal_counts);
+    hipLaunchKernelGGL(k_meshlet_cone, dim3((n + 255u) / 256u), dim3(256), 0, s, first, n, meshlet_minmax, normals, normal_counts,
+                       reinterpret_cast<uint4*>(out_bounds));
+  }
+  // partials live behind the per-meshlet boxes (the caller sized meshlet_minmax for it)
+  float* part_v = fold_scratch;
+  uint32_t* part_i = reinterpret_cast<uint32_t*>(fold_scratch + kMeshFoldBlocks * 6);
+  hipLaunchKernelGGL(k_mesh_bounds_partial, dim3(kMeshFoldBlocks), dim3(256), 0, s, meshlet_minmax, meshlet_count, part_v, part_i);
+  hipLaunchKernelGGL(k_mesh_bounds_final, dim3(1), dim3(256), 0, s, part_v, part_i, kMeshFoldBlocks, out_mesh6);
 }
 
 }  // namespace oxc

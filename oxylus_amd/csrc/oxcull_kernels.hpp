@@ -165,7 +165,7 @@ void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t 
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
 // oxcull_bounds.hip: meshlet bounds producer
 void launch_build_meshlet_bounds(const float* pos, uint32_t vertex_count, const void* meshlets, uint32_t meshlet_count, const uint32_t* vidx,
-                                 const uint8_t* micro, void* out_bounds, float* out_mesh6, void* out_qpos, float* meshlet_minmax, uint32_t max_grid,
-                                 hipStream_t s);
+                                 const uint8_t* micro, void* out_bounds, float* out_mesh6, void* out_qpos, float* meshlet_minmax, float* normals,
+                                 uint32_t* normal_counts, float* fold_scratch, uint32_t chunk, uint32_t max_grid, hipStream_t s);
 
 }  // namespace oxc
