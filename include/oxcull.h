@@ -262,6 +262,15 @@ typedef struct oxc_meshlet_bounds_desc {
 
 oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc* desc, void* hip_stream);
 
+/* ---- hierarchical page buffer producer ------------------------------------------
+ * Replaces the "vsm downsample hpb" pass (Oxylus/src/Render/Passes/Shadowmaps.cpp:331-366, pipeline
+ * rmvsm_downsample_hpb, Shaders/passes/rmvsm_downsample_hpb.slang:10-33): level 0 of the pyramid is 1 where
+ * the virtual page is Visible && Backed && Dirty (VSMPageState flags 1, 4, 2: rmvsm.slang:16-28,49-70), level i
+ * is the OR of the 2x2 children in level i-1 (texels outside the source level read as 0).
+ * `virtual_page_table` is the R32UI Texture2DArray as a linear u32 array [layers][height][width];
+ * the extent of level i is max(1, width >> i) x max(1, height >> i) (Shadowmaps.cpp:342-346). */
+oxc_status oxc_generate_hpb(oxc_ctx* ctx, oxc_buffer virtual_page_table, const oxc_image_array_u8* hpb_attachment, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         l.orc_cull_triangles_mt.restype = u32
         l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
         l.orc_entities_update_and_cull.restype = u32
+        l.orc_generate_hpb.argtypes = [vp, C.POINTER(Hpb)]
+        l.orc_generate_hpb.restype = None
         l.orc_quantize_half.argtypes = [f32]
         l.orc_quantize_half.restype = C.c_uint16
         l.orc_quantize_snorm.argtypes = [f32, C.c_int]
@@ -277,3 +279,8 @@ def build_meshlet_bounds(positions: torch.Tensor, meshlets: torch.Tensor, vidx: 
     lib().orc_build_meshlet_bounds(_p(positions.contiguous()), V, _p(meshlets.contiguous()), M, _p(vidx.contiguous()), _p(micro.contiguous()),
                                    _p(bounds), _p(mesh6), _p(qpos))
     return bounds, mesh6, qpos
+
+
+def generate_hpb(page_table: torch.Tensor, hpb: Hpb):
+    """page_table: int32 [layers, h, w] (R32UI page metadata); fills every level of `hpb` in place."""
+    lib().orc_generate_hpb(_p(page_table.contiguous()), C.byref(hpb))

@@ -992,3 +992,38 @@ void orc_build_meshlet_bounds(const float* positions, uint32_t vertex_count, con
     out_mesh6[3 + k] = mesh_max[k] - mesh_min[k];
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * HPB producer (passes/rmvsm_downsample_hpb.slang:10-33, Shadowmaps.cpp:331-366).
+ * ------------------------------------------------------------------------------------------ */
+void orc_generate_hpb(const uint32_t* page_table, orc_hpb* hpb) {
+  uint8_t* base = (uint8_t*)(uintptr_t)hpb->data;
+  for (uint32_t lvl = 0; lvl < hpb->levels; lvl++) {
+    uint32_t w = hpb->width >> lvl, h = hpb->height >> lvl; /* Shadowmaps.cpp:342-346 */
+    w = w ? w : 1u;
+    h = h ? h : 1u;
+    uint8_t* dst = base + hpb->level_offset[lvl];
+    if (lvl == 0) { /* IS_FIRST_PASS: page.is_visible() && page.is_backed() && page.is_dirty() */
+      for (size_t i = 0; i < (size_t)hpb->layers * w * h; i++) {
+        uint32_t page = page_table[i];
+        dst[i] = (uint8_t)(((page & 1u) != 0u) && ((page & 4u) != 0u) && ((page & 2u) != 0u));
+      }
+      continue;
+    }
+    uint32_t sw = hpb->width >> (lvl - 1), sh = hpb->height >> (lvl - 1);
+    sw = sw ? sw : 1u;
+    sh = sh ? sh : 1u;
+    const uint8_t* src = base + hpb->level_offset[lvl - 1];
+    for (uint32_t z = 0; z < hpb->layers; z++)
+      for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+          uint32_t acc = 0; /* tl | tr | bl | br, out-of-range Loads return 0 */
+          for (uint32_t dy = 0; dy < 2; dy++)
+            for (uint32_t dx = 0; dx < 2; dx++) {
+              uint32_t sx = x * 2 + dx, sy = y * 2 + dy;
+              if (sx < sw && sy < sh) acc |= src[((size_t)z * sh + sy) * sw + sx];
+            }
+          dst[((size_t)z * h + y) * w + x] = (uint8_t)(acc == 1u);
+        }
+  }
+}

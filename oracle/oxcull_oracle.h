@@ -238,6 +238,10 @@ void orc_build_meshlet_bounds(const float* positions, uint32_t vertex_count, con
                               const uint32_t* indirect_vertex_indices, const uint8_t* local_triangle_indices,
                               orc_meshlet_bounds* out_bounds, float* out_mesh6, uint16_t* out_qpos);
 
+/* ---- HPB producer.  passes/rmvsm_downsample_hpb.slang:10-33 driven by
+ * Passes/Shadowmaps.cpp:331-366; page flags rmvsm.slang:16-28 ([Flags]: Visible 1, Dirty 2, Backed 4). */
+void orc_generate_hpb(const uint32_t* page_table, orc_hpb* hpb);
+
 #ifdef __cplusplus
 }
 #endif

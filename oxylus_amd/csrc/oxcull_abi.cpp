@@ -832,4 +832,19 @@ oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc*
   return OXC_OK;
 }
 
+oxc_status oxc_generate_hpb(oxc_ctx* ctx, oxc_buffer page_table, const oxc_image_array_u8* h, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!h || !h->dptr) return fail(ctx, OXC_INVALID_ARG, "generate_hpb: null hpb_attachment");
+  if (h->levels == 0 || h->levels > 13 || h->width == 0 || h->height == 0) return fail(ctx, OXC_INVALID_ARG, "generate_hpb: bad extent / level count");
+  const uint64_t pages = (uint64_t)h->width * h->height * h->layers;
+  if (pages && (!page_table.dptr || page_table.bytes < pages * 4u)) return fail(ctx, OXC_INVALID_ARG, "generate_hpb: virtual_page_table smaller than width*height*layers u32");
+  for (uint32_t k = 0; k < h->levels; k++)
+    if (h->level_offset[k] > 0xFFFFFFFFull) return fail(ctx, OXC_INVALID_ARG, "generate_hpb: level offsets must fit 32 bits");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  launch_generate_hpb(static_cast<const uint32_t*>(page_table.dptr), static_cast<uint8_t*>(h->dptr), h->width, h->height, h->layers, h->levels, h->level_offset,
+                      static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
 }  // extern "C"

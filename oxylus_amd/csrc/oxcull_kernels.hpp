@@ -163,6 +163,9 @@ void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid,
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
+// oxcull_hpb.hip: hierarchical page buffer producer
+void launch_generate_hpb(const uint32_t* page_table, uint8_t* data, uint32_t w, uint32_t h, uint32_t layers, uint32_t levels, const uint64_t* level_offset,
+                         hipStream_t s);
 // oxcull_bounds.hip: meshlet bounds producer
 void launch_build_meshlet_bounds(const float* pos, uint32_t vertex_count, const void* meshlets, uint32_t meshlet_count, const uint32_t* vidx,
                                  const uint8_t* micro, void* out_bounds, float* out_mesh6, void* out_qpos, float* meshlet_minmax, float* normals,

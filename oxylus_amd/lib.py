@@ -157,6 +157,7 @@ EXPORTS = [
     "oxc_profile_begin",
     "oxc_profile_end",
     "oxc_build_meshlet_bounds",
+    "oxc_generate_hpb",
 ]
 
 
@@ -199,6 +200,7 @@ def load() -> C.CDLL:
     lib.oxc_profile_begin.argtypes = [vp]
     lib.oxc_profile_end.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.oxc_build_meshlet_bounds.argtypes = [vp, C.POINTER(MeshletBoundsDesc), vp]
+    lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
             getattr(lib, name).restype = C.c_int

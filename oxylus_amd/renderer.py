@@ -280,6 +280,12 @@ class RendererInstance:
         self._check(self._lib.oxc_build_meshlet_bounds(self._ctx, C.byref(d), self._stream(stream)))
         return bounds, mesh6, qpos
 
+    def generate_hpb(self, page_table: torch.Tensor, hpb: "HpbAttachment", stream=None):
+        """SURVEY 8(f)-3, Shadowmaps.cpp:331-366: page_table int32 [layers, h, w] -> every level of `hpb`."""
+        im = hpb.c()
+        self._keep = (page_table, hpb)
+        self._check(self._lib.oxc_generate_hpb(self._ctx, L.Buffer(C.c_void_p(page_table.data_ptr()), page_table.numel() * 4), C.byref(im), self._stream(stream)))
+
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))
 
