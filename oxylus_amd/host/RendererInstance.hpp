@@ -142,6 +142,17 @@ public:
     context.draw_geometry_cmd_buffer = c.draw_geometry_cmd_buffer;
   }
 
+  // Producers around the cull path: the downsample_hpb_pass of draw_virtual_shadowmap
+  // (Passes/Shadowmaps.cpp:331-366) and the per-meshlet bounds loop of the asset import
+  // (Asset/AssetManager_GLTF.cpp:573-578,683-744).
+  auto generate_hpb(oxc_buffer virtual_page_table, const oxc_image_array_u8& hpb_attachment) -> void {
+    check(oxc_generate_hpb(ctx_, virtual_page_table, &hpb_attachment, stream_));
+  }
+  auto build_meshlet_bounds(oxc_meshlet_bounds_desc desc) -> void {
+    desc.struct_size = sizeof desc;
+    check(oxc_build_meshlet_bounds(ctx_, &desc, stream_));
+  }
+
   oxc_ctx* native() { return ctx_; }
 
 private:
