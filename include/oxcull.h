@@ -271,6 +271,34 @@ oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc*
  * the extent of level i is max(1, width >> i) x max(1, height >> i) (Shadowmaps.cpp:342-346). */
 oxc_status oxc_generate_hpb(oxc_ctx* ctx, oxc_buffer virtual_page_table, const oxc_image_array_u8* hpb_attachment, void* hip_stream);
 
+/* ---- terrain patch cull ---------------------------------------------------------
+ * Replaces RendererInstance::cull_terrain (Oxylus/src/Render/Passes/Terrain.cpp:159-216) + pipeline
+ * terrain_cull (Shaders/passes/terrain_cull.slang:17-83): one thread per patch, world-space AABB from the
+ * patch grid and the patch_minmax image, the same test_frustum / project_aabb / test_occlusion and early/late
+ * mask protocol as cull_meshlets_hiz, survivors appended to visible_patches and counted in
+ * DrawIndirectCommand.instance_count.  The reference appends in atomic order; here the list is ascending. */
+typedef struct oxc_terrain_context {
+  uint32_t struct_size;
+  uint32_t cull_flags;               /* OXC_CULL_* (TestFrustum, TestOcclusion, LatePass) */
+  oxc_cull_camera cull_camera;       /* projection_view, near_clip; mesh_instance_count is set by the callee (Terrain.cpp:171) */
+  /* the GPU::TerrainData fields the shader reads (SceneGPU.hpp:440-453, scene.slang:634-661) */
+  float world_min[2];
+  float world_size[2];
+  uint32_t patch_count[2];
+  float base_height;
+  float height_scale;
+  oxc_image patch_minmax_attachment; /* RG32F, patch_count.x x patch_count.y, levels = 1: {min, max} normalised height per patch */
+  oxc_image hiz_attachment;          /* read when TestOcclusion or LatePass */
+  oxc_buffer visible_patches_buffer; /* out: u32[patch_total] */
+  oxc_buffer patch_visibility_mask_buffer; /* in/out: u32[ceil(patch_total / 32)] */
+  oxc_buffer draw_cmd_buffer;        /* out (callee-owned, like the reference's scratch_buffer): VkDrawIndirectCommand {4, instance_count, 0, 0} */
+} oxc_terrain_context;
+
+oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* context, void* hip_stream);
+
+/* Harness helper: copy n u32 from device memory (e.g. a callee-owned indirect command) to the host; synchronises the stream. */
+oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

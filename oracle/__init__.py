@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         l.orc_cull_triangles_mt.restype = u32
         l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
         l.orc_entities_update_and_cull.restype = u32
+        l.orc_cull_terrain.argtypes = [vp, vp, u32, u32, f32, f32, vp, vp, u32, C.POINTER(Hiz), vp, vp]
+        l.orc_cull_terrain.restype = u32
         l.orc_generate_hpb.argtypes = [vp, C.POINTER(Hpb)]
         l.orc_generate_hpb.restype = None
         l.orc_quantize_half.argtypes = [f32]
@@ -284,3 +286,14 @@ def build_meshlet_bounds(positions: torch.Tensor, meshlets: torch.Tensor, vidx: 
 def generate_hpb(page_table: torch.Tensor, hpb: Hpb):
     """page_table: int32 [layers, h, w] (R32UI page metadata); fills every level of `hpb` in place."""
     lib().orc_generate_hpb(_p(page_table.contiguous()), C.byref(hpb))
+
+
+def cull_terrain(world_min, world_size, patch_count, base_height: float, height_scale: float, patch_minmax: torch.Tensor, cam, cull_flags: int,
+                 hiz: Hiz, mask: torch.Tensor) -> torch.Tensor:
+    """patch_minmax f32 [py, px, 2]; mask int32 (updated in place).  Returns the emitted patch indices (ascending)."""
+    pcx, pcy = int(patch_count[0]), int(patch_count[1])
+    out = torch.zeros(max(pcx * pcy, 1), dtype=torch.int32)
+    wm, ws = f32a(world_min), f32a(world_size)
+    n = lib().orc_cull_terrain(_p(wm), _p(ws), pcx, pcy, float(np.float32(base_height)), float(np.float32(height_scale)), _p(patch_minmax.contiguous()),
+                               _p(cam), cull_flags, C.byref(hiz) if hiz is not None else None, _p(mask), _p(out))
+    return out[:n].clone()

@@ -1027,3 +1027,44 @@ void orc_generate_hpb(const uint32_t* page_table, orc_hpb* hpb) {
         }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * terrain patch cull, passes/terrain_cull.slang:17-83 (TerrainData helpers scene.slang:648-660).
+ * ------------------------------------------------------------------------------------------ */
+uint32_t orc_cull_terrain(const float* world_min2, const float* world_size2, uint32_t pcx, uint32_t pcy, float base_height, float height_scale,
+                          const float* patch_minmax, const orc_cull_camera* cam, uint32_t cull_flags, const orc_hiz* hiz, uint32_t* mask,
+                          uint32_t* out_visible) {
+  const uint32_t total = pcx * pcy;
+  const int late = (cull_flags & ORC_LATE_PASS) != 0;
+  const int occl_or_late = (cull_flags & (ORC_TEST_OCCLUSION | ORC_LATE_PASS)) != 0;
+  uint32_t n = 0;
+  for (uint32_t patch_index = 0; patch_index < total; patch_index++) {
+    uint32_t px = patch_index % pcx, py = patch_index / pcx;
+    /* patch_corner: world_min + (f32x2(patch + corner) / f32x2(patch_count)) * world_size */
+    float g0x = (float)(px + 0u) / (float)pcx, g0y = (float)(py + 0u) / (float)pcy;
+    float g1x = (float)(px + 1u) / (float)pcx, g1y = (float)(py + 1u) / (float)pcy;
+    float cminx = world_min2[0] + g0x * world_size2[0], cminy = world_min2[1] + g0y * world_size2[1];
+    float cmaxx = world_min2[0] + g1x * world_size2[0], cmaxy = world_min2[1] + g1y * world_size2[1];
+    float bx = patch_minmax[(size_t)patch_index * 2 + 0], by = patch_minmax[(size_t)patch_index * 2 + 1];
+    float center[3] = {(cminx + cmaxx) * 0.5f, base_height + ((bx + by) * 0.5f) * height_scale, (cminy + cmaxy) * 0.5f};
+    float hy = height_scale * (by - bx);
+    float extent[3] = {cmaxx - cminx, hy > 1e-3f ? hy : 1e-3f, cmaxy - cminy}; /* max(a, 1e-3) */
+    uint32_t word = patch_index / 32u, bit = 1u << (patch_index % 32u);
+    int was_visible = (mask[word] & bit) != 0u;
+    int visible = late ? 1 : was_visible;
+    if (cull_flags & ORC_TEST_FRUSTUM) visible = visible && orc_test_frustum(cam->projection_view, center, extent);
+    if (occl_or_late && visible) {
+      float sa[6];
+      if (orc_project_aabb(cam->projection_view, cam->near_clip, center, extent, sa)) visible = !orc_test_occlusion(sa, hiz);
+    }
+    int emit = visible && (!late || !was_visible);
+    if (occl_or_late) {
+      if (visible)
+        mask[word] |= bit;
+      else
+        mask[word] &= ~bit;
+    }
+    if (emit) out_visible[n++] = patch_index;
+  }
+  return n;
+}

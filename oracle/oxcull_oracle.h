@@ -242,6 +242,13 @@ void orc_build_meshlet_bounds(const float* positions, uint32_t vertex_count, con
  * Passes/Shadowmaps.cpp:331-366; page flags rmvsm.slang:16-28 ([Flags]: Visible 1, Dirty 2, Backed 4). */
 void orc_generate_hpb(const uint32_t* page_table, orc_hpb* hpb);
 
+/* ---- terrain patch cull (passes/terrain_cull.slang:17-83, Passes/Terrain.cpp:159-216).
+ * terrain8 = {world_min.xy, world_size.xy, base_height, height_scale, (float)patch_count.x, (float)patch_count.y}
+ * (patch counts passed separately as integers too).  Returns the number of emitted patches (ascending). */
+uint32_t orc_cull_terrain(const float* world_min2, const float* world_size2, uint32_t patch_count_x, uint32_t patch_count_y, float base_height,
+                          float height_scale, const float* patch_minmax /* 2 floats per patch */, const orc_cull_camera* cam, uint32_t cull_flags,
+                          const orc_hiz* hiz, uint32_t* mask, uint32_t* out_visible);
+
 #ifdef __cplusplus
 }
 #endif

@@ -847,4 +847,61 @@ oxc_status oxc_generate_hpb(oxc_ctx* ctx, oxc_buffer page_table, const oxc_image
   return OXC_OK;
 }
 
+oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!c || c->struct_size != sizeof(oxc_terrain_context)) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: bad context / struct_size");
+  const uint64_t total64 = (uint64_t)c->patch_count[0] * c->patch_count[1];
+  if (c->patch_count[0] == 0 || c->patch_count[1] == 0 || total64 > (1u << 24)) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: patch_count must be 1..2^24 patches");
+  const uint32_t total = (uint32_t)total64;
+  const oxc_image& mm = c->patch_minmax_attachment;
+  if (!mm.dptr || mm.width != c->patch_count[0] || mm.height != c->patch_count[1]) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: patch_minmax_attachment must be patch_count.x x patch_count.y RG32F");
+  if (!c->visible_patches_buffer.dptr || c->visible_patches_buffer.bytes < (uint64_t)total * 4u) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: visible_patches_buffer smaller than patch_total u32");
+  if (!c->patch_visibility_mask_buffer.dptr || c->patch_visibility_mask_buffer.bytes < (uint64_t)cdiv(total, 32u) * 4u)
+    return fail(ctx, OXC_INVALID_ARG, "cull_terrain: patch_visibility_mask_buffer smaller than ceil(patch_total / 32) words");
+  const bool needs_hiz = (c->cull_flags & (OXC_CULL_TEST_OCCLUSION | OXC_CULL_LATE_PASS)) != 0u;
+  const oxc_image& h = c->hiz_attachment;
+  if (needs_hiz && (!h.dptr || h.levels == 0 || h.levels > 13 || h.width == 0 || h.height == 0)) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: TestOcclusion / LatePass need hiz_attachment");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t* slot = next_slot(ctx);
+  TerrainArgs a;
+  std::memset(&a, 0, sizeof a);
+  std::memcpy(a.pv, c->cull_camera.projection_view, 64);
+  a.near_clip = c->cull_camera.near_clip;
+  a.cull_flags = c->cull_flags;
+  a.world_min[0] = c->world_min[0];
+  a.world_min[1] = c->world_min[1];
+  a.world_size[0] = c->world_size[0];
+  a.world_size[1] = c->world_size[1];
+  a.pcx = c->patch_count[0];
+  a.pcy = c->patch_count[1];
+  a.base_height = c->base_height;
+  a.height_scale = c->height_scale;
+  a.patch_minmax = reinterpret_cast<const float2*>(static_cast<const char*>(mm.dptr) + mm.level_offset[0]);
+  if (needs_hiz) {
+    a.hiz_data = static_cast<const float*>(h.dptr);
+    a.hiz_w = h.width;
+    a.hiz_h = h.height;
+    a.hiz_levels = h.levels;
+    for (uint32_t k = 0; k < h.levels; k++) a.hiz_level_off[k] = (uint32_t)(h.level_offset[k] / 4);
+  }
+  a.mask = static_cast<uint32_t*>(c->patch_visibility_mask_buffer.dptr);
+  a.visible = static_cast<uint32_t*>(c->visible_patches_buffer.dptr);
+  a.draw_cmd = slot + SLOT_DRAW_CMD;
+  c->cull_camera.mesh_instance_count = total;  // Terrain.cpp:171
+  c->draw_cmd_buffer = {a.draw_cmd, 16};
+  launch_cull_terrain(a, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!dptr || !host_out) return fail(ctx, OXC_INVALID_ARG, "debug_read_u32: null pointer");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  OXC_HIP(ctx, hipMemcpyAsync(host_out, dptr, (size_t)n * 4u, hipMemcpyDeviceToHost, s));
+  OXC_HIP(ctx, hipStreamSynchronize(s));
+  return OXC_OK;
+}
+
 }  // extern "C"

@@ -163,6 +163,23 @@ void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid,
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
+// oxcull_terrain.hip: terrain patch cull
+struct TerrainArgs {
+  float pv[16];
+  float near_clip;
+  uint32_t cull_flags;
+  float world_min[2], world_size[2];
+  uint32_t pcx, pcy;
+  float base_height, height_scale;
+  const float2* patch_minmax;
+  const float* hiz_data;
+  uint32_t hiz_level_off[13];
+  uint32_t hiz_w, hiz_h, hiz_levels;
+  uint32_t* mask;
+  uint32_t* visible;
+  uint32_t* draw_cmd;
+};
+void launch_cull_terrain(const TerrainArgs& a, hipStream_t s);
 // oxcull_hpb.hip: hierarchical page buffer producer
 void launch_generate_hpb(const uint32_t* page_table, uint8_t* data, uint32_t w, uint32_t h, uint32_t layers, uint32_t levels, const uint64_t* level_offset,
                          hipStream_t s);

@@ -140,6 +140,24 @@ class MeshletBoundsDesc(C.Structure):
     ]
 
 
+class TerrainContext(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("cull_flags", C.c_uint32),
+        ("cull_camera", CullCamera),
+        ("world_min", C.c_float * 2),
+        ("world_size", C.c_float * 2),
+        ("patch_count", C.c_uint32 * 2),
+        ("base_height", C.c_float),
+        ("height_scale", C.c_float),
+        ("patch_minmax_attachment", Image),
+        ("hiz_attachment", Image),
+        ("visible_patches_buffer", Buffer),
+        ("patch_visibility_mask_buffer", Buffer),
+        ("draw_cmd_buffer", Buffer),
+    ]
+
+
 # every symbol include/oxcull.h declares
 EXPORTS = [
     "oxc_abi_version",
@@ -158,6 +176,8 @@ EXPORTS = [
     "oxc_profile_end",
     "oxc_build_meshlet_bounds",
     "oxc_generate_hpb",
+    "oxc_cull_terrain",
+    "oxc_debug_read_u32",
 ]
 
 
@@ -201,6 +221,8 @@ def load() -> C.CDLL:
     lib.oxc_profile_end.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.oxc_build_meshlet_bounds.argtypes = [vp, C.POINTER(MeshletBoundsDesc), vp]
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
+    lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
+    lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
             getattr(lib, name).restype = C.c_int

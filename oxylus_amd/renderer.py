@@ -286,6 +286,35 @@ class RendererInstance:
         self._keep = (page_table, hpb)
         self._check(self._lib.oxc_generate_hpb(self._ctx, L.Buffer(C.c_void_p(page_table.data_ptr()), page_table.numel() * 4), C.byref(im), self._stream(stream)))
 
+    def cull_terrain(self, cull_flags: int, cull_camera, world_min, world_size, patch_count, base_height: float, height_scale: float,
+                     patch_minmax: torch.Tensor, mask: torch.Tensor, hiz: "ImageAttachment" = None, stream=None):
+        """SURVEY 8(f)-4, Terrain.cpp:159-216 + terrain_cull.slang: patch_minmax f32 [py, px, 2], mask int32 [ceil(total/32)] (in/out).
+        Returns (visible_patches int32 [count], count)."""
+        pcx, pcy = int(patch_count[0]), int(patch_count[1])
+        total = pcx * pcy
+        visible = torch.full((max(total, 1),), -1, dtype=torch.int32, device=patch_minmax.device)
+        c = L.TerrainContext()
+        c.struct_size = C.sizeof(L.TerrainContext)
+        c.cull_flags = cull_flags
+        c.cull_camera = cull_camera
+        c.world_min[0], c.world_min[1] = float(world_min[0]), float(world_min[1])
+        c.world_size[0], c.world_size[1] = float(world_size[0]), float(world_size[1])
+        c.patch_count[0], c.patch_count[1] = pcx, pcy
+        c.base_height, c.height_scale = float(base_height), float(height_scale)
+        mm = L.Image()
+        mm.dptr, mm.width, mm.height, mm.levels = patch_minmax.data_ptr(), pcx, pcy, 1
+        c.patch_minmax_attachment = mm
+        if hiz is not None:
+            c.hiz_attachment = hiz.c()
+        c.visible_patches_buffer = L.Buffer(C.c_void_p(visible.data_ptr()), visible.numel() * 4)
+        c.patch_visibility_mask_buffer = L.Buffer(C.c_void_p(mask.data_ptr()), mask.numel() * 4)
+        self._keep = (patch_minmax, mask, visible, hiz)
+        self._check(self._lib.oxc_cull_terrain(self._ctx, C.byref(c), self._stream(stream)))
+        host = (C.c_uint32 * 4)()
+        self._check(self._lib.oxc_debug_read_u32(self._ctx, c.draw_cmd_buffer.dptr, 4, C.cast(host, C.c_void_p), self._stream(stream)))
+        cmd_host = list(host)
+        return visible[: cmd_host[1]].clone(), cmd_host
+
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))
 
