@@ -296,6 +296,39 @@ typedef struct oxc_terrain_context {
 
 oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* context, void* hip_stream);
 
+/* ---- consumer of the indirect draw ------------------------------------------------
+ * What RendererInstance::draw_for_visbuffer does with cull_geometry's outputs (Passes/DrawGeometry.cpp:104-190,
+ * pipeline visbuffer_encode, passes/visbuffer_encode.slang:24-49; cullMode eBack, depth GreaterOrEqual,
+ * reversed Z), as a compute rasteriser -- so that early cull -> draw -> depth -> generate_hiz -> late cull -> draw
+ * runs without a graphics queue.  The fixed-function rasteriser's sample rules cannot be matched bit for bit;
+ * the rules used instead are stated here and in the checker:
+ *   vertex  VisBufferData(index) -> (meshlet instance, corner); Meshlet::index, Mesh::decode_position;
+ *           world = mul(world, (p,1)).xyz, clip = mul(projection_view, (world,1))              (as vs_main);
+ *   setup   a triangle with any clip.w <= 0 or a screen coordinate beyond +-2^20 pixels is dropped (no clipper);
+ *           screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel; back faces (fixed-point
+ *           area >= 0, the orientation cull_triangles' determinant test calls back-facing) are dropped;
+ *   cover   pixel centres, integer edge functions, top-left rule;
+ *   depth   z/w interpolated in binary64 from the exact edge values, rounded to binary32, kept when in (0, 1];
+ *           per pixel the maximum of (depth bits << 32) | vis wins (64-bit atomic max), vis = (instance << 8) |
+ *           (corner / 3) as VisBufferData::encode -- order-independent: one of the results the reference's
+ *           equal-depth race can produce.
+ * `visdepth_buffer` (u64[width * height]) persists between the early and the late draw of a frame; `clear` zeroes
+ * it first.  `depth_attachment` (R32F, levels = 1) and `visbuffer_attachment` (u32) are optional resolves. */
+typedef struct oxc_draw_context {
+  uint32_t struct_size;
+  uint32_t wide_triangle_index; /* same meaning as in oxc_cull_geometry_context */
+  uint32_t clear;
+  uint32_t width, height;
+  uint32_t _pad;
+  float projection_view[16];           /* Camera::projection_view, column-major */
+  oxc_buffer draw_geometry_cmd_buffer; /* from oxc_cull_geometry: indexCount is read on the device */
+  oxc_buffer visdepth_buffer;
+  oxc_image depth_attachment;          /* optional out */
+  oxc_buffer visbuffer_attachment;     /* optional out */
+} oxc_draw_context;
+
+oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* frame, const oxc_draw_context* context, void* hip_stream);
+
 /* Harness helper: copy n u32 from device memory (e.g. a callee-owned indirect command) to the host; synchronises the stream. */
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream);
 

@@ -92,6 +92,10 @@ def lib() -> C.CDLL:
         l.orc_cull_triangles_mt.restype = u32
         l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
         l.orc_entities_update_and_cull.restype = u32
+        l.orc_draw_visbuffer.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, u32, u32, vp]
+        l.orc_draw_visbuffer.restype = None
+        l.orc_resolve_visbuffer.argtypes = [vp, u32, u32, vp, vp]
+        l.orc_resolve_visbuffer.restype = None
         l.orc_cull_terrain.argtypes = [vp, vp, u32, u32, f32, f32, vp, vp, u32, C.POINTER(Hiz), vp, vp]
         l.orc_cull_terrain.restype = u32
         l.orc_generate_hpb.argtypes = [vp, C.POINTER(Hpb)]
@@ -297,3 +301,20 @@ def cull_terrain(world_min, world_size, patch_count, base_height: float, height_
     n = lib().orc_cull_terrain(_p(wm), _p(ws), pcx, pcy, float(np.float32(base_height)), float(np.float32(height_scale)), _p(patch_minmax.contiguous()),
                                _p(cam), cull_flags, C.byref(hiz) if hiz is not None else None, _p(mask), _p(out))
     return out[:n].clone()
+
+
+def draw_visbuffer(scene, meshlet_instances: torch.Tensor, indices: torch.Tensor, projection_view, width: int, height: int, visdepth: torch.Tensor,
+                   wide: bool = False):
+    """Rasterises `indices` (cull_triangles output) into visdepth (int64 [h, w], accumulated)."""
+    pv = f32a(projection_view)
+    idx = indices.contiguous()
+    lib().orc_draw_visbuffer(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(idx), idx.numel(), _p(pv),
+                             width, height, 9 if wide else 8, _p(visdepth))
+
+
+def resolve_visbuffer(visdepth: torch.Tensor):
+    h, w = visdepth.shape
+    depth = torch.zeros((h, w), dtype=torch.float32)
+    vis = torch.zeros((h, w), dtype=torch.int32)
+    lib().orc_resolve_visbuffer(_p(visdepth), w, h, _p(depth), _p(vis))
+    return depth, vis

@@ -1068,3 +1068,102 @@ uint32_t orc_cull_terrain(const float* world_min2, const float* world_size2, uin
   }
   return n;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * consumer of the indirect draw (see the header for the stated raster rules).
+ * ------------------------------------------------------------------------------------------ */
+static int64_t edge_fn(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t px, int64_t py) {
+  return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+/* top-left rule for triangles oriented with positive area: an edge owns its pixels when it goes down,
+ * or is horizontal going left (complementary for the neighbour that shares the edge reversed) */
+static int edge_inclusive(int64_t ax, int64_t ay, int64_t bx, int64_t by) {
+  int64_t dx = bx - ax, dy = by - ay;
+  return dy > 0 || (dy == 0 && dx < 0);
+}
+
+void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                        const orc_meshlet_instance* meshlet_instances, const uint32_t* indices, uint32_t index_count, const float* pv, uint32_t W,
+                        uint32_t H, uint32_t corner_bits, uint64_t* visdepth) {
+  const uint32_t corner_mask = (1u << corner_bits) - 1u;
+  for (uint32_t i = 0; i + 2 < index_count; i += 3) {
+    int64_t X[3], Y[3];
+    float z[3];
+    uint32_t vis_out = 0;
+    int drop = 0;
+    for (int k = 0; k < 3; k++) {
+      /* vs_main, visbuffer_encode.slang:24-49 */
+      uint32_t data = indices[i + k];
+      uint32_t mli_index = (data >> corner_bits) & (0xFFFFFFFFu >> corner_bits), corner = data & corner_mask;
+      const orc_meshlet_instance* mli = &meshlet_instances[mli_index];
+      const orc_mesh_instance* inst = &mesh_instances[mli->mesh_instance_index];
+      const orc_mesh* mesh = &meshes[inst->mesh_index];
+      const orc_mesh_lod* lod = &((const orc_mesh_lod*)(uintptr_t)mesh->lods)[inst->lod_index];
+      const orc_meshlet* ml = &((const orc_meshlet*)(uintptr_t)lod->meshlets)[mli->meshlet_index];
+      uint32_t li = micro_index((const uint32_t*)(uintptr_t)lod->local_triangle_indices, ml->local_triangle_index_offset + corner);
+      uint32_t vi = ((const uint32_t*)(uintptr_t)lod->indirect_vertex_indices)[ml->indirect_vertex_index_offset + li];
+      const uint16_t* pos = (const uint16_t*)(uintptr_t)mesh->vertex_positions;
+      float p[3] = {orc_dequantize_half(pos[(size_t)vi * 4 + 0]), orc_dequantize_half(pos[(size_t)vi * 4 + 1]), orc_dequantize_half(pos[(size_t)vi * 4 + 2])};
+      float world[4], clip[4];
+      mul_mp(xform(transforms, inst->transform_index), p, world);
+      mul_mp(pv, world, clip);
+      if (k == 0) vis_out = (mli_index << 8) | ((corner / 3u) & 0xFFu); /* VisBufferData(mli, triangle_index / 3).encode() */
+      if (!(clip[3] > 0.0f)) {
+        drop = 1;
+        continue;
+      }
+      float sx = ((clip[0] / clip[3]) * 0.5f + 0.5f) * (float)W;
+      float sy = ((clip[1] / clip[3]) * 0.5f + 0.5f) * (float)H;
+      z[k] = clip[2] / clip[3];
+      if (!(fabsf(sx) <= 1048576.0f) || !(fabsf(sy) <= 1048576.0f)) {
+        drop = 1;
+        continue;
+      }
+      X[k] = (int64_t)floorf(sx * 256.0f + 0.5f);
+      Y[k] = (int64_t)floorf(sy * 256.0f + 0.5f);
+    }
+    if (drop) continue;
+    int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+    if (area >= 0) continue; /* cullMode eBack: det(xyw) > 0 <=> positive area (cull.slang:169-171); 0 = no coverage */
+    /* orient positively: swap corners 1 and 2 */
+    int64_t t = X[1]; X[1] = X[2]; X[2] = t;
+    t = Y[1]; Y[1] = Y[2]; Y[2] = t;
+    float tz = z[1]; z[1] = z[2]; z[2] = tz;
+    area = -area;
+    int64_t minx = X[0] < X[1] ? X[0] : X[1], maxx = X[0] > X[1] ? X[0] : X[1];
+    int64_t miny = Y[0] < Y[1] ? Y[0] : Y[1], maxy = Y[0] > Y[1] ? Y[0] : Y[1];
+    minx = minx < X[2] ? minx : X[2]; maxx = maxx > X[2] ? maxx : X[2];
+    miny = miny < Y[2] ? miny : Y[2]; maxy = maxy > Y[2] ? maxy : Y[2];
+    /* pixel (px,py) has its centre at (256 px + 128, 256 py + 128) */
+    int64_t px0 = (minx - 128 + 255) >> 8, px1 = (maxx - 128) >> 8;
+    int64_t py0 = (miny - 128 + 255) >> 8, py1 = (maxy - 128) >> 8;
+    if (px0 < 0) px0 = 0;
+    if (py0 < 0) py0 = 0;
+    if (px1 > (int64_t)W - 1) px1 = (int64_t)W - 1;
+    if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
+    const int64_t b0 = edge_inclusive(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
+    const int64_t b1 = edge_inclusive(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
+    const int64_t b2 = edge_inclusive(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
+    for (int64_t py = py0; py <= py1; py++)
+      for (int64_t px = px0; px <= px1; px++) {
+        int64_t cxp = px * 256 + 128, cyp = py * 256 + 128;
+        int64_t e0 = edge_fn(X[1], Y[1], X[2], Y[2], cxp, cyp); /* weight of corner 0 */
+        int64_t e1 = edge_fn(X[2], Y[2], X[0], Y[0], cxp, cyp);
+        int64_t e2 = edge_fn(X[0], Y[0], X[1], Y[1], cxp, cyp);
+        if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) continue;
+        double zd = (((double)e0 * (double)z[0] + (double)e1 * (double)z[1]) + (double)e2 * (double)z[2]) / (double)area;
+        float zf = (float)zd;
+        if (!(zf > 0.0f) || zf > 1.0f) continue;
+        uint64_t packed = ((uint64_t)f2u(zf) << 32) | vis_out;
+        uint64_t* dst = &visdepth[(size_t)py * W + (size_t)px];
+        if (packed > *dst) *dst = packed;
+      }
+  }
+}
+
+void orc_resolve_visbuffer(const uint64_t* visdepth, uint32_t W, uint32_t H, float* depth, uint32_t* vis) {
+  for (size_t i = 0; i < (size_t)W * H; i++) {
+    depth[i] = u2f((uint32_t)(visdepth[i] >> 32));
+    vis[i] = (uint32_t)visdepth[i];
+  }
+}

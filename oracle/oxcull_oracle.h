@@ -249,6 +249,27 @@ uint32_t orc_cull_terrain(const float* world_min2, const float* world_size2, uin
                           float height_scale, const float* patch_minmax /* 2 floats per patch */, const orc_cull_camera* cam, uint32_t cull_flags,
                           const orc_hiz* hiz, uint32_t* mask, uint32_t* out_visible);
 
+/* ---- consumer of the indirect draw ------------------------------------------------
+ * What draw_for_visbuffer does with cull_geometry's outputs (Passes/DrawGeometry.cpp:104-190, pipeline
+ * visbuffer_encode: vs_main passes/visbuffer_encode.slang:24-49, cullMode eBack, depth GreaterOrEqual,
+ * reversed Z), as a software rasteriser with stated rules, because the fixed-function rasteriser's exact
+ * sample rules are not available to match:
+ *   vertex: VisBufferData(index) -> (meshlet instance, corner); Meshlet::index / Mesh::decode_position;
+ *           world = mul(world, (p,1)).xyz; clip = mul(projection_view, (world,1))   (two steps, as vs_main);
+ *   setup:  triangles with any clip.w <= 0 or a screen coordinate beyond +-2^20 pixels are dropped (no clipper);
+ *           screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel (nearest);
+ *           back faces (signed fixed-point area >= 0, the sign cull_triangles' determinant test uses) dropped;
+ *   cover:  pixel centres, integer edge functions, top-left rule;
+ *   depth:  z/w interpolated with the exact edge values in binary64, rounded to binary32; fragments outside
+ *           (0, 1] dropped; per pixel the maximum of (depth bits << 32) | vis wins, vis = (instance << 8) |
+ *           (corner / 3) (VisBufferData::encode) -- order-independent, i.e. one of the results the
+ *           reference's race between equal-depth fragments can produce.
+ * visdepth: u64[h * w], cleared to 0 by the caller before the first draw of a frame. */
+void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                        const orc_meshlet_instance* meshlet_instances, const uint32_t* indices, uint32_t index_count, const float* projection_view,
+                        uint32_t width, uint32_t height, uint32_t corner_bits, uint64_t* visdepth);
+void orc_resolve_visbuffer(const uint64_t* visdepth, uint32_t width, uint32_t height, float* depth, uint32_t* vis);
+
 #ifdef __cplusplus
 }
 #endif

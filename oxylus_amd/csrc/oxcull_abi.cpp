@@ -58,6 +58,7 @@ struct oxc_ctx {
   // meshlets the compacted triangle normals (768 B each) and their counts
   float* bounds_scratch = nullptr;
   uint32_t bounds_scratch_cap = 0;
+  void* raster_scratch = nullptr;  // oxc_draw_visbuffer: list of large triangles + its counter
   // counter slots
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
@@ -278,6 +279,7 @@ void oxc_destroy(oxc_ctx* ctx) {
     if (ln.arena) (void)hipFree(ln.arena);
   if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
   if (ctx->bounds_scratch) (void)hipFree(ctx->bounds_scratch);
+  if (ctx->raster_scratch) (void)hipFree(ctx->raster_scratch);
   if (ctx->slots) (void)hipFree(ctx->slots);
   delete ctx;
 }
@@ -890,6 +892,48 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   c->cull_camera.mesh_instance_count = total;  // Terrain.cpp:171
   c->draw_cmd_buffer = {a.draw_cmd, 16};
   launch_cull_terrain(a, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+constexpr uint32_t kRasterBigCapacity = 1u << 20;  // large triangles queued per draw; beyond that the setup lane rasterises itself
+
+oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const oxc_draw_context* d, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!f || !d || d->struct_size != sizeof(oxc_draw_context)) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: bad frame / context / struct_size");
+  if (d->width == 0 || d->height == 0 || d->width > 16384 || d->height > 16384) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: extent must be 1..16384");
+  const uint64_t n = (uint64_t)d->width * d->height;
+  if (!d->visdepth_buffer.dptr || d->visdepth_buffer.bytes < n * 8u) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: visdepth_buffer smaller than width*height u64");
+  if (!d->draw_geometry_cmd_buffer.dptr) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: draw_geometry_cmd_buffer is null (run oxc_cull_geometry with the triangle stage first)");
+  if (!f->meshes_buffer.dptr || !f->transforms_world_buffer.dptr || !f->mesh_instances_buffer.dptr || !f->meshlet_instances_buffer.dptr ||
+      !f->reordered_indices_buffer.dptr)
+    return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: null PreparedFrame buffer");
+  const oxc_image& dep = d->depth_attachment;
+  if (dep.dptr && (dep.width != d->width || dep.height != d->height)) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: depth_attachment extent differs from the draw extent");
+  if (d->visbuffer_attachment.dptr && d->visbuffer_attachment.bytes < n * 4u) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: visbuffer_attachment smaller than width*height u32");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->raster_scratch) {
+    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + 256);
+    if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster scratch)", e);
+  }
+  DrawArgs a;
+  std::memset(&a, 0, sizeof a);
+  std::memcpy(a.pv, d->projection_view, 64);
+  a.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
+  a.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
+  a.mesh_instances = static_cast<const GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
+  a.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
+  a.indices = static_cast<const uint32_t*>(f->reordered_indices_buffer.dptr);
+  a.draw_cmd = static_cast<const uint32_t*>(d->draw_geometry_cmd_buffer.dptr);
+  a.visdepth = static_cast<unsigned long long*>(d->visdepth_buffer.dptr);
+  a.width = d->width;
+  a.height = d->height;
+  a.wide = d->wide_triangle_index;
+  a.big_capacity = kRasterBigCapacity;
+  a.big_count = static_cast<uint32_t*>(ctx->raster_scratch);
+  a.big_list = reinterpret_cast<TriSetup*>(static_cast<char*>(ctx->raster_scratch) + 256);
+  launch_draw_visbuffer(a, d->clear != 0, dep.dptr ? reinterpret_cast<float*>(static_cast<char*>(dep.dptr) + dep.level_offset[0]) : nullptr,
+                        static_cast<uint32_t*>(d->visbuffer_attachment.dptr), ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }

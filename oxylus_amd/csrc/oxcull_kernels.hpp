@@ -163,6 +163,25 @@ void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid,
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
+// oxcull_raster.hip: consumer of the indirect draw
+struct TriSetup;
+struct DrawArgs {
+  float pv[16];
+  const GpuMesh* meshes;
+  const float* transforms;
+  const GpuMeshInstance* mesh_instances;
+  const GpuMeshletInstance* meshlet_instances;
+  const uint32_t* indices;    // reordered_indices
+  const uint32_t* draw_cmd;   // VkDrawIndexedIndirectCommand: [0] = indexCount
+  unsigned long long* visdepth;
+  uint32_t width, height;
+  uint32_t wide;
+  uint32_t big_capacity;
+  TriSetup* big_list;
+  uint32_t* big_count;
+};
+void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint32_t* vis_out, uint32_t max_grid, hipStream_t s);
+constexpr uint32_t kTriSetupBytes = 40;
 // oxcull_terrain.hip: terrain patch cull
 struct TerrainArgs {
   float pv[16];

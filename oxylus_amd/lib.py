@@ -158,6 +158,22 @@ class TerrainContext(C.Structure):
     ]
 
 
+class DrawContext(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("wide_triangle_index", C.c_uint32),
+        ("clear", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("projection_view", C.c_float * 16),
+        ("draw_geometry_cmd_buffer", Buffer),
+        ("visdepth_buffer", Buffer),
+        ("depth_attachment", Image),
+        ("visbuffer_attachment", Buffer),
+    ]
+
+
 # every symbol include/oxcull.h declares
 EXPORTS = [
     "oxc_abi_version",
@@ -177,6 +193,7 @@ EXPORTS = [
     "oxc_build_meshlet_bounds",
     "oxc_generate_hpb",
     "oxc_cull_terrain",
+    "oxc_draw_visbuffer",
     "oxc_debug_read_u32",
 ]
 
@@ -223,6 +240,7 @@ def load() -> C.CDLL:
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.oxc_draw_visbuffer.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(DrawContext), vp]
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
             getattr(lib, name).restype = C.c_int

@@ -315,6 +315,29 @@ class RendererInstance:
         cmd_host = list(host)
         return visible[: cmd_host[1]].clone(), cmd_host
 
+    def draw_visbuffer(self, context: CullGeometryContext, projection_view, width: int, height: int, visdepth: torch.Tensor, clear: bool,
+                       depth: "ImageAttachment" = None, visbuffer: torch.Tensor = None, stream=None):
+        """SURVEY 8(f)-2, DrawGeometry.cpp:104-190: rasterise the triangles the last cull_geometry(context) emitted into
+        `visdepth` (int64 [h, w]: depth bits << 32 | vis); optional resolves into `depth` (ImageAttachment, levels = 1) and
+        `visbuffer` (int32 [h, w])."""
+        assert self.prepared_frame is not None
+        f = self.prepared_frame.c()
+        d = L.DrawContext()
+        d.struct_size = C.sizeof(L.DrawContext)
+        d.wide_triangle_index = 1 if context.wide_triangle_index else 0
+        d.clear = 1 if clear else 0
+        d.width, d.height = width, height
+        for i in range(16):
+            d.projection_view[i] = float(projection_view[i])
+        d.draw_geometry_cmd_buffer = context._c.draw_geometry_cmd_buffer
+        d.visdepth_buffer = L.Buffer(C.c_void_p(visdepth.data_ptr()), visdepth.numel() * 8)
+        if depth is not None:
+            d.depth_attachment = depth.c()
+        if visbuffer is not None:
+            d.visbuffer_attachment = L.Buffer(C.c_void_p(visbuffer.data_ptr()), visbuffer.numel() * 4)
+        self._keep = (visdepth, depth, visbuffer)
+        self._check(self._lib.oxc_draw_visbuffer(self._ctx, C.byref(f), C.byref(d), self._stream(stream)))
+
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))
 
