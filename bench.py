@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=9600)
     ap.add_argument("--warmup", type=int, default=960)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "bounds"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "bounds", "loop"])
     ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses the wide packed index extension (<= 8M meshlets)")
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
@@ -163,6 +163,81 @@ def bench_bounds(args, r, dev, stream, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_loop(args, r, dev, stream, rank, world, dist):
+    """--workload loop: the closed two-pass frame of RendererInstance::render (RendererInstance.cpp:842-884) without a
+    graphics queue -- early cull (last frame's mask) -> oxc_draw_visbuffer -> depth -> oxc_generate_hiz -> late cull ->
+    draw on top -- on a static scene (steady state: the early pass draws everything, the late pass finds nothing new)."""
+    n_meshlets = args.meshlets or 2_000_000
+    K = 1000
+    M = max(1, n_meshlets // K)
+    n_meshlets = M * K
+    W = H = 2048
+    steps, warmup = min(args.steps, 30), min(max(args.warmup, 2), 5)
+    with torch.cuda.stream(stream):
+        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 9 + rank), dev)
+        r.reserve(M, n_meshlets)
+        frame = PreparedFrame.create(scene, with_triangles=True)
+        r.prepared_frame = frame
+        cam = scene.cull_camera()
+        pv = [cam.projection_view[i] for i in range(16)]
+        hiz = ImageAttachment.hiz(W // 2, H // 2, dev)
+        depth = ImageAttachment.depth(torch.zeros((H, W), dtype=torch.float32, device=dev))
+        visdepth = torch.zeros((H, W), dtype=torch.int64, device=dev)
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=cam, hiz_attachment=hiz, stages=L.STAGE_ALL)
+        r.seed_meshlet_instances(ctx, n_meshlets)
+    from oxylus_amd.renderer import MainGeometryContext
+
+    mg = MainGeometryContext(depth_attachment=depth, hiz_attachment=hiz)
+    counts = {}
+
+    def one_frame(record=False):
+        ctx.cull_flags = L.CULL_TEST_ALL
+        r.cull_geometry(ctx, stream=stream)
+        if record:
+            c = r.read_counters(ctx, stream=stream)
+            counts["early"], counts["early_indices"] = c.cull_triangles_cmd_x, c.draw_index_count
+        r.draw_visbuffer(ctx, pv, W, H, visdepth, clear=True, depth=depth, stream=stream)
+        r.generate_hiz(mg, stream=stream)
+        ctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
+        r.cull_geometry(ctx, stream=stream)
+        if record:
+            c = r.read_counters(ctx, stream=stream)
+            counts["late"], counts["late_indices"] = c.cull_triangles_cmd_x, c.draw_index_count
+        r.draw_visbuffer(ctx, pv, W, H, visdepth, clear=False, depth=depth, stream=stream)
+
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            one_frame()
+        one_frame(record=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            one_frame()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    covered = float((visdepth != 0).float().mean().item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "meshlets/s through the closed two-pass frame (cull + draw + HiZ)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SURVEY 8f-2 loop: early cull -> draw -> depth -> HiZ -> late cull -> draw, static scene, steady state",
+                       "meshlets_per_gpu": n_meshlets, "target": [W, H], "hiz": [W // 2, H // 2], "tris_per_meshlet": 64,
+                       "steady_state_counts": counts, "covered_pixel_fraction": round(covered, 4)},
+            "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +259,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     if args.workload == "bounds":
         return bench_bounds(args, r, dev, stream, rank, world, dist)
+    if args.workload == "loop":
+        return bench_loop(args, r, dev, stream, rank, world, dist)
     sp = C.c_void_p(stream.cuda_stream)
     n_streams = max(1, args.streams) if args.workload == "config2" else 1
     # extra contexts/streams for independent batches in flight (each context owns its scratch)
