@@ -20,7 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle  # noqa: E402
 from oxylus_amd import lib as L  # noqa: E402
-from oxylus_amd.synth import SceneSpec, make_depth, make_scene  # noqa: E402
+from oxylus_amd.lib import CullCamera  # noqa: E402
+from oxylus_amd.renderer import HpbAttachment  # noqa: E402
+from oxylus_amd.synth import SceneSpec, build_meshlets_simple, make_depth, make_mesh, make_scene, perspective_reversed_z  # noqa: E402
 from util import oracle_frame, oracle_hiz  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,6 +44,64 @@ def scene_arrays(s):
                                   [s.camera["near_clip"]], dtype=np.float32),
         "spec": np.asarray([s.spec.n_mesh_instances, s.spec.meshlets_per_mesh, s.spec.lod_count, s.n_meshes], dtype=np.int64),
     }
+
+
+def terrain_camera():
+    proj = perspective_reversed_z(60.0, 1.0, 0.1, 2000.0).view(4, 4)
+    view = torch.eye(4)
+    view[3, 0:3] = -torch.tensor([0.0, 40.0, 0.0])
+    pv = (proj.t() @ view.t()).t().contiguous().flatten()
+    cam = CullCamera()
+    for i in range(16):
+        cam.projection_view[i] = float(pv[i])
+    cam.position[1] = 40.0
+    cam.near_clip = 0.1
+    return cam, pv.numpy()
+
+
+def widening_rows():
+    """one small fixture with inputs and expected outputs per row."""
+    out = {}
+    # 8f-1 bounds producer: a bumpy height field with degenerate triangles
+    pos, tris = make_mesh("terrain", n=14, seed=0x601F)
+    meshlets, vidx, micro = build_meshlets_simple(tris)
+    b, m6, q = oracle.build_meshlet_bounds(pos, meshlets, vidx, micro)
+    out.update(bounds_positions=pos.numpy(), bounds_meshlets=meshlets.numpy(), bounds_vidx=vidx.numpy(), bounds_micro=micro.numpy(),
+               bounds_records=b.numpy(), bounds_mesh6=m6.numpy(), bounds_qpos=q.numpy())
+    # 8f-3 HPB producer: 3 layers of 9 x 6 pages, 4 levels (odd extents)
+    g = torch.Generator().manual_seed(0x6020)
+    pt = torch.randint(0, 32, (3, 6, 9), generator=g, dtype=torch.int32)
+    pt[torch.rand((3, 6, 9), generator=g) < 0.25] = 7
+    hpb = HpbAttachment.create(9, 6, 3, 4, "cpu")
+    oracle.generate_hpb(pt, oracle.make_hpb(hpb.data, 9, 6, 3, 4, hpb.level_offset))
+    out.update(hpb_page_table=pt.numpy(), hpb_data=hpb.data.numpy(), hpb_level_offset=np.asarray(hpb.level_offset, dtype=np.int64))
+    # 8f-4 terrain cull: 37 x 29 patches, early then late against a 64 x 64 HiZ
+    g = torch.Generator().manual_seed(0x6021)
+    lo = torch.rand((29, 37), generator=g) * 0.6
+    mm = torch.stack([lo, lo + torch.rand((29, 37), generator=g) * 0.4], -1).contiguous()
+    depth = make_depth(128, 128, 16, seed=0x6021)
+    hz, levels, offs = oracle_hiz(depth, 64, 64)
+    hzo = oracle.make_hiz(hz.numpy(), 64, 64, levels, offs)
+    total = 37 * 29
+    mask = ((torch.rand(((total + 31) // 32, 32), generator=g) < 0.35).to(torch.int64) << torch.arange(32)).sum(1).to(torch.int32)
+    cam, pv = terrain_camera()
+    out.update(terrain_minmax=mm.numpy(), terrain_depth=depth.numpy(), terrain_mask_in=mask.numpy().copy(), terrain_pv=pv,
+               terrain_params=np.asarray([-300.0, -700.0, 600.0, 650.0, -5.0, 60.0], dtype=np.float32))
+    early = oracle.cull_terrain([-300.0, -700.0], [600.0, 650.0], (37, 29), -5.0, 60.0, mm, cam, L.CULL_TEST_ALL, hzo, mask)
+    late = oracle.cull_terrain([-300.0, -700.0], [600.0, 650.0], (37, 29), -5.0, 60.0, mm, cam, L.CULL_TEST_ALL | L.CULL_LATE_PASS, hzo, mask)
+    out.update(terrain_early=early.numpy(), terrain_late=late.numpy(), terrain_mask_out=mask.numpy())
+    np.savez_compressed(os.path.join(HERE, "widening_rows.npz"), **out)
+    # 8f-2 draw consumer: the plain pipeline fixture's triangle list rasterised at 512 x 384 (expected image only:
+    # the inputs are pipeline_12x40.npz)
+    z = np.load(os.path.join(HERE, "pipeline_12x40.npz"))
+    from util import scene_from_golden
+
+    s, _ = scene_from_golden(os.path.join(HERE, "pipeline_12x40.npz"))
+    s.mesh_instances[:, 1] = torch.from_numpy(z["plain_lod_index"])  # the LODs cull_meshes selected
+    vd = torch.zeros((384, 512), dtype=torch.int64)
+    oracle.draw_visbuffer(s, torch.from_numpy(z["plain_meshlet_instances"]), torch.from_numpy(z["plain_indices"]), z["camera_pv"], 512, 384, vd)
+    assert int((vd != 0).sum()) >= 50
+    np.savez_compressed(os.path.join(HERE, "raster_512x384.npz"), visdepth=vd.numpy())
 
 
 def main():
@@ -82,6 +142,7 @@ def main():
     arrays["visible"] = vis.numpy()
     arrays["near_threshold"] = np.asarray(st.meshlets_near_threshold)
     np.savez_compressed(os.path.join(HERE, "meshlets_37x111.npz"), **arrays)
+    widening_rows()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

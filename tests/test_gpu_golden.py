@@ -33,3 +33,41 @@ def test_hip_matches_golden_pipeline(renderer):
     want = {k[4:]: z[k] for k in z.files if k.startswith("two_")}
     want["early"], want["late"] = int(want["early"]), int(want["late"])
     assert_same(want, got, ["early", "late", "early_visible", "late_visible", "early_indices", "late_indices", "mask"])
+
+
+def test_hip_matches_golden_widening_rows(renderer):
+    """SURVEY 8(f) rows against committed data: bounds producer, HPB producer, terrain cull, draw consumer."""
+    from oxylus_amd import lib as L
+    from oxylus_amd.renderer import CullGeometryContext, HpbAttachment, PreparedFrame
+
+    z = np.load(os.path.join(GOLDEN, "widening_rows.npz"))
+    cu = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    b, m6, q = renderer.build_meshlet_bounds(cu("bounds_positions"), cu("bounds_meshlets"), cu("bounds_vidx"), cu("bounds_micro"))
+    assert np.array_equal(b.cpu().numpy(), z["bounds_records"]) and np.array_equal(q.cpu().numpy(), z["bounds_qpos"])
+    assert np.array_equal(m6.cpu().numpy().view(np.uint32), z["bounds_mesh6"].view(np.uint32))
+    hpb = HpbAttachment.create(9, 6, 3, 4, "cuda")
+    renderer.generate_hpb(cu("hpb_page_table"), hpb)
+    assert np.array_equal(hpb.data.cpu().numpy(), z["hpb_data"])
+    hiz = ImageAttachment.hiz(64, 64, "cuda")
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(cu("terrain_depth")), hiz))
+    cam = L.CullCamera()
+    for i in range(16):
+        cam.projection_view[i] = float(z["terrain_pv"][i])
+    cam.near_clip = 0.1
+    p = z["terrain_params"]
+    mask = torch.from_numpy(z["terrain_mask_in"].copy()).cuda()
+    early, _ = renderer.cull_terrain(L.CULL_TEST_ALL, cam, p[0:2], p[2:4], (37, 29), float(p[4]), float(p[5]), cu("terrain_minmax"), mask, hiz=hiz)
+    late, cmd = renderer.cull_terrain(L.CULL_TEST_ALL | L.CULL_LATE_PASS, cam, p[0:2], p[2:4], (37, 29), float(p[4]), float(p[5]), cu("terrain_minmax"), mask,
+                                      hiz=hiz)
+    assert np.array_equal(early.cpu().numpy(), z["terrain_early"]) and np.array_equal(late.cpu().numpy(), z["terrain_late"])
+    assert np.array_equal(mask.cpu().numpy(), z["terrain_mask_out"]) and cmd == [4, len(z["terrain_late"]), 0, 0]
+    # draw consumer: cull the pipeline fixture on the GPU (== its golden lists, asserted above), then rasterise
+    s, zp = scene_from_golden(os.path.join(GOLDEN, "pipeline_12x40.npz"), "cuda")
+    frame = PreparedFrame.create(s, expand=False)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_ALL, cull_camera=s.cull_camera())
+    renderer.cull_geometry(ctx)
+    vd = torch.empty((384, 512), dtype=torch.int64, device="cuda")
+    renderer.draw_visbuffer(ctx, zp["camera_pv"], 512, 384, vd, clear=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(vd.cpu().numpy(), np.load(os.path.join(GOLDEN, "raster_512x384.npz"))["visdepth"])
