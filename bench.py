@@ -347,14 +347,39 @@ def main():
         k, cf, cc = groups[gi % len(groups)]
         check(lib.oxc_cull_geometry_batch(renderers[k]._ctx, batch, cf, cc, sps[0] if single_stream[0] else sps[k]))
 
+    # config 5: the views are independent cull_geometry calls over the same scene; `--batch` of them go through one
+    # oxc_cull_geometry_batch call (each element has its own outputs and its own mesh_instances copy: cull_meshes
+    # writes lod_index per view)
+    view_batch = max(1, min(4, args.batch)) if multiview else 1
+    view_groups = []
+    if multiview:
+        import dataclasses
+
+        with torch.cuda.stream(stream):
+            lanes = [steps[0]] + [Step(r, dataclasses.replace(base, mesh_instances=base.mesh_instances.clone()), stages) for _ in range(view_batch - 1)]
+            r.reserve(M, n_meshlets)
+        for v0 in range(0, args.views, view_batch):
+            cams = view_cams[v0:v0 + view_batch]
+            cc = (L.CullGeometryContext * len(cams))()
+            cf = (L.PreparedFrame * len(cams))()
+            for e, cam in enumerate(cams):
+                lanes[e].cctx.init_cull_meshes = 1
+                lanes[e].cctx.cull_flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+                lanes[e].cctx.cull_camera = cam
+                C.memmove(C.byref(cc, e * C.sizeof(L.CullGeometryContext)), lanes[e].pc, C.sizeof(L.CullGeometryContext))
+                C.memmove(C.byref(cf, e * C.sizeof(L.PreparedFrame)), lanes[e].pf, C.sizeof(L.PreparedFrame))
+            view_groups.append((len(cams), cf, cc))
+
     def run_step(i):
         st = steps[i % copies]
         if multiview:
-            st.cctx.init_cull_meshes = 1
-            st.cctx.cull_flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
-            for cam in view_cams:
-                st.cctx.cull_camera = cam
-                check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+            for n, cf, cc in view_groups:
+                if n == 1:
+                    check(lib.oxc_cull_geometry(ctxp, cf, cc, sp))
+                else:
+                    check(lib.oxc_cull_geometry_batch(ctxp, n, cf, cc, sp))
+            # the counters read below come from view 0's context
+            C.memmove(st.pc, C.byref(view_groups[0][2], 0), C.sizeof(L.CullGeometryContext))
             return
         if not full:
             k = (i % copies) % n_streams  # copy -> context/stream
@@ -632,7 +657,7 @@ def main():
                              f"configs[4]: 10M meshlets x {args.views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"),
                 "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris if full else None,
                 "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
-                "hip_graph": graph is not None, "streams": n_streams, "frames_per_launch": steps_per_call, "visible_fraction": round(visible_fraction, 4),
+                "hip_graph": graph is not None, "streams": n_streams, "frames_per_launch": (view_batch if multiview else steps_per_call), "visible_fraction": round(visible_fraction, 4),
                 "sharding": (f"contiguous range per rank x{world}; all-gather of per-rank counters"
                              + ("; HiZ built on rank 0 and broadcast" if full else "")) if world > 1 else "single GPU",
             },
