@@ -251,22 +251,61 @@ OXC_DEV void scan_body(const ScanArgs& a) {
   uint32_t* __restrict__ meshlets_cmd = a.meshlets_cmd;
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_part[16 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n; base += 1024) {
-    uint32_t i = base + threadIdx.x;
-    uint32_t v = i < n ? counts[i] : 0u;
-    uint32_t incl = wave_incl_scan(v, lane);
-    if (lane == 63) s_wave[wave] = incl;
+  constexpr uint32_t kTiles = 16;
+  if (n <= kTiles * 1024u) {
+    // Up to 16K mesh instances (the usual case): all loads in flight at once, one wave scan per 1024-element tile,
+    // then ONE block-level scan of the 256 (tile, wave) totals -- three barriers in all, and no load waits behind a
+    // barrier (the tile loop below costs ~1.5 us of latency per tile: 15 us for 10K instances, this path ~4 us).
+    uint32_t v[kTiles], incl[kTiles];
+#pragma unroll
+    for (uint32_t k = 0; k < kTiles; k++) {
+      const uint32_t i = k * 1024u + threadIdx.x;
+      v[k] = i < n ? counts[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kTiles; k++) {
+      incl[k] = wave_incl_scan(v[k], lane);
+      if (lane == 63) s_part[k * 16 + wave] = incl[k];
+    }
     __syncthreads();
-    uint32_t wave_off = 0;
-    for (int k = 0; k < wave; k++) wave_off += s_wave[k];
-    uint32_t carry = s_carry;
-    if (i < n) offsets[i] = carry + wave_off + incl - v;
+    uint32_t p = 0, pin = 0;
+    if (threadIdx.x < 256) {  // totals in element order: index = tile * 16 + wave
+      p = s_part[threadIdx.x];
+      pin = wave_incl_scan(p, lane);
+      if (lane == 63) s_wave[wave] = pin;
+    }
     __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+    if (threadIdx.x < 256) {
+      uint32_t woff = 0;
+      for (int k = 0; k < wave; k++) woff += s_wave[k];
+      s_part[threadIdx.x] = woff + pin - p;  // exclusive
+      if (threadIdx.x == 255) s_carry = woff + pin;
+    }
     __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kTiles; k++) {
+      const uint32_t i = k * 1024u + threadIdx.x;
+      if (i < n) offsets[i] = s_part[k * 16 + wave] + incl[k] - v[k];
+    }
+  } else {
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+      uint32_t i = base + threadIdx.x;
+      uint32_t v = i < n ? counts[i] : 0u;
+      uint32_t incl = wave_incl_scan(v, lane);
+      if (lane == 63) s_wave[wave] = incl;
+      __syncthreads();
+      uint32_t wave_off = 0;
+      for (int k = 0; k < wave; k++) wave_off += s_wave[k];
+      uint32_t carry = s_carry;
+      if (i < n) offsets[i] = carry + wave_off + incl - v;
+      __syncthreads();
+      if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+      __syncthreads();
+    }
   }
   if (threadIdx.x == 0) {
     uint32_t total = s_carry;

@@ -472,3 +472,14 @@ def test_triangle_stage_empty_and_oversized_meshlets(renderer, oracle_lib):
     got = gpu_frame(renderer, gpu)
     assert_same(want, got, ["total", "visible", "indices"])
     assert len(want["indices"]) == 0 and len(want["visible"]) > 0
+
+
+@pytest.mark.parametrize("m,k", [(3000, 5), (16384, 2), (20000, 2)], ids=["3-tiles", "16-tiles", "tile-loop"])
+def test_cull_meshes_scan_paths(renderer, oracle_lib, m, k):
+    """k_scan_mesh_counts: the all-in-registers path (<= 16K mesh instances) and the tile loop beyond it."""
+    spec = SceneSpec(n_mesh_instances=m, meshlets_per_mesh=k, lod_count=2, seed=900 + m, with_geometry=False, scene_depth=400.0)
+    cpu, gpu = _pair(spec)
+    want = oracle_frame(cpu, run_cull_meshes=True, with_triangles=False)
+    got = gpu_frame(renderer, gpu, run_cull_meshes=True, with_triangles=False)
+    assert_same(want, got, ["total", "cull_meshlets_cmd_x", "lod_index", "meshlet_instances", "visible"])
+    assert 0 < want["total"] < m * k
