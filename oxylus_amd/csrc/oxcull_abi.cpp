@@ -53,7 +53,7 @@ struct oxc_ctx {
     uint32_t* t_supers = nullptr;
   };
   Lane lane[kMaxBatch];
-  BatchBlob* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call
+  BatchElem* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call (kMaxBatch elements)
   // oxc_build_meshlet_bounds: per-meshlet {min xyz, max xyz} for all meshlets, then per chunk of kBoundsChunk
   // meshlets the compacted triangle normals (768 B each) and their counts
   float* bounds_scratch = nullptr;
@@ -564,15 +564,14 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     if (st != OXC_OK) return st;
   }
   if (!ctx->batch_dev) {
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->batch_dev), sizeof(BatchBlob));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->batch_dev), sizeof(BatchElem) * kMaxBatch);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(batch argument block)", e);
   }
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t max_grid = ctx->num_cus * 8;
   const bool do_meshes = ci[0].do_meshes, do_meshlets = ci[0].do_meshlets, do_tris = ci[0].do_tris;
-  BatchBlob blob;
-  std::memset(&blob, 0, sizeof blob);
-  blob.count = count;
+  static thread_local BatchElem elems[kMaxBatch];
+  std::memset(elems, 0, sizeof elems);
   uint32_t g_prep = 1, g_expand = 1, g_test = 1, g_emit = 1, g_ttest = 1, g_temit = 1;
   for (uint32_t e = 0; e < count; e++) {
     const oxc_prepared_frame* f = &frames[e];
@@ -600,7 +599,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     c->draw_geometry_cmd_buffer = {draw_cmd, 20};
     const uint32_t m_chunks = cdiv(std::max(N, 1u), kMeshletChunk), t_chunks = cdiv(std::max(N, 1u), kTriChunk);
 
-    PrepareArgs& pa = blob.prep[e];
+    PrepareArgs& pa = elems[e].prep;
     pa.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
     pa.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
     pa.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
@@ -623,11 +622,11 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     pa.view_cache = L.view_cache;
     g_prep = std::max(g_prep, std::min(cdiv(std::max(std::max(M * 8u, pa.n_supers_tris), 1u), 256), max_grid));
 
-    blob.scan[e] = ScanArgs{L.mesh_counts, L.mesh_offsets, M, vis, meshlets_cmd};
-    blob.expand[e] = ExpandArgs{L.mesh_counts, L.mesh_offsets, M, static_cast<GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr)};
+    elems[e].scan = ScanArgs{L.mesh_counts, L.mesh_offsets, M, vis, meshlets_cmd};
+    elems[e].expand = ExpandArgs{L.mesh_counts, L.mesh_offsets, M, static_cast<GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr)};
     g_expand = std::max(g_expand, std::max(std::min(cdiv(M, 4), max_grid), 1u));
 
-    MeshletTestArgs& ta = blob.test[e];
+    MeshletTestArgs& ta = elems[e].test;
     ta.n_host = n_host;
     ta.cache = L.cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
@@ -640,7 +639,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
     g_test = std::max(g_test, std::min(m_chunks, max_grid));
 
-    MeshletEmitArgs& ea = blob.emit[e];
+    MeshletEmitArgs& ea = elems[e].emit;
     ea.n_host = n_host;
     ea.count_meshlets = 64u * kPlainGroups;
     ea.bits = L.bits;
@@ -651,7 +650,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
     g_emit = std::max(g_emit, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid));
 
-    TriTestArgs& tt = blob.ttest[e];
+    TriTestArgs& tt = elems[e].ttest;
     tt.cache = L.cache;
     tt.meshlet_instances = ta.meshlet_instances;
     tt.visible = ea.out;
@@ -662,7 +661,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     tt.supers = L.t_supers;
     g_ttest = std::max(g_ttest, std::min(t_chunks, max_grid));
 
-    TriEmitArgs& te = blob.temit[e];
+    TriEmitArgs& te = elems[e].temit;
     te.tri_masks = L.tri_masks;
     te.visible = ea.out;
     te.vis = vis;
@@ -677,7 +676,14 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   const uint32_t cap = std::max(max_grid / count, ctx->num_cus);
   {
     KernelTimer t(ctx, OXC_K_PREPARE, s);
-    launch_prepare_batch(blob, ctx->batch_dev, g_prep, s);
+    for (uint32_t first = 0; first < count; first += kBatchPerPrepare) {  // kernarg-sized pieces
+      BatchBlob blob;
+      std::memset(&blob, 0, sizeof blob);
+      blob.count = std::min(kBatchPerPrepare, count - first);
+      blob.first = first;
+      std::memcpy(blob.elem, elems + first, sizeof(BatchElem) * blob.count);
+      launch_prepare_batch(blob, ctx->batch_dev, g_prep, s);
+    }
   }
   if (do_meshes) {
     {

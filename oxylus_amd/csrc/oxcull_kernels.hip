@@ -1338,32 +1338,33 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
 // Batched prepare: gets the whole blob by value (kernarg), publishes it for the later kernels of the
 // call, and runs its own element.  The switch keeps the kernarg indexing static (a dynamic index into
 // a by-value aggregate would be lowered through scratch).
-__global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchBlob* __restrict__ dev) {
+__global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchElem* __restrict__ dev) {
   if (blockIdx.x == 0 && blockIdx.y == 0) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&blob);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(dev);
-    for (uint32_t i = threadIdx.x; i < sizeof(BatchBlob) / 4; i += blockDim.x) dst[i] = src[i];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&blob.elem[0]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(dev + blob.first);
+    const uint32_t words = blob.count * (uint32_t)(sizeof(BatchElem) / 4);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
   }
   switch (blockIdx.y) {
-    case 0: prepare_body(blob.prep[0], 0u); break;
-    case 1: prepare_body(blob.prep[1], 0u); break;
-    case 2: prepare_body(blob.prep[2], 0u); break;
-    default: prepare_body(blob.prep[3], 0u); break;
+    case 0: prepare_body(blob.elem[0].prep, 0u); break;
+    case 1: prepare_body(blob.elem[1].prep, 0u); break;
+    case 2: prepare_body(blob.elem[2].prep, 0u); break;
+    default: prepare_body(blob.elem[3].prep, 0u); break;
   }
 }
-__global__ __launch_bounds__(1024) void k_scan_batch(const BatchBlob* __restrict__ dev) { scan_body(dev->scan[blockIdx.y]); }
-__global__ __launch_bounds__(256) void k_expand_batch(const BatchBlob* __restrict__ dev) { expand_body(dev->expand[blockIdx.y]); }
-__global__ __launch_bounds__(64 * kPlainBlockWaves) void k_cull_meshlets_test_batch(const BatchBlob* __restrict__ dev) {
-  meshlets_plain_body<(int)kGroupsPerWave>(dev->test[blockIdx.y]);
+__global__ __launch_bounds__(1024) void k_scan_batch(const BatchElem* __restrict__ dev) { scan_body(dev[blockIdx.y].scan); }
+__global__ __launch_bounds__(256) void k_expand_batch(const BatchElem* __restrict__ dev) { expand_body(dev[blockIdx.y].expand); }
+__global__ __launch_bounds__(64 * kPlainBlockWaves) void k_cull_meshlets_test_batch(const BatchElem* __restrict__ dev) {
+  meshlets_plain_body<(int)kGroupsPerWave>(dev[blockIdx.y].test);
 }
-__global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchBlob* __restrict__ dev) {
-  meshlets_emit_body<false, false>(dev->emit[blockIdx.y]);
+__global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchElem* __restrict__ dev) {
+  meshlets_emit_body<false, false>(dev[blockIdx.y].emit);
 }
-__global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchBlob* __restrict__ dev) {
-  tris_test_body<false, false>(dev->ttest[blockIdx.y]);
+__global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchElem* __restrict__ dev) {
+  tris_test_body<false, false>(dev[blockIdx.y].ttest);
 }
-__global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchBlob* __restrict__ dev) {
-  tris_emit_body<false, false>(dev->temit[blockIdx.y]);
+__global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchElem* __restrict__ dev) {
+  tris_emit_body<false, false>(dev[blockIdx.y].temit);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1381,14 +1382,14 @@ void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, 
   ExpandArgs a{counts, offsets, n, reinterpret_cast<GpuMeshletInstance*>(out)};
   hipLaunchKernelGGL(k_expand_meshlet_instances, dim3(grid), dim3(256), 0, s, a);
 }
-void launch_prepare_batch(const BatchBlob& blob, BatchBlob* dev, uint32_t grid, hipStream_t s) {
+void launch_prepare_batch(const BatchBlob& blob, BatchElem* dev, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_prepare_batch, dim3(grid, blob.count), dim3(256), 0, s, blob, dev);
 }
-void launch_scan_batch(const BatchBlob* dev, uint32_t count, hipStream_t s) { hipLaunchKernelGGL(k_scan_batch, dim3(1, count), dim3(1024), 0, s, dev); }
-void launch_expand_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+void launch_scan_batch(const BatchElem* dev, uint32_t count, hipStream_t s) { hipLaunchKernelGGL(k_scan_batch, dim3(1, count), dim3(1024), 0, s, dev); }
+void launch_expand_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_expand_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
-void launch_meshlets_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+void launch_meshlets_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   // OXC_LDS_PAD (bytes of unused dynamic LDS per block) throttles residency for occupancy experiments
   static const uint32_t lds_pad = [] {
     const char* e = std::getenv("OXC_LDS_PAD");
@@ -1396,13 +1397,13 @@ void launch_meshlets_test_batch(const BatchBlob* dev, uint32_t count, uint32_t g
   }();
   hipLaunchKernelGGL(k_cull_meshlets_test_batch, dim3(grid * (4 / kPlainBlockWaves), count), dim3(64 * kPlainBlockWaves), lds_pad, s, dev);
 }
-void launch_meshlets_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+void launch_meshlets_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_cull_meshlets_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
-void launch_tris_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+void launch_tris_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_cull_triangles_test_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
-void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s) {
+void launch_tris_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_cull_triangles_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
 

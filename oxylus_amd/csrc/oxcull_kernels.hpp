@@ -121,17 +121,23 @@ struct ExpandArgs {
 // Argument blocks of one oxc_cull_geometry_batch call (plain pipeline, <= kMaxBatch independent
 // frames).  Passed by value to the batched prepare kernel, which copies it to the context's device
 // buffer; every later kernel of the call reads its element through blockIdx.y from there.
-constexpr uint32_t kMaxBatch = 4;
+constexpr uint32_t kMaxBatch = 8;       // elements per batched call
+constexpr uint32_t kBatchPerPrepare = 4;  // elements whose argument blocks fit one kernarg segment (k_prepare_batch)
+struct BatchElem {
+  PrepareArgs prep;
+  ScanArgs scan;
+  ExpandArgs expand;
+  MeshletTestArgs test;
+  MeshletEmitArgs emit;
+  TriTestArgs ttest;
+  TriEmitArgs temit;
+};
+// What one k_prepare_batch launch receives by value: up to kBatchPerPrepare elements, which it publishes at
+// dev[first .. first + count) and prepares (blockIdx.y = element).
 struct BatchBlob {
-  PrepareArgs prep[kMaxBatch];
-  ScanArgs scan[kMaxBatch];
-  ExpandArgs expand[kMaxBatch];
-  MeshletTestArgs test[kMaxBatch];
-  MeshletEmitArgs emit[kMaxBatch];
-  TriTestArgs ttest[kMaxBatch];
-  TriEmitArgs temit[kMaxBatch];
+  BatchElem elem[kBatchPerPrepare];
   uint32_t count;
-  uint32_t _pad;
+  uint32_t first;
 };
 static_assert(sizeof(BatchBlob) <= 4000, "must fit the kernarg segment");
 
@@ -153,13 +159,13 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, uint32_t grid,
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
 void launch_hiz(const HizArgs& a, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch
-void launch_prepare_batch(const BatchBlob& blob, BatchBlob* dev, uint32_t grid, hipStream_t s);
-void launch_scan_batch(const BatchBlob* dev, uint32_t count, hipStream_t s);
-void launch_expand_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
-void launch_meshlets_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
-void launch_meshlets_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
-void launch_tris_test_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
-void launch_tris_emit_batch(const BatchBlob* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_prepare_batch(const BatchBlob& blob, BatchElem* dev, uint32_t grid, hipStream_t s);
+void launch_scan_batch(const BatchElem* dev, uint32_t count, hipStream_t s);
+void launch_expand_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_meshlets_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_meshlets_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_tris_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
+void launch_tris_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);

@@ -398,11 +398,13 @@ def test_stage_subsets_and_argument_validation(renderer, oracle_lib):
         expect_invalid(m)
 
 
-def test_batch_falls_back_for_mixed_or_large_batches(renderer, oracle_lib):
-    """More than 4 elements (or a HiZ element) is processed one call at a time with the same results."""
+@pytest.mark.parametrize("count", [6, 8, 10], ids=["6-two-prepare-pieces", "8-max", "10-falls-back"])
+def test_batch_sizes_beyond_one_kernarg_piece(renderer, oracle_lib, count):
+    """Up to 8 elements are fused (their argument blocks are published by two prepare launches of <= 4 elements);
+    more than 8 (or a HiZ element) is processed one call at a time -- always with the same results."""
     from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
 
-    pairs = [_pair(SceneSpec(n_mesh_instances=6, meshlets_per_mesh=40 + 7 * i, seed=100 + i)) for i in range(6)]
+    pairs = [_pair(SceneSpec(n_mesh_instances=6, meshlets_per_mesh=40 + 7 * i, seed=100 + i)) for i in range(count)]
     wants = [oracle_frame(cpu) for cpu, _ in pairs]
     frames, ctxs = [], []
     for _, gpu in pairs:
