@@ -674,9 +674,9 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   }
   // grid.y = count; a modest grid.x cap keeps the whole batch within the resident-block budget
   const uint32_t cap = std::max(max_grid / count, ctx->num_cus);
-  {
-    KernelTimer t(ctx, OXC_K_PREPARE, s);
-    for (uint32_t first = 0; first < count; first += kBatchPerPrepare) {  // kernarg-sized pieces
+  for (uint32_t first = 0; first < count; first += kBatchPerPrepare) {  // kernarg-sized pieces
+    {
+      KernelTimer t(ctx, OXC_K_PREPARE, s);
       BatchBlob blob;
       std::memset(&blob, 0, sizeof blob);
       blob.count = std::min(kBatchPerPrepare, count - first);
