@@ -760,63 +760,71 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
       if (group >= nwords) break;  // wave-uniform
       const uint32_t idx = group * 64 + lane;
       const bool in = idx < N;
-      const uint2 rec = in ? mlis[idx] : make_uint2(0xFFFFFFFFu, 0u);
+      // (unconditional load at a clamped index: an exec-masked load block waits vmcnt(0) inside)
+      uint2 rec = load_stream_u2(reinterpret_cast<uint64_t>(mlis), min(idx, N - 1u));
+      if (!in) rec = make_uint2(0xFFFFFFFFu, 0u);
       bool visible = false;
-      uint64_t pending = __ballot(in);
+      uint64_t pending = __builtin_amdgcn_ballot_w64(in);
       while (pending) {
         const uint32_t mi_u = readlane_u(rec.x, __ffsll((unsigned long long)pending) - 1);
         const bool mine = in && rec.x == mi_u;
-        // camera row: planes + normal matrix + bounds pointer
-        float pl[24], sg[18], nm[9];
-        uint64_t bounds;
-        {
-          const uint32_t* p = reinterpret_cast<const uint32_t*>(a.cache + mi_u);
-          uint32_t v0 = p[lane], v1 = p[64 + (lane & 31)];
-#pragma unroll
-          for (int k = 0; k < 24; k++) pl[k] = readlane_f(v0, kRowPlanes + k);
-#pragma unroll
-          for (int k = 0; k < 18; k++) sg[k] = readlane_f(v0, kRowSigns + k);
-#pragma unroll
-          for (int k = 0; k < 9; k++) nm[k] = readlane_f(v1, kRowNm - 64 + k);
-          bounds = (uint64_t)readlane_u(v1, kRowBounds - 64) | ((uint64_t)readlane_u(v1, kRowBounds - 64 + 1) << 32);
-        }
-        uint4 b = make_uint4(0, 0, 0, 0);
-        if (mine) b = load_global_u4(bounds, rec.y);
+        // camera row through scalar loads: planes + signs, then the normal matrix (never live together with the
+        // per-view operands below)
+        const kconst32p row = const_row(a.cache, mi_u);
+        const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
+        const uint4 b = load_stream_u4(bounds, mine ? rec.y : 0u);  // other lanes read element 0 (always valid)
         const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16), cz = dequantize_half(b.y & 0xFFFFu);
         const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16), ez = dequantize_half(b.w & 0xFFFFu);
-        const float ax = s8_over_127((int32_t)(b.y << 8) >> 24), ay = s8_over_127((int32_t)b.y >> 24);
-        const float az = s8_over_127((int32_t)(b.w << 8) >> 24), cutoff = s8_over_127((int32_t)b.w >> 24);
-        bool cand = mine && test_frustum_planes(pl, sg, cx, cy, cz, ex, ey, ez);
-        cand = cand && cone_visible_directional(nm, a.light_dir[0], a.light_dir[1], a.light_dir[2], ax, ay, az, cutoff);
+        bool cand = mine;
+        {
+          float pl[24], sg[18];
+#pragma unroll
+          for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+#pragma unroll
+          for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
+          cand = cand & test_frustum_planes(pl, sg, cx, cy, cz, ex, ey, ez);
+        }
+        if (__builtin_amdgcn_ballot_w64(cand)) {  // cull_meshlets_hpb.slang:53-54: directional cone
+          float nm[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) nm[k] = asf(row[kRowNm + k]);
+          const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
+          const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
+          cand = cand && cone_visible_directional(nm, a.light_dir[0], a.light_dir[1], a.light_dir[2], axy.x, axy.y, azc.x, azc.y);
+        }
         bool vis = false;
         for (uint32_t v = 0; v < a.clipmap_count; v++) {
-          if (a.dirty[v] == 0u) continue;          // uniform
-          if (!__any(cand && !vis)) break;         // nobody in the wave still needs a view
-          float vpl[24], vsg[18], vmvp[16];
-          {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(a.view_cache + (size_t)v * a.mesh_instance_count + mi_u);
-            uint32_t v0 = p[lane];
-#pragma unroll
-            for (int k = 0; k < 24; k++) vpl[k] = readlane_f(v0, kRowPlanes + k);
-#pragma unroll
-            for (int k = 0; k < 18; k++) vsg[k] = readlane_f(v0, kRowSigns + k);
-#pragma unroll
-            for (int k = 0; k < 16; k++) vmvp[k] = readlane_f(v0, kRowMvp + k);
-          }
-          const oxc_virtual_clipmap* cm = a.clipmaps + v;
-          const float z_near = cm->z_near;
-          const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
+          if (a.dirty[v] == 0u) continue;                                // uniform
+          if (__builtin_amdgcn_ballot_w64(cand && !vis) == 0) break;    // nobody in the wave still needs a view
+          const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
           const bool need = cand && !vis;
-          if (need && test_frustum_planes(vpl, vsg, cx, cy, cz, ex, ey, ez)) {
-            float sa[6];
-            if (project_aabb(vmvp, z_near, cx, cy, cz, ex, ey, ez, sa))
-              vis = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
-            else
-              vis = true;
+          bool inside;
+          {
+            float vpl[24], vsg[18];
+#pragma unroll
+            for (int k = 0; k < 24; k++) vpl[k] = asf(vrow[kRowPlanes + k]);
+#pragma unroll
+            for (int k = 0; k < 18; k++) vsg[k] = asf(vrow[kRowSigns + k]);
+            inside = need & test_frustum_planes(vpl, vsg, cx, cy, cz, ex, ey, ez);
+          }
+          if (__builtin_amdgcn_ballot_w64(inside)) {  // wave-uniform
+            float vmvp[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) vmvp[k] = asf(vrow[kRowMvp + k]);
+            const oxc_virtual_clipmap* cm = a.clipmaps + v;
+            const float z_near = cm->z_near;
+            const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
+            if (inside) {
+              float sa[6];
+              if (project_aabb(vmvp, z_near, cx, cy, cz, ex, ey, ez, sa))
+                vis = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
+              else
+                vis = true;
+            }
           }
         }
         if (mine) visible = vis;
-        pending &= ~__ballot(mine);
+        pending &= ~__builtin_amdgcn_ballot_w64(mine);
       }
       const uint64_t bits = __ballot(visible);
       if (lane == 0) a.bits[group] = bits;

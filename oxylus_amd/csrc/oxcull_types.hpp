@@ -38,7 +38,7 @@ static_assert(sizeof(GpuMesh) == 64, "layout");
 // k_prepare_instances instead of once per meshlet (the reference re-derives mvp/planes/normal
 // matrix in every thread and chases mesh_instance -> mesh -> lods[lod] -> pointer per meshlet,
 // cull_meshlets.slang:37-52).  Same arithmetic, same order => same bits.
-// The row is two coalesced wave loads (dwords 0..63 and 64..95).  Wave-uniform operands are laid
+// The row is read by scalar loads (s_load_dwordx16 and friends).  Wave-uniform operands are laid
 // out in PAIRS so that, once in SGPRs, they feed the packed f32 VALU ops (v_pk_mul_f32 /
 // v_pk_add_f32: two IEEE binary32 operations per instruction, no contraction) directly.
 struct alignas(64) InstCache {
@@ -65,7 +65,7 @@ struct alignas(64) InstCache {
   uint64_t positions;  // Mesh::vertex_positions
 };
 static_assert(sizeof(InstCache) == 384, "layout");
-// dword offsets used by the v_readlane unpackers (lane l of load 0 holds dword l, of load 1 dword 64 + l)
+// dword offsets of the fields: what the kernels' scalar loads index
 enum : int {
   kRowPlanes = 0, kRowSigns = 24, kRowVisOffset = 42, kRowMeshletCount = 43, kRowMvp = 44, kRowScale = 60,
   kRowNm = 64, kRowWorld2 = 74, kRowWorldT2 = 80, kRowWorldR2 = 82, kRowBounds = 86,
