@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=9600)
     ap.add_argument("--warmup", type=int, default=960)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "bounds", "loop"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "bounds", "loop", "vsm"])
     ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses the wide packed index extension (<= 8M meshlets)")
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
@@ -238,6 +238,79 @@ def bench_loop(args, r, dev, stream, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_vsm(args, r, dev, stream, rank, world, dist):
+    """--workload vsm: the virtual-shadow-map cull of draw_virtual_shadowmap (Passes/Shadowmaps.cpp:331-366,433-463):
+    oxc_generate_hpb from a page table, then oxc_cull_geometry(use_hpb) = cull_meshes against the coarsest clipmap +
+    cull_meshlets_hpb over the 10 dirty clipmap views ("visible if any view's pages want it")."""
+    import numpy as np
+    from oxylus_amd.renderer import HpbAttachment
+    from oxylus_amd.synth import pack_clipmaps, virtual_shadow_matrices
+
+    n_meshlets = args.meshlets or 10_000_000
+    K = 1000
+    M = max(1, n_meshlets // K)
+    n_meshlets = M * K
+    steps, warmup = min(args.steps, 50), min(max(args.warmup, 2), 5)
+    light = np.array([0.3, -1.0, 0.2])
+    light /= np.linalg.norm(light)
+    mats, offs, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], light, 500.0, 10.0, 10)
+    with torch.cuda.stream(stream):
+        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=False, lod_count=2, seed=0x0A1DE5 + 11 + rank), dev)
+        r.reserve(M, n_meshlets)
+        frame = PreparedFrame.create(scene, with_triangles=False, expand=False)
+        r.prepared_frame = frame
+        clip = pack_clipmaps(mats, offs, zn).to(dev)
+        g = torch.Generator(device=dev).manual_seed(3 + rank)
+        pt = torch.randint(0, 7, (10, 64, 64), generator=g, device=dev, dtype=torch.int32)
+        pt[torch.rand((10, 64, 64), generator=g, device=dev) < 0.15] = 7
+        hpb = HpbAttachment.create(64, 64, 10, 7, dev)
+        dirty = torch.ones(10, dtype=torch.int32, device=dev)
+        cam = scene.cull_camera()
+        for i in range(16):
+            cam.projection_view[i] = float(mats[9][i])
+        for i in range(3):
+            cam.position[i] = float(-light[i])
+        cam.near_clip = zn
+        ctx = CullGeometryContext(use_hpb=True, init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM, cull_camera=cam, hpb_attachment=hpb,
+                                  vsm_clipmaps_buffer=clip, vsm_clipmap_dirty_flags_buffer=dirty, vsm_clipmap_count=10,
+                                  stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+
+    def one():
+        r.generate_hpb(pt, hpb, stream=stream)
+        r.cull_geometry(ctx, stream=stream)
+
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            one()
+    torch.cuda.synchronize()
+    c = r.read_counters(ctx, stream)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(steps):
+            one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "meshlets/s culled against 10 clipmap views (VSM page pyramid)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SURVEY 8a-14 + 8f-3: generate_hpb + cull_meshes + cull_meshlets_hpb, 10 dirty clipmaps of 64x64 pages, 15 % pages wanted",
+                       "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "after_cull_meshes": c.total_visible_meshlet_instances,
+                       "visible": c.cull_triangles_cmd_x},
+            "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -261,6 +334,8 @@ def main():
         return bench_bounds(args, r, dev, stream, rank, world, dist)
     if args.workload == "loop":
         return bench_loop(args, r, dev, stream, rank, world, dist)
+    if args.workload == "vsm":
+        return bench_vsm(args, r, dev, stream, rank, world, dist)
     sp = C.c_void_p(stream.cuda_stream)
     n_streams = max(1, args.streams) if args.workload == "config2" else 1
     # extra contexts/streams for independent batches in flight (each context owns its scratch)
