@@ -329,6 +329,12 @@ typedef struct oxc_draw_context {
 
 oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* frame, const oxc_draw_context* context, void* hip_stream);
 
+/* Test hook: project_aabb (cull.slang:12-47) of n boxes {center.xyz, extent.xyz} with one matrix: out7 = {min.u, min.v,
+ * min.z, max.u, max.v, max.z, returned ? 1 : 0} per box -- lets the tests compare the device's division fast path with IEEE
+ * division bit for bit. */
+oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float near_clip, const void* boxes6_dptr, uint32_t n, float* out7_dptr,
+                                  void* hip_stream);
+
 /* Harness helper: copy n u32 from device memory (e.g. a callee-owned indirect command) to the host; synchronises the stream. */
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream);
 

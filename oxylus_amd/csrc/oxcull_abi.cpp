@@ -944,6 +944,21 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   return OXC_OK;
 }
 
+oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float near_clip, const void* boxes6_dptr, uint32_t n, float* out7_dptr, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!mvp16_host || !boxes6_dptr || !out7_dptr) return fail(ctx, OXC_INVALID_ARG, "debug_project_aabb: null pointer");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  DebugProjectArgs a;
+  std::memcpy(a.mvp, mvp16_host, 64);
+  a.near_clip = near_clip;
+  a.n = n;
+  a.boxes6 = static_cast<const float*>(boxes6_dptr);
+  a.out7 = out7_dptr;
+  launch_debug_project_aabb(a, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   if (!dptr || !host_out) return fail(ctx, OXC_INVALID_ARG, "debug_read_u32: null pointer");

@@ -309,18 +309,77 @@ OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy,
   for (int k = 6; k >= 0; k--) depth = fminf(P[k][3], depth);
   if (depth < near_clip) return false;
   float vmin[3], vmax[3];
+  // ---- the 24 perspective divisions.  A correctly rounded f32 division is, on this hardware, v_div_scale x2,
+  // v_rcp, two FMAs refining the reciprocal, one multiply and three FMAs refining the quotient, v_div_fmas,
+  // v_div_fixup (~12 instructions).  The scale / fixup steps only act outside a wide exponent window; inside it
+  // the sequence is the plain FMA chain below, and the reciprocal part depends on the denominator alone -- so the
+  // three quotients of a corner share it, and x / y run as one packed chain: bit-identical quotients for ~5
+  // instructions each.  The window is checked per lane (all |numerators| <= 2^60, every z numerator >= 2^-60 in
+  // magnitude, all w in [2^-30, 2^60]); x / y numerators below the window only produce |q| < 2^-25, which the
+  // caller's q * 0.5 + 0.5 maps to exactly 0.5 on either path.  If any lane of the wave is outside the window the
+  // wave takes the IEEE divisions.  (tests: test_project_aabb_matches_ieee_division_bit_for_bit)
+  float amax = 0.0f, zmin = 3.402823466e+38f, wmax = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    float lo = P[7][j] / P[7][3];
-    float hi = lo;
+  for (int k = 0; k < 8; k++) {
+    amax = fmaxf(amax, fmaxf(fmaxf(__builtin_fabsf(P[k][0]), __builtin_fabsf(P[k][1])), __builtin_fabsf(P[k][2])));
+    zmin = fminf(zmin, __builtin_fabsf(P[k][2]));
+    wmax = fmaxf(wmax, P[k][3]);
+  }
+  const bool in_window = amax <= 1.152921504606846976e18f && zmin >= 8.673617379884035e-19f && depth >= 9.313225746154785e-10f &&
+                         wmax <= 1.152921504606846976e18f;
+  if (__builtin_amdgcn_ballot_w64(!in_window) == 0) {
+    float qx[8], qy[8], qz[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float w = P[k][3];
+      const float r0 = __builtin_amdgcn_rcpf(w);
+      const float e = __builtin_fmaf(-w, r0, 1.0f);
+      const float r = __builtin_fmaf(e, r0, r0);
+      const f2 n = {P[k][0], P[k][1]};
+      const f2 nw = splat(-w), rr = splat(r);
+      f2 q = n * rr;
+      f2 e1 = __builtin_elementwise_fma(nw, q, n);
+      q = __builtin_elementwise_fma(e1, rr, q);
+      e1 = __builtin_elementwise_fma(nw, q, n);
+      q = __builtin_elementwise_fma(e1, rr, q);
+      qx[k] = q.x;
+      qy[k] = q.y;
+      const float nz = P[k][2];
+      float z = nz * r;
+      float ez = __builtin_fmaf(-w, z, nz);
+      z = __builtin_fmaf(ez, r, z);
+      ez = __builtin_fmaf(-w, z, nz);
+      qz[k] = __builtin_fmaf(ez, r, z);
+    }
+    float lo[3] = {qx[7], qy[7], qz[7]}, hi[3] = {qx[7], qy[7], qz[7]};
 #pragma unroll
     for (int k = 6; k >= 0; k--) {
-      float d = P[k][j] / P[k][3];
-      lo = fminf(d, lo);
-      hi = fmaxf(d, hi);
+      lo[0] = fminf(qx[k], lo[0]);
+      hi[0] = fmaxf(qx[k], hi[0]);
+      lo[1] = fminf(qy[k], lo[1]);
+      hi[1] = fmaxf(qy[k], hi[1]);
+      lo[2] = fminf(qz[k], lo[2]);
+      hi[2] = fmaxf(qz[k], hi[2]);
     }
-    vmin[j] = lo;
-    vmax[j] = hi;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      vmin[j] = lo[j];
+      vmax[j] = hi[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float lo = P[7][j] / P[7][3];
+      float hi = lo;
+#pragma unroll
+      for (int k = 6; k >= 0; k--) {
+        float d = P[k][j] / P[k][3];
+        lo = fminf(d, lo);
+        hi = fmaxf(d, hi);
+      }
+      vmin[j] = lo;
+      vmax[j] = hi;
+    }
   }
   out[0] = vmin[0] * 0.5f + 0.5f;
   out[1] = vmin[1] * 0.5f + 0.5f;

@@ -1476,6 +1476,20 @@ void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s) { hipLaunch
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(p), bytes / 16, sink);
 }
+__global__ __launch_bounds__(256) void k_debug_project_aabb(DebugProjectArgs a) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    const float* b = a.boxes6 + (size_t)i * 6;
+    float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool ok = project_aabb(a.mvp, a.near_clip, b[0], b[1], b[2], b[3], b[4], b[5], sa);
+    float* o = a.out7 + (size_t)i * 7;
+#pragma unroll
+    for (int k = 0; k < 6; k++) o[k] = ok ? sa[k] : 0.0f;
+    o[6] = ok ? 1.0f : 0.0f;
+  }
+}
+void launch_debug_project_aabb(const DebugProjectArgs& a, hipStream_t s) {
+  if (a.n) hipLaunchKernelGGL(k_debug_project_aabb, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s) {
   hipLaunchKernelGGL(k_debug_decode_bounds, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint4*>(bounds), n, out10);
 }

@@ -169,6 +169,14 @@ void launch_tris_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid,
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
+struct DebugProjectArgs {
+  float mvp[16];
+  float near_clip;
+  uint32_t n;
+  const float* boxes6;
+  float* out7;
+};
+void launch_debug_project_aabb(const DebugProjectArgs& a, hipStream_t s);
 // oxcull_raster.hip: consumer of the indirect draw
 struct TriSetup;
 struct DrawArgs {

@@ -195,6 +195,7 @@ EXPORTS = [
     "oxc_cull_terrain",
     "oxc_draw_visbuffer",
     "oxc_debug_read_u32",
+    "oxc_debug_project_aabb",
 ]
 
 
@@ -240,6 +241,7 @@ def load() -> C.CDLL:
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.oxc_debug_project_aabb.argtypes = [vp, C.POINTER(C.c_float), C.c_float, vp, C.c_uint32, vp, vp]
     lib.oxc_draw_visbuffer.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(DrawContext), vp]
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):

@@ -338,6 +338,14 @@ class RendererInstance:
         self._keep = (visdepth, depth, visbuffer)
         self._check(self._lib.oxc_draw_visbuffer(self._ctx, C.byref(f), C.byref(d), self._stream(stream)))
 
+    def debug_project_aabb(self, mvp16, near_clip: float, boxes6: torch.Tensor) -> torch.Tensor:
+        """boxes6 f32 [n, 6] = {center.xyz, extent.xyz} -> f32 [n, 7] = {min.u, min.v, min.z, max.u, max.v, max.z, valid}."""
+        n = boxes6.shape[0]
+        out = torch.empty((n, 7), dtype=torch.float32, device=boxes6.device)
+        m = (C.c_float * 16)(*[float(v) for v in mvp16])
+        self._check(self._lib.oxc_debug_project_aabb(self._ctx, m, float(near_clip), C.c_void_p(boxes6.data_ptr()), n, C.c_void_p(out.data_ptr()), self._stream(None)))
+        return out
+
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))
 
