@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="frames per oxc_cull_geometry_batch call (1 = one call per step; max 8)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="multi-GPU: run the two exchanges of the path (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
+                         "(oxc_exchange_counts / oxc_broadcast_hiz) instead of torch.distributed; the rendezvous stays torch.distributed")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     return ap.parse_args()
 
@@ -330,6 +333,11 @@ def main():
     r = RendererInstance(local_rank)
     lib, ctxp = r._lib, r._ctx
     stream = torch.cuda.Stream(device=dev)
+    native_comm = bool(args.native_comm and dist is not None)
+    if native_comm:
+        box = [r.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        r.comm_init(box[0], rank, world)
     if args.workload == "bounds":
         return bench_bounds(args, r, dev, stream, rank, world, dist)
     if args.workload == "loop":
@@ -468,7 +476,10 @@ def main():
         if world == 1 or rank == 0:
             check(lib.oxc_generate_hiz(ctxp, pmg, sp))
         if dist is not None:
-            dist.broadcast(hiz.data, src=0)
+            if native_comm:
+                r.broadcast_hiz(hiz, 0, stream)
+            else:
+                dist.broadcast(hiz.data, src=0)
         st.cctx.cull_flags = L.CULL_TEST_ALL
         check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
         st.cctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
@@ -540,6 +551,12 @@ def main():
         my_counts = torch.tensor([counts["emitted"], counts["early"], counts["late"], counts["index_count"]], dtype=torch.int32, device=dev)
         gathered = torch.zeros(world * 4, dtype=torch.int32, device=dev)  # flat all-gather target, [world, 4] counters
 
+    def gather_counts():
+        if native_comm:
+            check(lib.oxc_exchange_counts(ctxp, C.c_void_p(my_counts.data_ptr()), C.c_void_p(gathered.data_ptr()), sp))
+        else:
+            dist.all_gather_into_tensor(gathered, my_counts)
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -555,7 +572,7 @@ def main():
                 graph.replay()
                 done += per_replay
                 if dist is not None:  # per-rank visible counts -> every rank (north star's all-gather), bucketed per rotation
-                    dist.all_gather_into_tensor(gathered, my_counts)
+                    gather_counts()
         while args.steps - done >= steps_per_call:
             run_unit(done // steps_per_call)
             done += steps_per_call
@@ -563,7 +580,7 @@ def main():
             run_step(done)
             done += 1
         if dist is not None and graph is None:
-            dist.all_gather_into_tensor(gathered, my_counts)
+            gather_counts()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()

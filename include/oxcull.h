@@ -329,6 +329,23 @@ typedef struct oxc_draw_context {
 
 oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* frame, const oxc_draw_context* context, void* hip_stream);
 
+/* ---- multi-GPU exchange: one process per GPU, RCCL over xGMI ---------------------------
+ * The meshlet-instance array shards by contiguous range and every rank culls its shard on its own; the only
+ * exchanges of the path are (1) the per-rank counters {emitted meshlets, early, late, index count} to every rank
+ * (16 bytes per rank) so that each can place its compacted buffers in a merged list, and (2) the HiZ pyramid from
+ * the rank that owns the depth buffer.  These entry points are those two collectives on the caller's stream,
+ * through RCCL (loaded with dlopen, so the single-GPU path does not need the library).
+ *   rank 0: oxc_comm_unique_id(id) -> the launcher hands the 128 bytes to the other ranks (any side channel)
+ *   all:    oxc_comm_init(ctx, id, rank, world)                                                          */
+#define OXC_COMM_UNIQUE_ID_BYTES 128
+oxc_status oxc_comm_unique_id(oxc_ctx* ctx, void* id128_host_out);
+oxc_status oxc_comm_init(oxc_ctx* ctx, const void* id128_host, uint32_t rank, uint32_t world);
+oxc_status oxc_comm_destroy(oxc_ctx* ctx);
+/* all-gather of 4 u32 per rank: counts4_dptr (this rank's {emitted, early, late, index_count}) -> all_counts_dptr[world][4] */
+oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all_counts_dptr, void* hip_stream);
+/* broadcast of every level of `hiz` from rank `root` (in place) */
+oxc_status oxc_broadcast_hiz(oxc_ctx* ctx, const oxc_image* hiz, uint64_t total_bytes, uint32_t root, void* hip_stream);
+
 /* Test hook: project_aabb (cull.slang:12-47) of n boxes {center.xyz, extent.xyz} with one matrix: out7 = {min.u, min.v,
  * min.z, max.u, max.v, max.z, returned ? 1 : 0} per box -- lets the tests compare the device's division fast path with IEEE
  * division bit for bit. */

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <new>
 #include <string>
@@ -59,6 +60,8 @@ struct oxc_ctx {
   float* bounds_scratch = nullptr;
   uint32_t bounds_scratch_cap = 0;
   void* raster_scratch = nullptr;  // oxc_draw_visbuffer: list of large triangles + its counter
+  void* comm = nullptr;            // ncclComm_t (oxc_comm_init)
+  uint32_t comm_rank = 0, comm_world = 0;
   // counter slots
   uint32_t* slots = nullptr;
   uint32_t slot_cursor = 0;
@@ -280,6 +283,7 @@ void oxc_destroy(oxc_ctx* ctx) {
   if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
   if (ctx->bounds_scratch) (void)hipFree(ctx->bounds_scratch);
   if (ctx->raster_scratch) (void)hipFree(ctx->raster_scratch);
+  if (ctx->comm) (void)oxc_comm_destroy(ctx);
   if (ctx->slots) (void)hipFree(ctx->slots);
   delete ctx;
 }
@@ -942,6 +946,106 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
                         static_cast<uint32_t*>(d->visbuffer_attachment.dptr), ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
+}
+
+// ---- RCCL through dlopen: the exchange entry points are the only users ----
+struct OxcRcclId {  // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+  char internal[OXC_COMM_UNIQUE_ID_BYTES];
+};
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, OxcRcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (r.lib) {
+      r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+      r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+      r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+      r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
+      r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    }
+  }
+  return (r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Broadcast) ? &r : nullptr;
+}
+oxc_status rccl_fail(oxc_ctx* ctx, const char* what, int code) {
+  static thread_local std::string msg;
+  Rccl* r = rccl();
+  msg = std::string(what) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(code) : "RCCL error");
+  ctx->last_error = msg;
+  return OXC_RCCL_ERROR;
+}
+constexpr int kNcclUint8 = 1, kNcclUint32 = 3;  // ncclDataType_t values (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3)
+}  // namespace
+
+oxc_status oxc_comm_unique_id(oxc_ctx* ctx, void* id128_host_out) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!id128_host_out) return fail(ctx, OXC_INVALID_ARG, "comm_unique_id: null output");
+  Rccl* r = rccl();
+  if (!r) return fail(ctx, OXC_RCCL_ERROR, "librccl.so could not be loaded (needed only for the multi-GPU exchange)");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = r->GetUniqueId(id128_host_out);
+  return rc == 0 ? OXC_OK : rccl_fail(ctx, "ncclGetUniqueId", rc);
+}
+
+oxc_status oxc_comm_init(oxc_ctx* ctx, const void* id128_host, uint32_t rank, uint32_t world) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!id128_host || world == 0 || rank >= world) return fail(ctx, OXC_INVALID_ARG, "comm_init: null id or rank >= world");
+  if (ctx->comm) return fail(ctx, OXC_INVALID_ARG, "comm_init: the context already has a communicator");
+  Rccl* r = rccl();
+  if (!r) return fail(ctx, OXC_RCCL_ERROR, "librccl.so could not be loaded (needed only for the multi-GPU exchange)");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OxcRcclId id;
+  std::memcpy(&id, id128_host, sizeof id);
+  int rc = r->CommInitRank(&ctx->comm, (int)world, id, (int)rank);
+  if (rc != 0) {
+    ctx->comm = nullptr;
+    return rccl_fail(ctx, "ncclCommInitRank", rc);
+  }
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  return OXC_OK;
+}
+
+oxc_status oxc_comm_destroy(oxc_ctx* ctx) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (ctx->comm) {
+    Rccl* r = rccl();
+    if (r) (void)r->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 0;
+  }
+  return OXC_OK;
+}
+
+oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all_counts_dptr, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!ctx->comm) return fail(ctx, OXC_INVALID_ARG, "exchange_counts: oxc_comm_init has not been called");
+  if (!counts4_dptr || !all_counts_dptr) return fail(ctx, OXC_INVALID_ARG, "exchange_counts: null buffer");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = rccl()->AllGather(counts4_dptr, all_counts_dptr, 4, kNcclUint32, ctx->comm, static_cast<hipStream_t>(hip_stream));
+  return rc == 0 ? OXC_OK : rccl_fail(ctx, "ncclAllGather", rc);
+}
+
+oxc_status oxc_broadcast_hiz(oxc_ctx* ctx, const oxc_image* hiz, uint64_t total_bytes, uint32_t root, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!ctx->comm) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz: oxc_comm_init has not been called");
+  if (!hiz || !hiz->dptr || total_bytes == 0 || root >= ctx->comm_world) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz: null image, zero size or bad root");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = rccl()->Broadcast(hiz->dptr, hiz->dptr, (size_t)total_bytes, kNcclUint8, (int)root, ctx->comm, static_cast<hipStream_t>(hip_stream));
+  return rc == 0 ? OXC_OK : rccl_fail(ctx, "ncclBroadcast", rc);
 }
 
 oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float near_clip, const void* boxes6_dptr, uint32_t n, float* out7_dptr, void* hip_stream) {

@@ -194,6 +194,11 @@ EXPORTS = [
     "oxc_generate_hpb",
     "oxc_cull_terrain",
     "oxc_draw_visbuffer",
+    "oxc_comm_unique_id",
+    "oxc_comm_init",
+    "oxc_comm_destroy",
+    "oxc_exchange_counts",
+    "oxc_broadcast_hiz",
     "oxc_debug_read_u32",
     "oxc_debug_project_aabb",
 ]
@@ -241,6 +246,11 @@ def load() -> C.CDLL:
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.oxc_comm_unique_id.argtypes = [vp, vp]
+    lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    lib.oxc_comm_destroy.argtypes = [vp]
+    lib.oxc_exchange_counts.argtypes = [vp, vp, vp, vp]
+    lib.oxc_broadcast_hiz.argtypes = [vp, C.POINTER(Image), C.c_uint64, C.c_uint32, vp]
     lib.oxc_debug_project_aabb.argtypes = [vp, C.POINTER(C.c_float), C.c_float, vp, C.c_uint32, vp, vp]
     lib.oxc_draw_visbuffer.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(DrawContext), vp]
     for name in EXPORTS:

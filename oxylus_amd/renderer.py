@@ -346,6 +346,31 @@ class RendererInstance:
         self._check(self._lib.oxc_debug_project_aabb(self._ctx, m, float(near_clip), C.c_void_p(boxes6.data_ptr()), n, C.c_void_p(out.data_ptr()), self._stream(None)))
         return out
 
+    # ---- multi-GPU exchange through the C ABI (RCCL): SURVEY 8e ----
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.oxc_comm_unique_id(self._ctx, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._check(self._lib.oxc_comm_init(self._ctx, C.c_char_p(unique_id), rank, world))
+        self._comm_world = world
+
+    def comm_destroy(self):
+        self._check(self._lib.oxc_comm_destroy(self._ctx))
+
+    def exchange_counts(self, counts4: torch.Tensor, stream=None) -> torch.Tensor:
+        """counts4: int32 [4] on the device -> int32 [world, 4] (all-gather on the stream)."""
+        out = torch.empty((self._comm_world, 4), dtype=torch.int32, device=counts4.device)
+        self._keep = (counts4, out)
+        self._check(self._lib.oxc_exchange_counts(self._ctx, C.c_void_p(counts4.data_ptr()), C.c_void_p(out.data_ptr()), self._stream(stream)))
+        return out
+
+    def broadcast_hiz(self, hiz: "ImageAttachment", root: int, stream=None):
+        im = hiz.c()
+        self._check(self._lib.oxc_broadcast_hiz(self._ctx, C.byref(im), hiz.data.numel() * 4, root, self._stream(stream)))
+
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))
 

@@ -519,3 +519,28 @@ def test_project_aabb_matches_ieee_division_bit_for_bit(renderer, oracle_lib):
         gu, wu = got[ok][:, [0, 1, 3, 4, 5]].view(np.uint32), want[ok][:, [0, 1, 3, 4, 5]].view(np.uint32)
         assert np.array_equal(gu, wu), f"{name}: {int((gu != wu).any(1).sum())} boxes differ"
         assert ok.sum() > n // 4
+
+
+def test_comm_entry_points_single_rank(oracle_lib):
+    """oxc_comm_* / oxc_exchange_counts / oxc_broadcast_hiz on a world of one: RCCL is loaded, a communicator
+    comes up on the stream, the all-gather returns this rank's counters, the broadcast leaves the root's pyramid intact."""
+    from oxylus_amd.renderer import ImageAttachment, RendererInstance
+
+    r = RendererInstance(0)
+    uid = r.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    r.comm_init(uid, 0, 1)
+    mine = torch.tensor([11, 22, 33, 44], dtype=torch.int32, device="cuda")
+    got = r.exchange_counts(mine)
+    hiz = ImageAttachment.hiz(64, 64, "cuda")
+    hiz.data.copy_(torch.arange(hiz.data.numel(), dtype=torch.float32))
+    r.broadcast_hiz(hiz, 0)
+    torch.cuda.synchronize()
+    assert got.cpu().tolist() == [[11, 22, 33, 44]]
+    assert torch.equal(hiz.data.cpu(), torch.arange(hiz.data.numel(), dtype=torch.float32))
+    from oxylus_amd.lib import OxcError
+    with pytest.raises(OxcError):
+        r.comm_init(uid, 0, 1)  # already initialised
+    r.comm_destroy()
+    with pytest.raises(OxcError):
+        r.exchange_counts(mine)
