@@ -87,24 +87,41 @@ OXC_DEV bool tri_setup(const DrawArgs& a, uint32_t tri, TriSetup& out) {
   int64_t X[3], Y[3];
   float z[3];
   bool drop = false;
+  // The three indices of a triangle written by cull_triangles name the same meshlet instance, so everything up to
+  // the Meshlet record and the world matrix is fetched once and reused while the instance id repeats (vs_main
+  // decodes every index on its own; an index list that mixes instances inside a triangle still works, slower).
+  uint32_t cur_mli = 0xFFFFFFFFu;
+  uint4 ml = make_uint4(0, 0, 0, 0);
+  uint64_t micro = 0, vidx = 0, positions = 0;
+  float w[12] = {0};  // rows 0..2 of world
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const uint32_t data = a.indices[tri * 3u + (uint32_t)k];
     const uint32_t mli_index = data >> corner_bits, corner = data & corner_mask;
-    const uint2 mli = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli_index];
-    const GpuMeshInstance inst = a.mesh_instances[mli.x];
-    const GpuMesh* mesh = a.meshes + inst.mesh_index;
-    const GpuMeshLOD* lod = reinterpret_cast<const GpuMeshLOD*>(mesh->lods) + inst.lod_index;
-    const uint4 ml = load_global_u4(lod->meshlets, mli.y);  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
+    if (mli_index != cur_mli) {
+      cur_mli = mli_index;
+      const uint2 mli = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli_index];
+      const GpuMeshInstance inst = a.mesh_instances[mli.x];
+      const GpuMesh* mesh = a.meshes + inst.mesh_index;
+      const GpuMeshLOD* lod = reinterpret_cast<const GpuMeshLOD*>(mesh->lods) + inst.lod_index;
+      ml = load_global_u4(lod->meshlets, mli.y);  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
+      micro = lod->local_triangle_indices;
+      vidx = lod->indirect_vertex_indices;
+      positions = mesh->vertex_positions;
+      const float* wm = a.transforms + (size_t)inst.transform_index * 16;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) w[r * 4 + c] = OXC_M(wm, r, c);
+    }
     const uint32_t boff = ml.y + corner;
-    const uint32_t li = (load_global_u32(lod->local_triangle_indices, boff >> 2) >> ((boff & 3u) * 8u)) & 0xFFu;  // scene.slang:336-348
-    const uint32_t vi = load_global_u32(lod->indirect_vertex_indices, ml.x + li);
-    const uint2 q = load_global_u2(mesh->vertex_positions, vi);  // u16x4
+    const uint32_t li = (load_global_u32(micro, boff >> 2) >> ((boff & 3u) * 8u)) & 0xFFu;  // scene.slang:336-348
+    const uint32_t vi = load_global_u32(vidx, ml.x + li);
+    const uint2 q = load_global_u2(positions, vi);  // u16x4
     const float p[3] = {dequantize_half(q.x & 0xFFFFu), dequantize_half(q.x >> 16), dequantize_half(q.y & 0xFFFFu)};
-    const float* w = a.transforms + (size_t)inst.transform_index * 16;
     float world[3], clip[4];
 #pragma unroll
-    for (int r = 0; r < 3; r++) world[r] = ((OXC_M(w, r, 0) * p[0] + OXC_M(w, r, 1) * p[1]) + OXC_M(w, r, 2) * p[2]) + OXC_M(w, r, 3);
+    for (int r = 0; r < 3; r++) world[r] = ((w[r * 4 + 0] * p[0] + w[r * 4 + 1] * p[1]) + w[r * 4 + 2] * p[2]) + w[r * 4 + 3];
 #pragma unroll
     for (int r = 0; r < 4; r++) clip[r] = ((OXC_M(a.pv, r, 0) * world[0] + OXC_M(a.pv, r, 1) * world[1]) + OXC_M(a.pv, r, 2) * world[2]) + OXC_M(a.pv, r, 3);
     if (k == 0) out.vis = (mli_index << 8) | ((corner / 3u) & 0xFFu);  // VisBufferData(mli, triangle_index / 3).encode()
