@@ -308,7 +308,8 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* context, void* hi
  *           screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel; back faces (fixed-point
  *           area >= 0, the orientation cull_triangles' determinant test calls back-facing) are dropped;
  *   cover   pixel centres, integer edge functions, top-left rule;
- *   depth   z/w interpolated in binary64 from the exact edge values, rounded to binary32, kept when in (0, 1];
+ *   depth   z/w interpolated in binary64, ((e0 z0 + e1 z1) + e2 z2) * (1 / area) with the exact integer edge values e_i, rounded to
+ *           binary32, kept when in (0, 1];
  *           per pixel the maximum of (depth bits << 32) | vis wins (64-bit atomic max), vis = (instance << 8) |
  *           (corner / 3) as VisBufferData::encode -- order-independent: one of the results the reference's
  *           equal-depth race can produce.

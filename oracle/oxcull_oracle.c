@@ -1144,6 +1144,7 @@ void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const o
     const int64_t b0 = edge_inclusive(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
     const int64_t b1 = edge_inclusive(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
     const int64_t b2 = edge_inclusive(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
+    const double inv_area = 1.0 / (double)area; /* one reciprocal per triangle */
     for (int64_t py = py0; py <= py1; py++)
       for (int64_t px = px0; px <= px1; px++) {
         int64_t cxp = px * 256 + 128, cyp = py * 256 + 128;
@@ -1151,7 +1152,7 @@ void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const o
         int64_t e1 = edge_fn(X[2], Y[2], X[0], Y[0], cxp, cyp);
         int64_t e2 = edge_fn(X[0], Y[0], X[1], Y[1], cxp, cyp);
         if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) continue;
-        double zd = (((double)e0 * (double)z[0] + (double)e1 * (double)z[1]) + (double)e2 * (double)z[2]) / (double)area;
+        double zd = (((double)e0 * (double)z[0] + (double)e1 * (double)z[1]) + (double)e2 * (double)z[2]) * inv_area;
         float zf = (float)zd;
         if (!(zf > 0.0f) || zf > 1.0f) continue;
         uint64_t packed = ((uint64_t)f2u(zf) << 32) | vis_out;

@@ -260,7 +260,7 @@ uint32_t orc_cull_terrain(const float* world_min2, const float* world_size2, uin
  *           screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel (nearest);
  *           back faces (signed fixed-point area >= 0, the sign cull_triangles' determinant test uses) dropped;
  *   cover:  pixel centres, integer edge functions, top-left rule;
- *   depth:  z/w interpolated with the exact edge values in binary64, rounded to binary32; fragments outside
+ *   depth:  z/w interpolated in binary64: (e0 z0 + e1 z1 + e2 z2) * (1 / area) with the exact integer edge values, rounded to binary32; fragments outside
  *           (0, 1] dropped; per pixel the maximum of (depth bits << 32) | vis wins, vis = (instance << 8) |
  *           (corner / 3) (VisBufferData::encode) -- order-independent, i.e. one of the results the
  *           reference's race between equal-depth fragments can produce.

@@ -43,6 +43,8 @@ struct TriRaster {
   uint32_t vis;
   int64_t area, b0, b1, b2;
   int64_t px0, px1, py0, py1;
+  double inv_area;
+  int64_t dx0, dx1, dx2, dy0, dy1, dy2;  // change of the three edge functions per pixel step in x / in y (exact)
 };
 
 OXC_DEV void tri_prepare(const TriSetup& t, uint32_t W, uint32_t H, TriRaster& r) {
@@ -64,18 +66,30 @@ OXC_DEV void tri_prepare(const TriSetup& t, uint32_t W, uint32_t H, TriRaster& r
   r.b0 = edge_inclusive(r.X[1], r.Y[1], r.X[2], r.Y[2]) ? 0 : -1;
   r.b1 = edge_inclusive(r.X[2], r.Y[2], r.X[0], r.Y[0]) ? 0 : -1;
   r.b2 = edge_inclusive(r.X[0], r.Y[0], r.X[1], r.Y[1]) ? 0 : -1;
+  r.inv_area = 1.0 / (double)r.area;  // one reciprocal per triangle
+  // E(a->b)(p) = (bx - ax)(py - ay) - (by - ay)(px - ax): one pixel = 256 units
+  r.dx0 = -(r.Y[2] - r.Y[1]) * 256;
+  r.dy0 = (r.X[2] - r.X[1]) * 256;
+  r.dx1 = -(r.Y[0] - r.Y[2]) * 256;
+  r.dy1 = (r.X[0] - r.X[2]) * 256;
+  r.dx2 = -(r.Y[1] - r.Y[0]) * 256;
+  r.dy2 = (r.X[1] - r.X[0]) * 256;
 }
 
-OXC_DEV void tri_pixel(const TriRaster& r, int64_t px, int64_t py, uint32_t W, unsigned long long* visdepth) {
+// edge values (weights of corners 0, 1, 2) at the centre of pixel (px, py)
+OXC_DEV void tri_edges(const TriRaster& r, int64_t px, int64_t py, int64_t& e0, int64_t& e1, int64_t& e2) {
   const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
-  const int64_t e0 = edge_fn(r.X[1], r.Y[1], r.X[2], r.Y[2], cx, cy);  // weight of corner 0
-  const int64_t e1 = edge_fn(r.X[2], r.Y[2], r.X[0], r.Y[0], cx, cy);
-  const int64_t e2 = edge_fn(r.X[0], r.Y[0], r.X[1], r.Y[1], cx, cy);
+  e0 = edge_fn(r.X[1], r.Y[1], r.X[2], r.Y[2], cx, cy);
+  e1 = edge_fn(r.X[2], r.Y[2], r.X[0], r.Y[0], cx, cy);
+  e2 = edge_fn(r.X[0], r.Y[0], r.X[1], r.Y[1], cx, cy);
+}
+OXC_DEV void tri_fragment(const TriRaster& r, int64_t e0, int64_t e1, int64_t e2, int64_t px, int64_t py, uint32_t W, unsigned long long* visdepth) {
   if (e0 + r.b0 < 0 || e1 + r.b1 < 0 || e2 + r.b2 < 0) return;
-  const double zd = (((double)e0 * (double)r.z[0] + (double)e1 * (double)r.z[1]) + (double)e2 * (double)r.z[2]) / (double)r.area;
+  const double zd = (((double)e0 * (double)r.z[0] + (double)e1 * (double)r.z[1]) + (double)e2 * (double)r.z[2]) * r.inv_area;
   const float zf = (float)zd;
   if (!(zf > 0.0f) || zf > 1.0f) return;
   const unsigned long long packed = ((unsigned long long)asu(zf) << 32) | r.vis;
+  // (reading the stored value first to skip occluded fragments was measured slower: 1.61 -> 2.15 ms per frame)
   atomicMax(&visdepth[(size_t)py * W + (size_t)px], packed);
 }
 
@@ -176,8 +190,20 @@ __global__ __launch_bounds__(256) void k_draw_setup(DrawArgs a) {
       }
       small = true;  // the list is full: this lane walks the box itself (slow, correct)
     }
-    for (int64_t py = r.py0; py <= r.py1; py++)
-      for (int64_t px = r.px0; px <= r.px1; px++) tri_pixel(r, px, py, a.width, a.visdepth);
+    int64_t r0, r1, r2;  // edge values at the start of the row: stepped exactly (integers) instead of re-multiplied
+    tri_edges(r, r.px0, r.py0, r0, r1, r2);
+    for (int64_t py = r.py0; py <= r.py1; py++) {
+      int64_t e0 = r0, e1 = r1, e2 = r2;
+      for (int64_t px = r.px0; px <= r.px1; px++) {
+        tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
+        e0 += r.dx0;
+        e1 += r.dx1;
+        e2 += r.dx2;
+      }
+      r0 += r.dy0;
+      r1 += r.dy1;
+      r2 += r.dy2;
+    }
   }
 }
 
@@ -187,7 +213,12 @@ __global__ __launch_bounds__(256) void k_draw_big(DrawArgs a) {
     TriRaster r;
     tri_prepare(a.big_list[i], a.width, a.height, r);
     const int64_t bw = r.px1 - r.px0 + 1, bh = r.py1 - r.py0 + 1;
-    for (int64_t k = threadIdx.x; k < bw * bh; k += blockDim.x) tri_pixel(r, r.px0 + k % bw, r.py0 + k / bw, a.width, a.visdepth);
+    for (int64_t k = threadIdx.x; k < bw * bh; k += blockDim.x) {
+      const int64_t px = r.px0 + k % bw, py = r.py0 + k / bw;
+      int64_t e0, e1, e2;
+      tri_edges(r, px, py, e0, e1, e2);
+      tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
+    }
   }
 }
 
