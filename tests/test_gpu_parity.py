@@ -544,3 +544,48 @@ def test_comm_entry_points_single_rank(oracle_lib):
     r.comm_destroy()
     with pytest.raises(OxcError):
         r.exchange_counts(mine)
+
+
+def test_maximum_instance_count_of_the_packed_index(renderer, oracle_lib):
+    """The reference's packed index holds a 24-bit meshlet-instance id (visbuffer.slang:9-14): the largest frame the
+    triangle stage accepts has 2^24 instances.  Just below the limit the ids in the top byte range must come out right
+    (compared with the oracle on the tail of the visible list); above it the call is refused."""
+    import oracle
+    from oxylus_amd.lib import OxcError
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    K = 1000
+    spec = SceneSpec(n_mesh_instances=16777, meshlets_per_mesh=K, share_meshes=2, seed=501, scene_depth=900.0)   # 16 777 000 < 2^24
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    N = cpu.n_meshlet_instances
+    cam = cpu.cull_camera()
+    want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances, nthreads=16)
+    frame = PreparedFrame.create(gpu)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera())
+    renderer.seed_meshlet_instances(ctx, N)
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    got_vis = frame.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu()
+    assert torch.equal(got_vis, want_vis)
+    assert int(want_vis.max()) >= (1 << 23)                 # ids with the top bit of the 24-bit field set are in play
+    # triangles of the last 64 visible meshlets (largest ids): their packed indices are the tail of the GPU list
+    tail = 64
+    want_tail = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, want_vis.numel() - tail, tail)
+    got_idx = frame.reordered_indices_buffer[c.draw_index_count - want_tail.numel(): c.draw_index_count].cpu()
+    assert torch.equal(got_idx, want_tail)
+    assert int((got_idx.to(torch.int64) & 0xFFFFFFFF).max() >> 8) == int(want_vis[-tail:].max()) or want_tail.numel() == 0
+    del frame, gpu
+    # one mesh instance more: 16 778 000 > 2^24 -> refused when the triangle stage runs, accepted without it
+    spec2 = SceneSpec(n_mesh_instances=16778, meshlets_per_mesh=K, share_meshes=2, seed=501, with_geometry=False, scene_depth=900.0)
+    big = make_scene(spec2, "cuda")
+    frame = PreparedFrame.create(big, with_triangles=False)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=big.cull_camera(), stages=L.STAGE_ALL)
+    renderer.seed_meshlet_instances(ctx, big.n_meshlet_instances)
+    with pytest.raises(OxcError):
+        renderer.cull_geometry(ctx)
+    ctx.stages = L.STAGE_MESHLETS
+    renderer.cull_geometry(ctx)
+    assert renderer.read_counters(ctx).total_visible_meshlet_instances == big.n_meshlet_instances
