@@ -61,11 +61,14 @@ def test_cull_meshes_frustum_only_flags(renderer, oracle_lib):
     assert (want["lod_index"] == 0).all()
 
 
-@pytest.mark.parametrize("size,depth_scale", [(64, 2), (256, 2), (1024, 2), (256, 1), (128, 3), (32, 2), (8, 2)])
+@pytest.mark.parametrize("size,depth_scale", [(64, 2), (256, 2), (1024, 2), (256, 1), (128, 3), (32, 2), (8, 2), (4096, 2)],
+                         ids=["64", "256", "1024", "256-same-size", "128-x3", "32", "8", "4096-max-13-mips"])
 def test_generate_hiz(renderer, oracle_lib, size, depth_scale):
     depth = make_depth(size * depth_scale, size * depth_scale, 24, seed=size)
     depth += torch.rand(depth.shape, generator=torch.Generator().manual_seed(size)) * 1e-4  # no flat areas
     want, levels, offs = oracle_hiz(depth, size, size)
+    if size == 4096:
+        assert levels == 13  # hiz.slang binds at most 13 mips (CullGeometry.cpp:24,36-38)
     hiz = ImageAttachment.hiz(size, size, "cuda")
     renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth.cuda()), hiz))
     got = hiz.data.cpu()
