@@ -318,6 +318,60 @@ def test_meshlet_stage_one_million(renderer, oracle_lib):
     assert 0.1 < want.numel() / 1e6 < 0.6
 
 
+def test_two_pass_occlusion_ten_million_sampled(renderer, oracle_lib):
+    """BASELINE configs[2] at full size (10M meshlets, 4096^2 HiZ, prior mask p = 0.3): the early and late decisions are
+    per-meshlet independent, so the oracle is run on a 300K-instance PREFIX of the list (same HiZ, same mask words) and
+    must reproduce exactly the part of the GPU's early / late lists and mask that falls into that prefix; the lists of the
+    whole frame must be ascending and their sizes consistent with the counters."""
+    import oracle
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    spec = SceneSpec(n_mesh_instances=10000, meshlets_per_mesh=1000, seed=0x0A1DE5 + 3, with_geometry=False)
+    gpu = make_scene(spec, "cuda")
+    N, P = gpu.n_meshlet_instances, 300_000
+    depth = make_depth(8192, 8192, 64, seed=3, device="cuda")
+    hiz = ImageAttachment.hiz(4096, 4096, "cuda")
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    words = (N + 31) // 32
+    mask0 = torch.randint(-2**31, 2**31 - 1, (words,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    mask0 &= torch.randint(-2**31, 2**31 - 1, (words,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)  # p ~ 0.25
+    frame = PreparedFrame.create(gpu, with_triangles=False)
+    frame.meshlet_instance_visibility_mask_buffer.copy_(mask0)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz,
+                              stages=L.STAGE_MESHLETS)
+    renderer.seed_meshlet_instances(ctx, N)
+    renderer.cull_geometry(ctx)
+    c1 = renderer.read_counters(ctx)
+    early = frame.visible_meshlet_instances_indices_buffer[: c1.cull_triangles_cmd_x].clone()
+    ctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
+    renderer.cull_geometry(ctx)
+    c2 = renderer.read_counters(ctx)
+    late = frame.visible_meshlet_instances_indices_buffer[c2.early_visible_meshlet_instances: c2.early_visible_meshlet_instances + c2.cull_triangles_cmd_x].clone()
+    assert c2.early_visible_meshlet_instances == early.numel() and c2.late_visible_meshlet_instances == late.numel()
+    for lst in (early, late):
+        assert bool((lst[1:] > lst[:-1]).all())  # ascending, no duplicates
+    assert early.numel() > 0 and late.numel() > 0 and not bool(torch.isin(late[:100000], early).any())
+    # oracle on the prefix
+    cpu = gpu.to("cpu")
+    hiz_host = hiz.data.cpu().numpy()  # kept alive: make_hiz stores the pointer
+    hz = oracle.make_hiz(hiz_host, 4096, 4096, hiz.levels, hiz.level_offset)
+    mli = cpu.meshlet_instances[:P].contiguous()
+    mask = mask0.cpu().clone()
+    v = oracle.Visibility(P, 0, 0)
+    out = torch.zeros(P, dtype=torch.int32)
+    n_e = oracle.cull_meshlets_hiz(cpu, cpu.cull_camera(), mli, L.CULL_TEST_ALL, hz, v, mask, out)
+    want_early = out[:n_e].clone()
+    n_l = oracle.cull_meshlets_hiz(cpu, cpu.cull_camera(), mli, L.CULL_TEST_ALL | L.CULL_LATE_PASS, hz, v, mask, out)
+    want_late = out[v.early: v.early + n_l].clone()
+    e_cpu, l_cpu = early.cpu(), late.cpu()
+    assert torch.equal(e_cpu[e_cpu < P], want_early) and torch.equal(l_cpu[l_cpu < P], want_late)
+    # mask words wholly inside the prefix (mask index = visibility offset + meshlet index = list position here)
+    wp = P // 32
+    assert torch.equal(frame.meshlet_instance_visibility_mask_buffer[:wp].cpu(), mask[:wp])
+
+
 @pytest.mark.parametrize("run_cull_meshes", [True, False])
 def test_cull_geometry_batch_equals_individual_calls(renderer, oracle_lib, run_cull_meshes):
     """oxc_cull_geometry_batch: several independent frames per launch (grid.y = batch element) must give
