@@ -466,6 +466,8 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
           need[j] = nc ? 1u : 0u;
           any_need |= __builtin_amdgcn_ballot_w64(nc);
           st[j] = mine[j] ? (vis ? 2u : 0u) : st[j];
+          // keeps the scheduler from interleaving all four groups' frustum math: no SGPR spills left (6 before), -2 %
+          if (j == 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
       // ---- phase 2: normal cone, only when some frustum survivor of this instance needs it
