@@ -328,9 +328,9 @@ OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy,
   const bool in_window = amax <= 1.152921504606846976e18f && zmin >= 8.673617379884035e-19f && depth >= 9.313225746154785e-10f &&
                          wmax <= 1.152921504606846976e18f;
   if (__builtin_amdgcn_ballot_w64(!in_window) == 0) {
-    float qx[8], qy[8], qz[8];
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 7; k >= 0; k--) {  // corner 7 first, then 6..0: the fold order of the IEEE branch below
       const float w = P[k][3];
       const float r0 = __builtin_amdgcn_rcpf(w);
       const float e = __builtin_fmaf(-w, r0, 1.0f);
@@ -342,24 +342,24 @@ OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy,
       q = __builtin_elementwise_fma(e1, rr, q);
       e1 = __builtin_elementwise_fma(nw, q, n);
       q = __builtin_elementwise_fma(e1, rr, q);
-      qx[k] = q.x;
-      qy[k] = q.y;
       const float nz = P[k][2];
       float z = nz * r;
       float ez = __builtin_fmaf(-w, z, nz);
       z = __builtin_fmaf(ez, r, z);
       ez = __builtin_fmaf(-w, z, nz);
-      qz[k] = __builtin_fmaf(ez, r, z);
-    }
-    float lo[3] = {qx[7], qy[7], qz[7]}, hi[3] = {qx[7], qy[7], qz[7]};
-#pragma unroll
-    for (int k = 6; k >= 0; k--) {
-      lo[0] = fminf(qx[k], lo[0]);
-      hi[0] = fmaxf(qx[k], hi[0]);
-      lo[1] = fminf(qy[k], lo[1]);
-      hi[1] = fmaxf(qy[k], hi[1]);
-      lo[2] = fminf(qz[k], lo[2]);
-      hi[2] = fmaxf(qz[k], hi[2]);
+      z = __builtin_fmaf(ez, r, z);
+      if (k == 7) {
+        lo[0] = hi[0] = q.x;
+        lo[1] = hi[1] = q.y;
+        lo[2] = hi[2] = z;
+      } else {
+        lo[0] = fminf(q.x, lo[0]);
+        hi[0] = fmaxf(q.x, hi[0]);
+        lo[1] = fminf(q.y, lo[1]);
+        hi[1] = fmaxf(q.y, hi[1]);
+        lo[2] = fminf(z, lo[2]);
+        hi[2] = fmaxf(z, hi[2]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
