@@ -494,7 +494,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     {
       {
         KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
-        launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), s);
+        launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, s);
       }
       MeshletEmitArgs ea;
       ea.n_host = n_host;

@@ -1418,18 +1418,32 @@ void launch_tris_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid,
 }
 
 constexpr int kHizGroups = (int)kHizGroupsPerWave;  // groups per wave of the HiZ variants (block = 16 / kHizGroups waves)
-void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, hipStream_t s) {
-  dim3 g(grid);
+// The HiZ variants stage ~22 KB of the pyramid per block and loop over chunks: a grid of exactly the resident block
+// count (occupancy query) runs one round of blocks; with the generic 8 blocks per CU the second half of the grid starts
+// late and stages the pyramid again (measured on config 3: 112 -> 106 us per launch; 1.25x / 1.5x the resident count
+// are worse than both).
+template <class K>
+static uint32_t resident_grid(K kernel, uint32_t block, uint32_t num_cus) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, 0) != hipSuccess || per_cu <= 0) return num_cus * 8u;
+  return (uint32_t)per_cu * num_cus;
+}
+void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, hipStream_t s) {
+  constexpr uint32_t hb = 1024 / kHizGroups;
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
   } else if (occl && late) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    static const uint32_t cap = resident_grid(k_cull_meshlets_test<true, true, true, kHizGroups>, hb, num_cus);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
   } else if (occl) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    static const uint32_t cap = resident_grid(k_cull_meshlets_test<true, true, false, kHizGroups>, hb, num_cus);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, true, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
   } else if (late) {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, true, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    static const uint32_t cap = resident_grid(k_cull_meshlets_test<true, false, true, kHizGroups>, hb, num_cus);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false, kHizGroups>), g, dim3(1024 / kHizGroups), 0, s, a);
+    static const uint32_t cap = resident_grid(k_cull_meshlets_test<true, false, false, kHizGroups>, hb, num_cus);
+    hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
   }
 }
 void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_cull_meshlets_hpb_test, dim3(grid), dim3(256), 0, s, a); }
