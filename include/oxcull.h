@@ -262,6 +262,70 @@ typedef struct oxc_meshlet_bounds_desc {
 
 oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc* desc, void* hip_stream);
 
+/* ---- SURVEY 8(f)-1, format side: vertex streams and the mesh blob ---------------------------------
+ * oxc_quantize_vertex_streams replaces the three per-vertex loops of AssetManager_GLTF.cpp:570-588:
+ *   positions -> u16x4 {half(x), half(y), half(z), 0}                     (:571-575, meshopt_quantizeHalf)
+ *   normals   -> u32 ((snorm10(x)+511) << 20) | ((snorm10(y)+511) << 10) | (snorm10(z)+511)
+ *                                                                         (:578-582, meshopt_quantizeSnorm(v, 10))
+ *   texcoords -> u16x2 {half(u), half(v)}                                 (:585-588)
+ * A stream whose input dptr is NULL is skipped (its output is not touched).  Device pointers. */
+typedef struct oxc_vertex_streams_desc {
+  uint32_t struct_size;
+  uint32_t vertex_count;
+  oxc_buffer positions;           /* in, optional:  glm::vec3[vertex_count] */
+  oxc_buffer normals;             /* in, optional:  glm::vec3[vertex_count] */
+  oxc_buffer texcoords;           /* in, optional:  glm::vec2[vertex_count] */
+  oxc_buffer quantized_positions; /* out: u16x4[vertex_count] */
+  oxc_buffer quantized_normals;   /* out: u32[vertex_count]   */
+  oxc_buffer quantized_texcoords; /* out: u16x2[vertex_count] */
+} oxc_vertex_streams_desc;
+
+oxc_status oxc_quantize_vertex_streams(oxc_ctx* ctx, const oxc_vertex_streams_desc* desc, void* hip_stream);
+
+/* The mesh blob: one allocation per mesh holding the vertex streams, every LOD's five arrays and, last, the
+ * GPU::MeshLOD table (AssetManager_GLTF.cpp:466-474 blob_append, :590-597, :748-752, :768-769).  Offsets follow
+ * blob_append's rule offset = align_up(current size, alignment): positions 8, normals 4, texcoords 4 (only when
+ * present), then per LOD indices 8, meshlets 8, meshlet_bounds 8, local_triangle_indices 8,
+ * indirect_vertex_indices 4, then the LOD table at align_up(size, 8).  Host-only arithmetic: no context, no GPU. */
+#define OXC_MESH_MAX_LODS 8u /* GPU::Mesh::MAX_LODS, SceneGPU.hpp:143 */
+
+typedef struct oxc_mesh_lod_counts { /* the *_count fields of GPU::MeshLOD (SceneGPU.hpp:125-139) + error */
+  uint32_t indices_count;                 /* u32 elements */
+  uint32_t meshlet_count;                 /* GPU::Meshlet (16 B) and GPU::MeshletBounds (16 B) records */
+  uint32_t local_triangle_indices_count;  /* u8 elements (last meshlet's run padded to 4, :699) */
+  uint32_t indirect_vertex_indices_count; /* u32 elements */
+  float error;
+} oxc_mesh_lod_counts;
+
+typedef struct oxc_mesh_blob_desc {
+  uint32_t struct_size;
+  uint32_t vertex_count;
+  uint32_t has_texture_coords;
+  uint32_t lod_count; /* 1..OXC_MESH_MAX_LODS */
+  oxc_mesh_lod_counts lods[OXC_MESH_MAX_LODS];
+} oxc_mesh_blob_desc;
+
+typedef struct oxc_mesh_lod_offsets {
+  uint64_t indices, meshlets, meshlet_bounds, local_triangle_indices, indirect_vertex_indices;
+} oxc_mesh_lod_offsets;
+
+typedef struct oxc_mesh_blob_layout { /* byte offsets from the start of the blob */
+  uint64_t size;                /* whole blob, LOD table included */
+  uint64_t lod_metadata_offset; /* GPU::MeshLOD[lod_count] */
+  uint64_t vertex_positions, vertex_normals, texture_coords; /* texture_coords = 0 when absent */
+  oxc_mesh_lod_offsets lods[OXC_MESH_MAX_LODS];
+} oxc_mesh_blob_layout;
+
+oxc_status oxc_mesh_blob_layout_of(const oxc_mesh_blob_desc* desc, oxc_mesh_blob_layout* out_layout);
+
+/* upload_gltf_mesh's relocation (AssetManager_GLTF.cpp:780-800): with the blob resident at `device_address`,
+ * write the GPU::MeshLOD table (absolute addresses + counts + error) into the HOST copy `blob` at
+ * lod_metadata_offset and fill `out_gpu_mesh` (64 B GPU::Mesh: absolute stream addresses, texture_coords 0 when
+ * absent, vertex_count, lod_count, lods, bounds = mesh_bounds {aabb_center.xyz, aabb_extent.xyz}).  The caller
+ * then copies the blob to the device (the reference's staging upload, :802-818). */
+oxc_status oxc_mesh_blob_finalize(const oxc_mesh_blob_desc* desc, const oxc_mesh_blob_layout* layout, uint64_t device_address,
+                                  void* blob, uint64_t blob_bytes, const float mesh_bounds[6], void* out_gpu_mesh);
+
 /* ---- hierarchical page buffer producer ------------------------------------------
  * Replaces the "vsm downsample hpb" pass (Oxylus/src/Render/Passes/Shadowmaps.cpp:331-366, pipeline
  * rmvsm_downsample_hpb, Shaders/passes/rmvsm_downsample_hpb.slang:10-33): level 0 of the pyramid is 1 where

@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
         l.orc_quantize_snorm.restype = C.c_int
         l.orc_build_meshlet_bounds.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp]
         l.orc_build_meshlet_bounds.restype = None
+        l.orc_quantize_vertex_streams.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+        l.orc_quantize_vertex_streams.restype = None
         _lib = l
     return _lib
 
@@ -285,6 +287,45 @@ def build_meshlet_bounds(positions: torch.Tensor, meshlets: torch.Tensor, vidx: 
     lib().orc_build_meshlet_bounds(_p(positions.contiguous()), V, _p(meshlets.contiguous()), M, _p(vidx.contiguous()), _p(micro.contiguous()),
                                    _p(bounds), _p(mesh6), _p(qpos))
     return bounds, mesh6, qpos
+
+
+def quantize_vertex_streams(positions: torch.Tensor = None, normals: torch.Tensor = None, texcoords: torch.Tensor = None):
+    """f32 [V,3] / [V,3] / [V,2] (any may be None) -> (i16 [V,4], i32 [V], i16 [V,2]) or None per absent stream."""
+    given = [t for t in (positions, normals, texcoords) if t is not None]
+    V = given[0].shape[0] if given else 0
+    qpos = torch.zeros((V, 4), dtype=torch.int16) if positions is not None else None
+    qnrm = torch.zeros(V, dtype=torch.int32) if normals is not None else None
+    quv = torch.zeros((V, 2), dtype=torch.int16) if texcoords is not None else None
+
+    def p(t):
+        return _p(t.contiguous()) if t is not None else None
+
+    lib().orc_quantize_vertex_streams(p(positions), p(normals), p(texcoords), V, p(qpos), p(qnrm), p(quv))
+    return qpos, qnrm, quv
+
+
+def mesh_blob_layout(vertex_count: int, has_texture_coords: bool, lod_counts):
+    """Byte offsets of the mesh blob, restating build_gltf_mesh's blob_append sequence
+    (AssetManager_GLTF.cpp:466-474 `offset = align_up(size, alignment)`; :592-596 streams; :748-752 per-LOD arrays;
+    :768-769 LOD table).  lod_counts: [(indices_count, meshlet_count, local_triangle_indices_count,
+    indirect_vertex_indices_count), ...].  Element sizes: u16vec4 8, u32 4, u16vec2 4 (:500-502), GPU::Meshlet 16,
+    GPU::MeshletBounds 16, GPU::MeshLOD 64 (SceneGPU.hpp:84-139)."""
+    size = 0
+
+    def append(nbytes, alignment):
+        nonlocal size
+        offset = -(-size // alignment) * alignment
+        size = offset + nbytes
+        return offset
+
+    out = {"vertex_positions": append(vertex_count * 8, 8), "vertex_normals": append(vertex_count * 4, 4),
+           "texture_coords": append(vertex_count * 4, 4) if has_texture_coords else 0, "lods": []}
+    for (ic, mc, lc, vc) in lod_counts:
+        out["lods"].append({"indices": append(ic * 4, 8), "meshlets": append(mc * 16, 8), "meshlet_bounds": append(mc * 16, 8),
+                            "local_triangle_indices": append(lc, 8), "indirect_vertex_indices": append(vc * 4, 4)})
+    out["lod_metadata_offset"] = -(-size // 8) * 8
+    out["size"] = out["lod_metadata_offset"] + len(lod_counts) * 64
+    return out
 
 
 def generate_hpb(page_table: torch.Tensor, hpb: Hpb):

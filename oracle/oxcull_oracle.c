@@ -844,6 +844,23 @@ int orc_quantize_snorm(float v, int bits) {
   return (int)(v * scale + round);
 }
 
+/* AssetManager_GLTF.cpp:570-588 */
+void orc_quantize_vertex_streams(const float* positions, const float* normals, const float* texcoords, uint32_t vertex_count,
+                                 uint16_t* out_qpos, uint32_t* out_qnrm, uint16_t* out_quv) {
+  for (uint32_t v = 0; v < vertex_count; v++) {
+    if (positions) {
+      for (int k = 0; k < 3; k++) out_qpos[4 * v + k] = orc_quantize_half(positions[3 * v + k]);
+      out_qpos[4 * v + 3] = 0; /* glm::u16vec4 value-initialised by resize(), only xyz assigned */
+    }
+    if (normals)
+      out_qnrm[v] = ((uint32_t)(orc_quantize_snorm(normals[3 * v + 0], 10) + 511) << 20) |
+                    ((uint32_t)(orc_quantize_snorm(normals[3 * v + 1], 10) + 511) << 10) |
+                    (uint32_t)(orc_quantize_snorm(normals[3 * v + 2], 10) + 511);
+    if (texcoords)
+      for (int k = 0; k < 2; k++) out_quv[2 * v + k] = orc_quantize_half(texcoords[2 * v + k]);
+  }
+}
+
 /* clusterizer.cpp computeBoundingSphere with all radii 0 and axis_count = 3 (the call that fits the normal
  * cone): seed with the most distant pair among the per-axis extrema, then one sweep growing the sphere. */
 static void bounding_sphere_axes3(float result[4], const float (*points)[3], uint32_t count) {

@@ -238,6 +238,12 @@ void orc_build_meshlet_bounds(const float* positions, uint32_t vertex_count, con
                               const uint32_t* indirect_vertex_indices, const uint8_t* local_triangle_indices,
                               orc_meshlet_bounds* out_bounds, float* out_mesh6, uint16_t* out_qpos);
 
+/* The three vertex streams of AssetManager_GLTF.cpp:570-588: positions -> u16x4 halfs (w = 0), normals ->
+ * ((snorm10(x)+511) << 20) | ((snorm10(y)+511) << 10) | (snorm10(z)+511), texcoords -> u16x2 halfs.
+ * Any input may be NULL (that stream is skipped). */
+void orc_quantize_vertex_streams(const float* positions, const float* normals, const float* texcoords, uint32_t vertex_count,
+                                 uint16_t* out_qpos, uint32_t* out_qnrm, uint16_t* out_quv);
+
 /* ---- HPB producer.  passes/rmvsm_downsample_hpb.slang:10-33 driven by
  * Passes/Shadowmaps.cpp:331-366; page flags rmvsm.slang:16-28 ([Flags]: Visible 1, Dirty 2, Backed 4). */
 void orc_generate_hpb(const uint32_t* page_table, orc_hpb* hpb);

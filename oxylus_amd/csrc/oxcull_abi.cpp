@@ -845,6 +845,91 @@ oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc*
   return OXC_OK;
 }
 
+oxc_status oxc_quantize_vertex_streams(oxc_ctx* ctx, const oxc_vertex_streams_desc* d, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!d || d->struct_size != sizeof(oxc_vertex_streams_desc)) return fail(ctx, OXC_INVALID_ARG, "quantize_vertex_streams: bad desc / struct_size");
+  const uint64_t n = d->vertex_count;
+  struct Stream {
+    const oxc_buffer *in, *out;
+    uint32_t in_stride, out_stride;
+    const char* what;
+  } streams[3] = {{&d->positions, &d->quantized_positions, 12, 8, "quantize_vertex_streams: positions / quantized_positions too small or null"},
+                  {&d->normals, &d->quantized_normals, 12, 4, "quantize_vertex_streams: normals / quantized_normals too small or null"},
+                  {&d->texcoords, &d->quantized_texcoords, 8, 4, "quantize_vertex_streams: texcoords / quantized_texcoords too small or null"}};
+  for (const Stream& st : streams)
+    if (st.in->dptr && n && (!st.out->dptr || st.in->bytes < n * st.in_stride || st.out->bytes < n * st.out_stride)) return fail(ctx, OXC_INVALID_ARG, st.what);
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  launch_quantize_vertex_streams(static_cast<const float*>(d->positions.dptr), static_cast<const float*>(d->normals.dptr),
+                                 static_cast<const float*>(d->texcoords.dptr), d->vertex_count, d->quantized_positions.dptr, d->quantized_normals.dptr,
+                                 d->quantized_texcoords.dptr, ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+// ---- mesh blob (host arithmetic only) --------------------------------------------------------------
+oxc_status oxc_mesh_blob_layout_of(const oxc_mesh_blob_desc* d, oxc_mesh_blob_layout* out) {
+  if (!d || !out || d->struct_size != sizeof(oxc_mesh_blob_desc)) return OXC_INVALID_ARG;
+  if (d->lod_count == 0 || d->lod_count > OXC_MESH_MAX_LODS) return OXC_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  uint64_t size = 0;
+  auto append = [&size](uint64_t bytes, uint64_t alignment) {  // blob_append, AssetManager_GLTF.cpp:466-474
+    const uint64_t offset = (size + alignment - 1) / alignment * alignment;
+    size = offset + bytes;
+    return offset;
+  };
+  const uint64_t V = d->vertex_count;
+  out->vertex_positions = append(V * 8, 8);  // :592-596
+  out->vertex_normals = append(V * 4, 4);
+  if (d->has_texture_coords) out->texture_coords = append(V * 4, 4);
+  for (uint32_t i = 0; i < d->lod_count; i++) {  // :748-752
+    const oxc_mesh_lod_counts& c = d->lods[i];
+    oxc_mesh_lod_offsets& o = out->lods[i];
+    o.indices = append((uint64_t)c.indices_count * 4, 8);
+    o.meshlets = append((uint64_t)c.meshlet_count * sizeof(GpuMeshlet), 8);
+    o.meshlet_bounds = append((uint64_t)c.meshlet_count * 16, 8);
+    o.local_triangle_indices = append(c.local_triangle_indices_count, 8);
+    o.indirect_vertex_indices = append((uint64_t)c.indirect_vertex_indices_count * 4, 4);
+  }
+  out->lod_metadata_offset = (size + 7) / 8 * 8;  // :768-769
+  out->size = out->lod_metadata_offset + (uint64_t)d->lod_count * sizeof(GpuMeshLOD);
+  return OXC_OK;
+}
+
+oxc_status oxc_mesh_blob_finalize(const oxc_mesh_blob_desc* d, const oxc_mesh_blob_layout* l, uint64_t device_address, void* blob, uint64_t blob_bytes,
+                                  const float mesh_bounds[6], void* out_gpu_mesh) {
+  if (!d || !l || !blob || !mesh_bounds || !out_gpu_mesh || d->struct_size != sizeof(oxc_mesh_blob_desc)) return OXC_INVALID_ARG;
+  if (d->lod_count == 0 || d->lod_count > OXC_MESH_MAX_LODS) return OXC_INVALID_ARG;
+  if (blob_bytes < l->size || l->lod_metadata_offset + (uint64_t)d->lod_count * sizeof(GpuMeshLOD) > l->size) return OXC_INVALID_ARG;
+  GpuMeshLOD table[OXC_MESH_MAX_LODS] = {};
+  for (uint32_t i = 0; i < d->lod_count; i++) {  // AssetManager_GLTF.cpp:787-794 + the counts of :754-758
+    const oxc_mesh_lod_counts& c = d->lods[i];
+    const oxc_mesh_lod_offsets& o = l->lods[i];
+    GpuMeshLOD& t = table[i];
+    t.indices = device_address + o.indices;
+    t.meshlets = device_address + o.meshlets;
+    t.meshlet_bounds = device_address + o.meshlet_bounds;
+    t.local_triangle_indices = device_address + o.local_triangle_indices;
+    t.indirect_vertex_indices = device_address + o.indirect_vertex_indices;
+    t.indices_count = c.indices_count;
+    t.meshlet_count = c.meshlet_count;
+    t.meshlet_bounds_count = c.meshlet_count;
+    t.local_triangle_indices_count = c.local_triangle_indices_count;
+    t.indirect_vertex_indices_count = c.indirect_vertex_indices_count;
+    t.error = c.error;
+  }
+  std::memcpy(static_cast<uint8_t*>(blob) + l->lod_metadata_offset, table, (size_t)d->lod_count * sizeof(GpuMeshLOD));  // :796-800
+  GpuMesh m = {};
+  m.vertex_positions = device_address + l->vertex_positions;  // :780-785
+  m.vertex_normals = device_address + l->vertex_normals;
+  m.texture_coords = d->has_texture_coords ? device_address + l->texture_coords : 0;
+  m.vertex_count = d->vertex_count;
+  m.lod_count = d->lod_count;
+  m.lods = device_address + l->lod_metadata_offset;
+  for (int k = 0; k < 3; k++) m.aabb_center[k] = mesh_bounds[k], m.aabb_extent[k] = mesh_bounds[3 + k];
+  std::memcpy(out_gpu_mesh, &m, sizeof(m));
+  return OXC_OK;
+}
+
 oxc_status oxc_generate_hpb(oxc_ctx* ctx, oxc_buffer page_table, const oxc_image_array_u8* h, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   if (!h || !h->dptr) return fail(ctx, OXC_INVALID_ARG, "generate_hpb: null hpb_attachment");

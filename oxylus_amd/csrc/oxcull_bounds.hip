@@ -97,6 +97,40 @@ __global__ __launch_bounds__(256) void k_quantize_positions(const float* __restr
   }
 }
 
+// meshoptimizer.h meshopt_quantizeSnorm(v, 10): scale 511, round half away from zero, clamp first (a NaN
+// fails both comparisons' keep-branch and becomes -1).
+OXC_DEV int32_t quantize_snorm10(float v) {
+  const float round = (v >= 0.0f ? 0.5f : -0.5f);
+  v = (v >= -1.0f) ? v : -1.0f;
+  v = (v <= 1.0f) ? v : 1.0f;
+  return (int32_t)(v * 511.0f + round);
+}
+
+// AssetManager_GLTF.cpp:578-582: three biased 10-bit fields, x in the top one
+__global__ __launch_bounds__(256) void k_quantize_normals(const float* __restrict__ nrm, uint32_t n, uint32_t* __restrict__ out) {
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const float x = nrm[(size_t)v * 3 + 0], y = nrm[(size_t)v * 3 + 1], z = nrm[(size_t)v * 3 + 2];
+    out[v] = ((uint32_t)(quantize_snorm10(x) + 511) << 20) | ((uint32_t)(quantize_snorm10(y) + 511) << 10) | (uint32_t)(quantize_snorm10(z) + 511);
+  }
+}
+
+// AssetManager_GLTF.cpp:585-588
+__global__ __launch_bounds__(256) void k_quantize_texcoords(const float2* __restrict__ uv, uint32_t n, uint32_t* __restrict__ out) {
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const float2 t = uv[v];
+    out[v] = quantize_half(t.x) | (quantize_half(t.y) << 16);
+  }
+}
+
+void launch_quantize_vertex_streams(const float* pos, const float* nrm, const float* uv, uint32_t vertex_count, void* out_qpos, void* out_qnrm,
+                                    void* out_quv, uint32_t max_grid, hipStream_t s) {
+  if (!vertex_count) return;
+  const dim3 grid(min((vertex_count + 255u) / 256u, max_grid));
+  if (pos) hipLaunchKernelGGL(k_quantize_positions, grid, dim3(256), 0, s, pos, vertex_count, reinterpret_cast<uint2*>(out_qpos));
+  if (nrm) hipLaunchKernelGGL(k_quantize_normals, grid, dim3(256), 0, s, nrm, vertex_count, static_cast<uint32_t*>(out_qnrm));
+  if (uv) hipLaunchKernelGGL(k_quantize_texcoords, grid, dim3(256), 0, s, reinterpret_cast<const float2*>(uv), vertex_count, static_cast<uint32_t*>(out_quv));
+}
+
 // meshopt_computeClusterBounds from the compacted normals on: computeBoundingSphere(normals, radii = 0,
 // axis_count = 3) -- per-axis extrema, most distant pair as the seed, one growing sweep --, the axis, the
 // minimum dot and the s8 quantisation.  Strictly sequential, exactly as published; `normal_at(i, q)` fetches

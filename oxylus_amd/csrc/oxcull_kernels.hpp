@@ -221,4 +221,6 @@ void launch_build_meshlet_bounds(const float* pos, uint32_t vertex_count, const 
                                  const uint8_t* micro, void* out_bounds, float* out_mesh6, void* out_qpos, float* meshlet_minmax, float* normals,
                                  uint32_t* normal_counts, float* fold_scratch, uint32_t chunk, uint32_t max_grid, hipStream_t s);
 
+void launch_quantize_vertex_streams(const float* pos, const float* nrm, const float* uv, uint32_t vertex_count, void* out_qpos, void* out_qnrm,
+                                    void* out_quv, uint32_t max_grid, hipStream_t s);
 }  // namespace oxc

@@ -152,6 +152,11 @@ public:
     desc.struct_size = sizeof desc;
     check(oxc_build_meshlet_bounds(ctx_, &desc, stream_));
   }
+  // AssetManager_GLTF.cpp:570-588: the three quantised vertex streams of the mesh blob
+  auto quantize_vertex_streams(oxc_vertex_streams_desc desc) -> void {
+    desc.struct_size = sizeof desc;
+    check(oxc_quantize_vertex_streams(ctx_, &desc, stream_));
+  }
 
   oxc_ctx* native() { return ctx_; }
 

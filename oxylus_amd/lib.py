@@ -140,6 +140,57 @@ class MeshletBoundsDesc(C.Structure):
     ]
 
 
+class VertexStreamsDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("vertex_count", C.c_uint32),
+        ("positions", Buffer),
+        ("normals", Buffer),
+        ("texcoords", Buffer),
+        ("quantized_positions", Buffer),
+        ("quantized_normals", Buffer),
+        ("quantized_texcoords", Buffer),
+    ]
+
+
+MESH_MAX_LODS = 8
+
+
+class MeshLodCounts(C.Structure):
+    _fields_ = [
+        ("indices_count", C.c_uint32),
+        ("meshlet_count", C.c_uint32),
+        ("local_triangle_indices_count", C.c_uint32),
+        ("indirect_vertex_indices_count", C.c_uint32),
+        ("error", C.c_float),
+    ]
+
+
+class MeshBlobDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("vertex_count", C.c_uint32),
+        ("has_texture_coords", C.c_uint32),
+        ("lod_count", C.c_uint32),
+        ("lods", MeshLodCounts * MESH_MAX_LODS),
+    ]
+
+
+class MeshLodOffsets(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("indices", "meshlets", "meshlet_bounds", "local_triangle_indices", "indirect_vertex_indices")]
+
+
+class MeshBlobLayout(C.Structure):
+    _fields_ = [
+        ("size", C.c_uint64),
+        ("lod_metadata_offset", C.c_uint64),
+        ("vertex_positions", C.c_uint64),
+        ("vertex_normals", C.c_uint64),
+        ("texture_coords", C.c_uint64),
+        ("lods", MeshLodOffsets * MESH_MAX_LODS),
+    ]
+
+
 class TerrainContext(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -191,6 +242,9 @@ EXPORTS = [
     "oxc_profile_begin",
     "oxc_profile_end",
     "oxc_build_meshlet_bounds",
+    "oxc_quantize_vertex_streams",
+    "oxc_mesh_blob_layout_of",
+    "oxc_mesh_blob_finalize",
     "oxc_generate_hpb",
     "oxc_cull_terrain",
     "oxc_draw_visbuffer",
@@ -243,6 +297,9 @@ def load() -> C.CDLL:
     lib.oxc_profile_begin.argtypes = [vp]
     lib.oxc_profile_end.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.oxc_build_meshlet_bounds.argtypes = [vp, C.POINTER(MeshletBoundsDesc), vp]
+    lib.oxc_quantize_vertex_streams.argtypes = [vp, C.POINTER(VertexStreamsDesc), vp]
+    lib.oxc_mesh_blob_layout_of.argtypes = [C.POINTER(MeshBlobDesc), C.POINTER(MeshBlobLayout)]
+    lib.oxc_mesh_blob_finalize.argtypes = [C.POINTER(MeshBlobDesc), C.POINTER(MeshBlobLayout), C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_float * 6), vp]
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]

@@ -280,6 +280,28 @@ class RendererInstance:
         self._check(self._lib.oxc_build_meshlet_bounds(self._ctx, C.byref(d), self._stream(stream)))
         return bounds, mesh6, qpos
 
+    def quantize_vertex_streams(self, positions: torch.Tensor = None, normals: torch.Tensor = None, texcoords: torch.Tensor = None, stream=None):
+        """AssetManager_GLTF.cpp:570-588: f32 [V,3] positions -> i16 [V,4] (u16x4 halfs), f32 [V,3] normals -> i32 [V] (10:10:10),
+        f32 [V,2] texcoords -> i16 [V,2]; absent streams come back as None."""
+        given = [t for t in (positions, normals, texcoords) if t is not None]
+        if not given:
+            return None, None, None
+        dev, V = given[0].device, given[0].shape[0]
+        qpos = torch.empty((V, 4), dtype=torch.int16, device=dev) if positions is not None else None
+        qnrm = torch.empty(V, dtype=torch.int32, device=dev) if normals is not None else None
+        quv = torch.empty((V, 2), dtype=torch.int16, device=dev) if texcoords is not None else None
+
+        def buf(t):
+            return L.Buffer(C.c_void_p(t.data_ptr()), t.numel() * t.element_size()) if t is not None and t.numel() else L.Buffer(None, 0)
+
+        d = L.VertexStreamsDesc()
+        d.struct_size, d.vertex_count = C.sizeof(L.VertexStreamsDesc), V
+        d.positions, d.normals, d.texcoords = buf(positions), buf(normals), buf(texcoords)
+        d.quantized_positions, d.quantized_normals, d.quantized_texcoords = buf(qpos), buf(qnrm), buf(quv)
+        self._keep = (positions, normals, texcoords)
+        self._check(self._lib.oxc_quantize_vertex_streams(self._ctx, C.byref(d), self._stream(stream)))
+        return qpos, qnrm, quv
+
     def generate_hpb(self, page_table: torch.Tensor, hpb: "HpbAttachment", stream=None):
         """SURVEY 8(f)-3, Shadowmaps.cpp:331-366: page_table int32 [layers, h, w] -> every level of `hpb`."""
         im = hpb.c()

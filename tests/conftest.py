@@ -21,6 +21,15 @@ def oracle_lib():
 
 
 @pytest.fixture(scope="session")
+def liboxcull():
+    """liboxcull.so loaded with prototypes; host-only entry points (mesh blob arithmetic) run without a GPU."""
+    from oxylus_amd import lib as L
+
+    L.build()
+    return L.load()
+
+
+@pytest.fixture(scope="session")
 def renderer():
     """One RendererInstance (oxc_ctx) on cuda:0 for the whole GPU session."""
     import torch
