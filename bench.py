@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
     ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
     ap.add_argument("--streams", type=int, default=3, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
-    ap.add_argument("--batch", type=int, default=8, help="frames per oxc_cull_geometry_batch call (1 = one call per step; max 8)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per oxc_cull_geometry_batch call (1 = one call per step; max 16)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--native-comm", action="store_true",
@@ -413,7 +413,7 @@ def main():
             view_cams.append(cam)
 
     single_stream = [False]  # instrumented pass: every context on stream 0, so kernels do not overlap
-    batch = max(1, min(8, args.batch)) if args.workload == "config2" else 1
+    batch = max(1, min(16, args.batch)) if args.workload == "config2" else 1
     groups = []  # (context index k, C arrays) : `batch` copies of the same context culled by ONE batched call
     if batch > 1:
         per_ctx = [[st for i, st in enumerate(steps) if i % n_streams == k] for k in range(n_streams)]
@@ -433,7 +433,7 @@ def main():
     # config 5: the views are independent cull_geometry calls over the same scene; `--batch` of them go through one
     # oxc_cull_geometry_batch call (each element has its own outputs and its own mesh_instances copy: cull_meshes
     # writes lod_index per view)
-    view_batch = max(1, min(8, args.batch)) if multiview else 1
+    view_batch = max(1, min(16, args.batch)) if multiview else 1
     view_groups = []
     if multiview:
         import dataclasses

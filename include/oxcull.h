@@ -188,7 +188,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* frame, oxc_
  * INDEPENDENT frames (no buffer of one element is written by another) -- several views or scenes culled per
  * launch, the way the reference's cull_meshlets_hpb handles all clipmap views in one dispatch.  When every
  * element uses the plain pipeline (use_hiz == use_hpb == 0, no LatePass) with the same `stages` and
- * `init_cull_meshes`, and count <= 8, each stage is ONE launch with grid.y = count; otherwise the elements
+ * `init_cull_meshes`, and count <= 16, each stage is ONE launch with grid.y = count; otherwise the elements
  * are processed one after the other.  A 1M-meshlet call is launch-latency bound on MI355X (a HIP graph
  * sustains ~3 us per kernel node); batching is what amortises it. */
 oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepared_frame* frames,

@@ -570,12 +570,13 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   if (!ctx->batch_dev) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->batch_dev), sizeof(BatchElem) * kMaxBatch);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(batch argument block)", e);
+    OXC_HIP(ctx, hipMemset(ctx->batch_dev, 0, sizeof(BatchElem) * kMaxBatch));  // fields no plain-pipeline block uses stay 0
   }
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t max_grid = ctx->num_cus * 8;
   const bool do_meshes = ci[0].do_meshes, do_meshlets = ci[0].do_meshlets, do_tris = ci[0].do_tris;
-  static thread_local BatchElem elems[kMaxBatch];
-  std::memset(elems, 0, sizeof elems);
+  BatchCore cores[kMaxBatch];
+  std::memset(cores, 0, sizeof cores);
   uint32_t g_prep = 1, g_expand = 1, g_test = 1, g_emit = 1, g_ttest = 1, g_temit = 1;
   for (uint32_t e = 0; e < count; e++) {
     const oxc_prepared_frame* f = &frames[e];
@@ -597,83 +598,45 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
         n_host = ctx->seeded_total[(vis - ctx->slots) / SLOT_U32S];
       if (n_host > N) n_host = 0;
     }
-    uint32_t* tri_cmd = slot + SLOT_TRI_CMD;
-    uint32_t* draw_cmd = slot + SLOT_DRAW_CMD;
-    c->cull_triangles_cmd_buffer = {tri_cmd, 12};
-    c->draw_geometry_cmd_buffer = {draw_cmd, 20};
+    c->cull_triangles_cmd_buffer = {slot + SLOT_TRI_CMD, 12};
+    c->draw_geometry_cmd_buffer = {slot + SLOT_DRAW_CMD, 20};
     const uint32_t m_chunks = cdiv(std::max(N, 1u), kMeshletChunk), t_chunks = cdiv(std::max(N, 1u), kTriChunk);
 
-    PrepareArgs& pa = elems[e].prep;
-    pa.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
-    pa.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
-    pa.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
-    pa.cache = L.cache;
-    pa.mesh_counts = L.mesh_counts;
-    pa.slot = slot;
-    pa.vis = vis;
-    pa.meshlets_cmd = meshlets_cmd;
-    pa.supers_meshlets = L.m_supers;
-    pa.supers_tris = L.t_supers;
-    pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
-    pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
-    pa.mesh_instance_count = M;
-    pa.cull_flags = c->cull_flags;
-    pa.do_cull_meshes = do_meshes ? 1u : 0u;
-    pa.init_vis = c->init_cull_meshes ? 1u : 0u;
-    pa.seed_total = 0;
-    pa.cam = c->cull_camera;
-    pa.clipmaps = nullptr;
-    pa.view_cache = L.view_cache;
-    g_prep = std::max(g_prep, std::min(cdiv(std::max(std::max(M * 8u, pa.n_supers_tris), 1u), 256), max_grid));
-
-    elems[e].scan = ScanArgs{L.mesh_counts, L.mesh_offsets, M, vis, meshlets_cmd};
-    elems[e].expand = ExpandArgs{L.mesh_counts, L.mesh_offsets, M, static_cast<GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr)};
+    // every field once; k_prepare_batch rebuilds the seven stage blocks from it on the device (expand_batch_core)
+    BatchCore& k = cores[e];
+    k.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
+    k.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
+    k.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
+    k.meshlet_instances = static_cast<GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
+    k.visible_out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    k.reordered_out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
+    k.cache = L.cache;
+    k.view_cache = L.view_cache;
+    k.mesh_counts = L.mesh_counts;
+    k.mesh_offsets = L.mesh_offsets;
+    k.bits = L.bits;
+    k.m_chunk_counts = L.m_chunk_counts;
+    k.m_supers = L.m_supers;
+    k.tri_masks = L.tri_masks;
+    k.t_chunk_counts = L.t_chunk_counts;
+    k.t_supers = L.t_supers;
+    k.slot = slot;
+    k.vis = vis;
+    k.meshlets_cmd = meshlets_cmd;
+    k.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
+    k.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
+    k.mesh_instance_count = M;
+    k.cull_flags = c->cull_flags;
+    k.do_cull_meshes = do_meshes ? 1u : 0u;
+    k.init_vis = c->init_cull_meshes ? 1u : 0u;
+    k.n_host = n_host;
+    k.count_meshlets = 64u * kPlainGroups;
+    k.cam = c->cull_camera;
+    g_prep = std::max(g_prep, std::min(cdiv(std::max(std::max(M * 8u, k.n_supers_tris), 1u), 256), max_grid));
     g_expand = std::max(g_expand, std::max(std::min(cdiv(M, 4), max_grid), 1u));
-
-    MeshletTestArgs& ta = elems[e].test;
-    ta.n_host = n_host;
-    ta.cache = L.cache;
-    ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
-    ta.vis = vis;
-    ta.mask = nullptr;
-    ta.bits = L.bits;
-    ta.chunk_counts = L.m_chunk_counts;
-    ta.supers = L.m_supers;
-    ta.near_clip = c->cull_camera.near_clip;
-    std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
     g_test = std::max(g_test, std::min(m_chunks, max_grid));
-
-    MeshletEmitArgs& ea = elems[e].emit;
-    ea.n_host = n_host;
-    ea.count_meshlets = 64u * kPlainGroups;
-    ea.bits = L.bits;
-    ea.chunk_counts = L.m_chunk_counts;
-    ea.supers = L.m_supers;
-    ea.vis = vis;
-    ea.tri_cmd = tri_cmd;
-    ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
     g_emit = std::max(g_emit, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid));
-
-    TriTestArgs& tt = elems[e].ttest;
-    tt.cache = L.cache;
-    tt.meshlet_instances = ta.meshlet_instances;
-    tt.visible = ea.out;
-    tt.vis = vis;
-    tt.tri_cmd = tri_cmd;
-    tt.tri_masks = L.tri_masks;
-    tt.chunk_counts = L.t_chunk_counts;
-    tt.supers = L.t_supers;
     g_ttest = std::max(g_ttest, std::min(t_chunks, max_grid));
-
-    TriEmitArgs& te = elems[e].temit;
-    te.tri_masks = L.tri_masks;
-    te.visible = ea.out;
-    te.vis = vis;
-    te.tri_cmd = tri_cmd;
-    te.chunk_counts = L.t_chunk_counts;
-    te.supers = L.t_supers;
-    te.draw_cmd = draw_cmd;
-    te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     g_temit = std::max(g_temit, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid));
   }
   // grid.y = count; grid.x cap per element.  Measured for the meshlet test kernel with 8 x 1M meshlets (us per launch):
@@ -686,7 +649,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       std::memset(&blob, 0, sizeof blob);
       blob.count = std::min(kBatchPerPrepare, count - first);
       blob.first = first;
-      std::memcpy(blob.elem, elems + first, sizeof(BatchElem) * blob.count);
+      std::memcpy(blob.core, cores + first, sizeof(BatchCore) * blob.count);
       launch_prepare_batch(blob, ctx->batch_dev, g_prep, s);
     }
   }

@@ -1349,18 +1349,38 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
 // call, and runs its own element.  The switch keeps the kernarg indexing static (a dynamic index into
 // a by-value aggregate would be lowered through scratch).
 __global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchElem* __restrict__ dev) {
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&blob.elem[0]);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(dev + blob.first);
-    const uint32_t words = blob.count * (uint32_t)(sizeof(BatchElem) / 4);
-    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
-  }
+#define OXC_PREPARE_CASE(i)                                                                             \
+  case i: {                                                                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0) expand_batch_core(blob.core[i], dev[blob.first + i]);      \
+    PrepareArgs pa;                                                                                     \
+    prepare_args_of(blob.core[i], pa);                                                                  \
+    prepare_body(pa, 0u);                                                                               \
+  } break;
   switch (blockIdx.y) {
-    case 0: prepare_body(blob.elem[0].prep, 0u); break;
-    case 1: prepare_body(blob.elem[1].prep, 0u); break;
-    case 2: prepare_body(blob.elem[2].prep, 0u); break;
-    default: prepare_body(blob.elem[3].prep, 0u); break;
+    OXC_PREPARE_CASE(0)
+    OXC_PREPARE_CASE(1)
+    OXC_PREPARE_CASE(2)
+    OXC_PREPARE_CASE(3)
+    OXC_PREPARE_CASE(4)
+    OXC_PREPARE_CASE(5)
+    OXC_PREPARE_CASE(6)
+    OXC_PREPARE_CASE(7)
+    OXC_PREPARE_CASE(8)
+    OXC_PREPARE_CASE(9)
+    OXC_PREPARE_CASE(10)
+    OXC_PREPARE_CASE(11)
+    OXC_PREPARE_CASE(12)
+    OXC_PREPARE_CASE(13)
+    OXC_PREPARE_CASE(14)
+    default: {
+      if (blockIdx.x == 0 && threadIdx.x == 0) expand_batch_core(blob.core[15], dev[blob.first + 15]);
+      PrepareArgs pa;
+      prepare_args_of(blob.core[15], pa);
+      prepare_body(pa, 0u);
+    } break;
   }
+#undef OXC_PREPARE_CASE
+  static_assert(kBatchPerPrepare == 16, "one case per element core of the blob");
 }
 __global__ __launch_bounds__(1024) void k_scan_batch(const BatchElem* __restrict__ dev) { scan_body(dev[blockIdx.y].scan); }
 __global__ __launch_bounds__(256) void k_expand_batch(const BatchElem* __restrict__ dev) { expand_body(dev[blockIdx.y].expand); }

@@ -121,8 +121,8 @@ struct ExpandArgs {
 // Argument blocks of one oxc_cull_geometry_batch call (plain pipeline, <= kMaxBatch independent
 // frames).  Passed by value to the batched prepare kernel, which copies it to the context's device
 // buffer; every later kernel of the call reads its element through blockIdx.y from there.
-constexpr uint32_t kMaxBatch = 8;       // elements per batched call
-constexpr uint32_t kBatchPerPrepare = 4;  // elements whose argument blocks fit one kernarg segment (k_prepare_batch)
+constexpr uint32_t kMaxBatch = 16;      // elements per batched call
+constexpr uint32_t kBatchPerPrepare = 16;  // element cores (BatchCore) per kernarg segment of k_prepare_batch
 struct BatchElem {
   PrepareArgs prep;
   ScanArgs scan;
@@ -132,14 +132,128 @@ struct BatchElem {
   TriTestArgs ttest;
   TriEmitArgs temit;
 };
-// What one k_prepare_batch launch receives by value: up to kBatchPerPrepare elements, which it publishes at
+// What the host hands over per element: every pointer and scalar of BatchElem exactly once (the seven stage
+// blocks repeat them 2-5 times).  k_prepare_batch rebuilds the stage blocks from it on the device
+// (expand_batch_core), so a kernarg segment carries kBatchPerPrepare = 8 elements instead of 5.
+struct BatchCore {
+  // caller buffers
+  const GpuMesh* meshes;
+  const float* transforms;
+  GpuMeshInstance* mesh_instances;
+  GpuMeshletInstance* meshlet_instances;
+  uint32_t* visible_out;    // visible_meshlet_instances_indices
+  uint32_t* reordered_out;  // reordered_indices
+  // the element's scratch lane
+  InstCache* cache;
+  InstCache* view_cache;
+  uint32_t* mesh_counts;
+  uint32_t* mesh_offsets;
+  uint64_t* bits;
+  uint32_t* m_chunk_counts;
+  uint32_t* m_supers;
+  uint64_t* tri_masks;
+  uint32_t* t_chunk_counts;
+  uint32_t* t_supers;
+  // counters
+  uint32_t* slot;  // tri_cmd / draw_cmd live at slot + SLOT_TRI_CMD / SLOT_DRAW_CMD
+  uint32_t* vis;
+  uint32_t* meshlets_cmd;
+  uint32_t n_supers_meshlets, n_supers_tris;
+  uint32_t mesh_instance_count;
+  uint32_t cull_flags;
+  uint32_t do_cull_meshes;
+  uint32_t init_vis;
+  uint32_t n_host;
+  uint32_t count_meshlets;  // meshlets per published count of the test kernel (64 * groups per wave)
+  oxc_cull_camera cam;
+};
+// What one k_prepare_batch launch receives by value: up to kBatchPerPrepare elements, which it expands to
 // dev[first .. first + count) and prepares (blockIdx.y = element).
 struct BatchBlob {
-  BatchElem elem[kBatchPerPrepare];
+  BatchCore core[kBatchPerPrepare];
   uint32_t count;
   uint32_t first;
 };
-static_assert(sizeof(BatchBlob) <= 4000, "must fit the kernarg segment");
+static_assert(sizeof(BatchBlob) <= 8000, "must fit the kernarg segment");
+
+// The stage blocks of one element from its core (the only place that knows which block needs which field).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void prepare_args_of(const BatchCore& c, PrepareArgs& pa) {
+  pa.meshes = c.meshes;
+  pa.transforms = c.transforms;
+  pa.mesh_instances = c.mesh_instances;
+  pa.cache = c.cache;
+  pa.mesh_counts = c.mesh_counts;
+  pa.slot = c.slot;
+  pa.vis = c.vis;
+  pa.meshlets_cmd = c.meshlets_cmd;
+  pa.supers_meshlets = c.m_supers;
+  pa.supers_tris = c.t_supers;
+  pa.n_supers_meshlets = c.n_supers_meshlets;
+  pa.n_supers_tris = c.n_supers_tris;
+  pa.mesh_instance_count = c.mesh_instance_count;
+  pa.cull_flags = c.cull_flags;
+  pa.do_cull_meshes = c.do_cull_meshes;
+  pa.init_vis = c.init_vis;
+  pa.seed_total = 0;
+  pa.cam = c.cam;
+  pa.clipmaps = nullptr;
+  pa.view_cache = c.view_cache;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
+  uint32_t* tri_cmd = c.slot + SLOT_TRI_CMD;
+  uint32_t* draw_cmd = c.slot + SLOT_DRAW_CMD;
+  prepare_args_of(c, e.prep);
+  e.scan = ScanArgs{c.mesh_counts, c.mesh_offsets, c.mesh_instance_count, c.vis, c.meshlets_cmd};
+  e.expand = ExpandArgs{c.mesh_counts, c.mesh_offsets, c.mesh_instance_count, c.meshlet_instances};
+  MeshletTestArgs& ta = e.test;
+  ta.n_host = c.n_host;
+  ta.cache = c.cache;
+  ta.meshlet_instances = c.meshlet_instances;
+  ta.vis = c.vis;
+  ta.mask = nullptr;
+  ta.bits = c.bits;
+  ta.chunk_counts = c.m_chunk_counts;
+  ta.supers = c.m_supers;
+  ta.hiz_data = nullptr;
+  ta.hiz_w = ta.hiz_h = ta.hiz_levels = ta.hiz_lds_first = 0;
+  ta.near_clip = c.cam.near_clip;
+  ta.cam_pos[0] = c.cam.position[0];
+  ta.cam_pos[1] = c.cam.position[1];
+  ta.cam_pos[2] = c.cam.position[2];
+  MeshletEmitArgs& ea = e.emit;
+  ea.n_host = c.n_host;
+  ea.count_meshlets = c.count_meshlets;
+  ea.bits = c.bits;
+  ea.chunk_counts = c.m_chunk_counts;
+  ea.supers = c.m_supers;
+  ea.vis = c.vis;
+  ea.tri_cmd = tri_cmd;
+  ea.out = c.visible_out;
+  TriTestArgs& tt = e.ttest;
+  tt.cache = c.cache;
+  tt.meshlet_instances = c.meshlet_instances;
+  tt.visible = c.visible_out;
+  tt.vis = c.vis;
+  tt.tri_cmd = tri_cmd;
+  tt.tri_masks = c.tri_masks;
+  tt.chunk_counts = c.t_chunk_counts;
+  tt.supers = c.t_supers;
+  TriEmitArgs& te = e.temit;
+  te.tri_masks = c.tri_masks;
+  te.visible = c.visible_out;
+  te.vis = c.vis;
+  te.tri_cmd = tri_cmd;
+  te.chunk_counts = c.t_chunk_counts;
+  te.supers = c.t_supers;
+  te.draw_cmd = draw_cmd;
+  te.out = c.reordered_out;
+}
 
 struct HizArgs {
   const float* depth;

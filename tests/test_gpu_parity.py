@@ -455,10 +455,11 @@ def test_stage_subsets_and_argument_validation(renderer, oracle_lib):
         expect_invalid(m)
 
 
-@pytest.mark.parametrize("count", [6, 8, 10], ids=["6-two-prepare-pieces", "8-max", "10-falls-back"])
+@pytest.mark.parametrize("count", [3, 8, 9, 16, 18], ids=["3", "8-one-full-piece", "9-two-pieces", "16-max", "18-falls-back"])
 def test_batch_sizes_beyond_one_kernarg_piece(renderer, oracle_lib, count):
-    """Up to 8 elements are fused (their argument blocks are published by two prepare launches of <= 4 elements);
-    more than 8 (or a HiZ element) is processed one call at a time -- always with the same results."""
+    """Up to 16 elements are fused (their argument cores are handed over by prepare launches of <= 8 elements each, which
+    rebuild the per-stage argument blocks on the device); more than 16 (or a HiZ element) is processed one call at a time --
+    always with the same results."""
     from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
 
     pairs = [_pair(SceneSpec(n_mesh_instances=6, meshlets_per_mesh=40 + 7 * i, seed=100 + i)) for i in range(count)]
