@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=3, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
     ap.add_argument("--batch", type=int, default=16, help="frames per oxc_cull_geometry_batch call (1 = one call per step; max 16)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a HIP graph even with >= 8 frames per launch (default there: eager launches on real streams, which overlap "
+                         "the small prepare/emit kernels of one call with the test kernel of another; measured 1.94e11 vs 1.73e11)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--native-comm", action="store_true",
                     help="multi-GPU: run the two exchanges of the path (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
@@ -532,7 +535,10 @@ def main():
     # ---- optional HIP graph over one rotation through the copies ----
     graph = None
     per_replay = units_per_rotation * steps_per_call
-    if not args.no_graph and not full and not multiview and args.steps >= per_replay:
+    # a HIP graph pays when the loop is launch-bound (few frames per launch); at >= 8 frames per launch there are three
+    # launches per ~100 us and the graph executor only gets in the way of cross-stream overlap
+    want_graph = not args.no_graph and (args.graph or steps_per_call < 8)
+    if want_graph and not full and not multiview and args.steps >= per_replay:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             for s_ in streams[1:]:
@@ -576,6 +582,8 @@ def main():
         while args.steps - done >= steps_per_call:
             run_unit(done // steps_per_call)
             done += steps_per_call
+            if dist is not None and graph is None and (done // steps_per_call) % units_per_rotation == 0:
+                gather_counts()  # same cadence as the graph path: once per rotation through the copies
         while done < args.steps:  # remainder smaller than a batch: single calls
             run_step(done)
             done += 1
@@ -593,7 +601,7 @@ def main():
 
     # ---- secondary figure: the same steps with ONE batch in flight (one stream, dependent launches) ----
     single = None
-    if n_streams > 1 and graph is not None:
+    if n_streams > 1 and not full and not multiview and args.steps >= per_replay:
         single_stream[0] = True
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, stream=stream):
@@ -644,8 +652,11 @@ def main():
     probe = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
     probe.random_(0, 255)
     with torch.cuda.stream(stream):
-        for _ in range(30):  # the memory clock needs tens of ms of sustained streaming before the rate settles
-            r.stream_read_probe(probe, stream)
+        t_probe = time.perf_counter()  # the memory clock needs sustained streaming before the rate settles (a short --steps run
+        while time.perf_counter() - t_probe < 0.3:  # leaves the GPU idling at low clocks by the time it gets here: 2.0 instead of 6.0 TB/s)
+            for _ in range(30):
+                r.stream_read_probe(probe, stream)
+            stream.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(30):
