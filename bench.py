@@ -429,9 +429,9 @@ def main():
         assert groups, "--batch needs at least `batch` copies per stream"
     steps_per_call = batch
 
-    def run_group(gi):
+    def run_group(gi, n=None):
         k, cf, cc = groups[gi % len(groups)]
-        check(lib.oxc_cull_geometry_batch(renderers[k]._ctx, batch, cf, cc, sps[0] if single_stream[0] else sps[k]))
+        check(lib.oxc_cull_geometry_batch(renderers[k]._ctx, n or batch, cf, cc, sps[0] if single_stream[0] else sps[k]))
 
     # config 5: the views are independent cull_geometry calls over the same scene; `--batch` of them go through one
     # oxc_cull_geometry_batch call (each element has its own outputs and its own mesh_instances copy: cull_meshes
@@ -584,7 +584,10 @@ def main():
             done += steps_per_call
             if dist is not None and graph is None and (done // steps_per_call) % units_per_rotation == 0:
                 gather_counts()  # same cadence as the graph path: once per rotation through the copies
-        while done < args.steps:  # remainder smaller than a batch: single calls
+        if batch > 1 and 1 < args.steps - done:  # remainder smaller than a batch: one shorter batched call
+            run_group(done // steps_per_call, args.steps - done)
+            done = args.steps
+        while done < args.steps:
             run_step(done)
             done += 1
         if dist is not None and graph is None:
