@@ -642,15 +642,27 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   // grid.y = count; grid.x cap per element.  Measured for the meshlet test kernel with 8 x 1M meshlets (us per launch):
   // 128 -> 48.8, 256 -> 46.1, 320 -> 43.2, 512 -> 42.3, 768 -> 42.9, 1024 -> 43.1 blocks per element
   const uint32_t cap = std::max(max_grid / count, ctx->num_cus * 2);
-  for (uint32_t first = 0; first < count; first += kBatchPerPrepare) {  // kernarg-sized pieces
+  {
+    // One launch hands over all element cores: a 4.5 KB kernarg segment.  A runtime that refuses a segment of that
+    // size fails the launch synchronously; nothing has been enqueued then and the elements are culled one by one.
+    static_assert(kBatchPerPrepare == kMaxBatch, "one prepare launch per batched call");
+    BatchBlob blob;
+    std::memset(&blob, 0, sizeof blob);
+    blob.count = count;
+    blob.first = 0;
+    std::memcpy(blob.core, cores, sizeof(BatchCore) * count);
+    hipError_t launch_err;
     {
       KernelTimer t(ctx, OXC_K_PREPARE, s);
-      BatchBlob blob;
-      std::memset(&blob, 0, sizeof blob);
-      blob.count = std::min(kBatchPerPrepare, count - first);
-      blob.first = first;
-      std::memcpy(blob.core, cores + first, sizeof(BatchCore) * blob.count);
       launch_prepare_batch(blob, ctx->batch_dev, g_prep, s);
+      launch_err = hipGetLastError();
+    }
+    if (launch_err != hipSuccess) {
+      for (uint32_t e = 0; e < count; e++) {
+        oxc_status st = oxc_cull_geometry(ctx, &frames[e], &contexts[e], hip_stream);
+        if (st != OXC_OK) return st;
+      }
+      return OXC_OK;
     }
   }
   if (do_meshes) {

@@ -1345,9 +1345,10 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
   tris_emit_body<LATE, WIDE>(a);
 }
 
-// Batched prepare: gets the whole blob by value (kernarg), publishes it for the later kernels of the
-// call, and runs its own element.  The switch keeps the kernarg indexing static (a dynamic index into
-// a by-value aggregate would be lowered through scratch).
+// Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
+// element in device memory for the later kernels of the call (expand_batch_core), and prepares that element's
+// instance rows.  The switch keeps the kernarg indexing static (a dynamic index into a by-value aggregate
+// would be lowered through scratch).
 __global__ __launch_bounds__(256) void k_prepare_batch(BatchBlob blob, BatchElem* __restrict__ dev) {
 #define OXC_PREPARE_CASE(i)                                                                             \
   case i: {                                                                                             \
