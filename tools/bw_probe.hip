@@ -80,6 +80,28 @@ __global__ __launch_bounds__(256) void k_fill(u4* __restrict__ o, uint64_t n16) 
   }
 }
 
+// The HiZ build's access shape on an 8192-wide f32 image: only EVEN rows are read.
+// TILE = false: a block reads whole rows (grid-stride over even rows); TILE = true: a block reads a 512-byte segment of 64
+// even rows (what a 64x64 mip-0 tile touches).  pitch in floats (8192 = tight, 8192 + 64 = padded by 256 B).
+template <bool TILE>
+__global__ __launch_bounds__(256) void k_read_even_rows(const float* __restrict__ img, uint32_t pitch, uint32_t rows, uint32_t* sink) {
+  uint32_t acc = 0;
+  if (!TILE) {
+    for (uint32_t r = blockIdx.x; r < rows / 2; r += gridDim.x) {
+      const u4* row = reinterpret_cast<const u4*>(img + (size_t)(2 * r) * pitch);
+      for (uint32_t c = threadIdx.x; c < 8192 / 4; c += 256) acc ^= fold(row[c]);
+    }
+  } else {
+    const uint32_t tiles_x = 8192 / 128, bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;  // 128 floats = 512 B per row
+    const uint32_t lane = threadIdx.x & 31, rsub = threadIdx.x >> 5;                             // 32 lanes x 16 B = one segment
+    for (uint32_t r = rsub; r < 64; r += 8) {
+      const u4* row = reinterpret_cast<const u4*>(img + (size_t)(2 * (by * 64 + r)) * pitch + bx * 128);
+      acc ^= fold(row[lane]);
+    }
+  }
+  if (acc == 0x9E3779B9u) *sink = acc;
+}
+
 template <class F>
 static double time_us(F&& launch, int reps) {
   hipEvent_t e0, e1;
@@ -136,6 +158,19 @@ int main() {
     report(nm, time_us([&] { hipLaunchKernelGGL((k_read_lanecontig<L>), dim3((uint32_t)(n16 / (256 * L))), dim3(256), 0, 0, a, sink); }, 5), bytes); }
   LANEC(2)
   LANEC(4)
+  {
+    const uint32_t rows = 8192;  // 8192 x 8192 f32 = 256 MiB (tight); every other row = 128 MiB read per launch
+    for (uint32_t pad : {0u, 64u, 32u}) {
+      const uint32_t pitch = 8192 + pad;
+      char nm[96];
+      snprintf(nm, 96, "even rows, whole rows per block, pitch 8192+%u", pad);
+      int it = 0;  // rotate through 7 images so that no launch finds its rows in the 256 MB Infinity Cache
+      auto image = [&] { return reinterpret_cast<const float*>(a) + (size_t)(it++ % 7) * pitch * rows; };
+      report(nm, time_us([&] { hipLaunchKernelGGL((k_read_even_rows<false>), dim3(2048), dim3(256), 0, 0, image(), pitch, rows, sink); }, 21), 4.0 * 8192 * rows / 2);
+      snprintf(nm, 96, "even rows, 512 B x 64-row tiles, pitch 8192+%u", pad);
+      report(nm, time_us([&] { hipLaunchKernelGGL((k_read_even_rows<true>), dim3(64 * 64), dim3(256), 0, 0, image(), pitch, rows, sink); }, 21), 4.0 * 8192 * rows / 2);
+    }
+  }
   report("copy grid-stride grid=4096 (read+write bytes)", time_us([&] { hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, a, b, n16); }, 5), 2.0 * bytes);
   report("copy grid-stride grid=16384 (read+write bytes)", time_us([&] { hipLaunchKernelGGL(k_copy, dim3(16384), dim3(256), 0, 0, a, b, n16); }, 5), 2.0 * bytes);
   report("copy oneshot L=4 (read+write bytes)", time_us([&] { hipLaunchKernelGGL((k_copy_oneshot<4>), dim3((uint32_t)(n16 / 1024)), dim3(256), 0, 0, a, b); }, 5), 2.0 * bytes);
