@@ -615,9 +615,18 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
         for (int j = 0; j < G; j++) {
           const uint4 b = bnd[j];
+          const bool was_visible = (mword[j] & 1u) != 0u;
+          if (!LATE && __builtin_amdgcn_ballot_w64(mine[j] && was_visible) == 0) {
+            // early pass, and no meshlet of this group was visible last frame (cull_meshlets_hiz.slang:45-51: they all return
+            // before any test): skip the decode + frustum code for the whole group.  Visibility is coherent per instance, so
+            // this is most groups of a typical frame.
+            cx[j] = cy[j] = cz[j] = ex[j] = ey[j] = ez[j] = 0.0f;
+            need[j] = 0u;
+            st[j] = mine[j] ? 0u : st[j];
+            continue;
+          }
           cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
           ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
-          const bool was_visible = (mword[j] & 1u) != 0u;
           bool vis = mine[j] & (LATE ? true : was_visible);
           vis = vis & test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j]);
           const bool nc = vis & (((int32_t)b.w >> 24) != 127);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
