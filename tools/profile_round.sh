@@ -10,7 +10,7 @@ rm -rf gpurun_out/raw; mkdir -p gpurun_out/raw gpurun_out/profiles_out
 ./tools/profile_trace.sh gpurun_out/raw/trace_c2 --steps 2400 --warmup 240 > /dev/null
 ./tools/pmc_passes.sh gpurun_out/raw/pmc_c2 > /dev/null
 python tools/summarize_profiles.py ${TAG}_config2_pmc --stats gpurun_out/raw/trace_c2/t_kernel_stats.csv --pmc gpurun_out/raw/pmc_c2 \
-  --note "bench.py config2 (1M meshlets x 48 rotating copies), --streams 1; kernel_trace_stats from rocprofv3 --kernel-trace --stats (graph replay), pmc from separate --pmc passes (eager)"
+  --note "bench.py config2 (1M meshlets x 48 rotating copies), --streams 1; 16 frames per launch; kernel_trace_stats from rocprofv3 --kernel-trace --stats, pmc from separate --pmc passes (both eager launches)"
 cp gpurun_out/raw/trace_c2/bench.json gpurun_out/profiles_out/${TAG}_config2_trace_bench.json
 ./tools/profile_trace.sh gpurun_out/raw/trace_c3 --workload config3 --steps 20 --warmup 3 > /dev/null
 BENCH_ARGS="--workload config3 --steps 6 --warmup 2" ./tools/pmc_passes.sh gpurun_out/raw/pmc_c3 > /dev/null
