@@ -689,8 +689,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": round(bytes_per_unit * units), "kernel_avg_us": dom_us,
-                    "measured_stream_read_GBps": round(stream_read_gbps, 1),
-                    "frac_of_measured_stream_read": round(achieved / stream_read_gbps, 4)}
+                    "measured_stream_read_GBps": round(stream_read_gbps, 1),  # plain 16 B/lane loads; `nt` loads stream at 6.8-7.1 TB/s
+                    "frac_of_measured_stream_read": round(achieved / stream_read_gbps, 4)}  # (profiles/r01_bw_probe.txt)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary (collected in its own
     # passes, FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 as MI355X_MICROARCH.md prescribes); PMC counters
