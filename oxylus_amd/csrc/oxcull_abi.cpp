@@ -639,8 +639,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     g_ttest = std::max(g_ttest, std::min(t_chunks, max_grid));
     g_temit = std::max(g_temit, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid));
   }
-  // grid.y = count; grid.x cap per element.  Measured for the meshlet test kernel with 8 x 1M meshlets (us per launch):
-  // 128 -> 48.8, 256 -> 46.1, 320 -> 43.2, 512 -> 42.3, 768 -> 42.9, 1024 -> 43.1 blocks per element
+  // grid.y = count; grid.x cap per element for the small stages (the meshlet test kernel takes its full grid, below)
   const uint32_t cap = std::max(max_grid / count, ctx->num_cus * 2);
   {
     // One launch hands over all element cores: a 4.5 KB kernarg segment.  A runtime that refuses a segment of that
@@ -681,7 +680,9 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
         const char* e = std::getenv("OXC_TEST_GRID");
         return e ? (uint32_t)std::atoi(e) : 0u;
       }();
-      launch_meshlets_test_batch(ctx->batch_dev, count, std::min(g_test, grid_env ? grid_env : cap), s);
+      // At 64 VGPRs (8 waves/SIMD) the test kernel wants every block it can get: with 16 x 1M meshlets, blocks per element
+      // 384 -> 74.6 us, 512 -> 73.7, 768 -> 73.2, 1024 -> 70.7, 2048 -> 70.0 (>= 977 blocks: one 1024-meshlet step per block)
+      launch_meshlets_test_batch(ctx->batch_dev, count, grid_env ? std::min(g_test, grid_env) : g_test, s);
     }
     KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
     launch_meshlets_emit_batch(ctx->batch_dev, count, std::min(g_emit, cap), s);
