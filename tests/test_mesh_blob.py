@@ -205,3 +205,36 @@ def test_gpu_two_lod_blob_selects_and_culls_like_checker(renderer, oracle_lib):
     assert set(np.unique(want["lod_index"]).tolist()) == {0, 1}
     got = gpu_frame(renderer, gpu_scene, run_cull_meshes=True)
     assert_same(want, got, ["total", "lod_index", "visible", "indices"])
+
+
+def test_packed_blob_round_trips_every_array(liboxcull, oracle_lib):
+    """Every array can be read back from the packed blob at the offsets the LOD table / GPU::Mesh record point to (here: host
+    addresses), texcoords included; padding bytes between arrays are zero."""
+    import oracle
+
+    pos, lods = _two_lod_mesh(seed=3)
+    nrm = torch.nn.functional.normalize(pos, dim=1)
+    uv = pos[:, :2] * 0.25 + 0.5
+    qpos, qnrm, quv = oracle.quantize_vertex_streams(pos, nrm, uv)
+    arrays = []
+    for sub, meshlets, vidx, micro, err in lods:
+        b, m6, _ = oracle.build_meshlet_bounds(pos, meshlets, vidx, micro)
+        arrays.append(MeshLodArrays(sub.reshape(-1).to(torch.int32), meshlets, b, micro, vidx, err))
+    blob, mesh, lay = pack_mesh_blob(qpos, qnrm, quv, arrays, torch.tensor([0., 0, 0, 1, 1, 1]), "cpu")
+    base = blob.data_ptr()
+    used = torch.zeros(lay.size, dtype=torch.bool)
+
+    def view(addr, like):
+        off, n = addr - base, like.numel() * like.element_size()
+        assert 0 <= off and off + n <= lay.size and not used[off:off + n].any()  # in range, no overlap
+        used[off:off + n] = True
+        return blob[off:off + n].view(like.dtype).reshape(like.shape)
+
+    assert torch.equal(view(mesh[0].item(), qpos), qpos)
+    assert torch.equal(view(mesh[1].item(), qnrm), qnrm)
+    assert torch.equal(view(mesh[2].item(), quv), quv)
+    table = view(mesh[4].item(), torch.zeros((2, 8), dtype=torch.int64)).clone()
+    for i, a in enumerate(arrays):
+        for k, t in enumerate((a.indices, a.meshlets, a.meshlet_bounds, a.local_triangle_indices, a.indirect_vertex_indices)):
+            assert torch.equal(view(table[i, k].item(), t), t)
+    assert not blob[~used].any()  # alignment padding only
