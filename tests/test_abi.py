@@ -64,6 +64,8 @@ def test_cpp_shim_compiles_and_links(tmp_path):
 
 def test_header_is_plain_c99(tmp_path):
     """The boundary is a C ABI: include/oxcull.h must compile as strict C99 (what a cgo / JNI / ctypes-gen binding would parse)."""
+    import subprocess
+
     src = tmp_path / "c99.c"
     src.write_text('#include "oxcull.h"\nint main(void) { oxc_cull_geometry_context c; oxc_mesh_blob_layout l; (void)c; (void)l; return 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only", str(src)])
