@@ -104,6 +104,32 @@ def widening_rows():
     np.savez_compressed(os.path.join(HERE, "raster_512x384.npz"), visdepth=vd.numpy())
 
 
+def vertex_streams():
+    """SURVEY 8(f)-1, format side: the three quantised vertex streams (specials first: signed zeros, +-1, out-of-range, Inf,
+    NaN, half overflow / underflow, snorm10 ties, a float denormal) and two mesh-blob layouts."""
+    g = torch.Generator().manual_seed(404)  # the data of tests/test_mesh_blob.py::test_gpu_quantize_vertex_streams_matches_checker
+    V = 100_003
+    pos = (torch.rand((V, 3), generator=g) * 2 - 1) * torch.tensor([1e-6, 1.0, 7e4])[torch.randint(0, 3, (V, 1), generator=g)]
+    nrm = torch.nn.functional.normalize(torch.randn((V, 3), generator=g), dim=1)
+    uv = torch.rand((V, 2), generator=g) * 4 - 1
+    specials = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.5, -1.5, float("inf"), float("-inf"), float("nan"), 65504.0, 65520.0, 6.1e-5, 5.96e-8,
+                             0.5 / 511, 1.5 / 511, -0.5 / 511, 1e-40])
+    for t in (pos, nrm, uv):
+        t.reshape(-1)[:specials.numel()] = specials
+    pos, nrm, uv = pos[:4096].contiguous(), nrm[:4096].contiguous(), uv[:4096].contiguous()
+    qpos, qnrm, quv = oracle.quantize_vertex_streams(pos, nrm, uv)
+    counts = [[(9, 3, 13, 7)], [(6000, 47, 5640, 2950), (3000, 24, 2880, 1500), (1500, 12, 1440, 760)]]
+    layouts = []
+    for (v, tex), c in zip(((5, False), (1234, True)), counts):
+        lay = oracle.mesh_blob_layout(v, tex, c)
+        row = [v, int(tex), len(c), lay["size"], lay["lod_metadata_offset"], lay["vertex_positions"], lay["vertex_normals"], lay["texture_coords"]]
+        for cc, lo in zip(c, lay["lods"]):
+            row += list(cc) + [lo[k] for k in ("indices", "meshlets", "meshlet_bounds", "local_triangle_indices", "indirect_vertex_indices")]
+        layouts.append(np.asarray(row + [0] * (8 + 9 * 3 - len(row)), dtype=np.int64))
+    np.savez_compressed(os.path.join(HERE, "vertex_streams_4096.npz"), positions=pos.numpy(), normals=nrm.numpy(), texcoords=uv.numpy(),
+                        qpos=qpos.numpy(), qnrm=qnrm.numpy(), quv=quv.numpy(), blob_layouts=np.stack(layouts))
+
+
 def main():
     oracle.build()
     # (a) full pipeline: cull_meshes + LOD, two-pass occlusion against a 64x64 HiZ, triangles
@@ -143,6 +169,7 @@ def main():
     arrays["near_threshold"] = np.asarray(st.meshlets_near_threshold)
     np.savez_compressed(os.path.join(HERE, "meshlets_37x111.npz"), **arrays)
     widening_rows()
+    vertex_streams()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

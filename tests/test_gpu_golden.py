@@ -71,3 +71,14 @@ def test_hip_matches_golden_widening_rows(renderer):
     renderer.draw_visbuffer(ctx, zp["camera_pv"], 512, 384, vd, clear=True)
     torch.cuda.synchronize()
     assert np.array_equal(vd.cpu().numpy(), np.load(os.path.join(GOLDEN, "raster_512x384.npz"))["visdepth"])
+
+
+def test_hip_matches_golden_vertex_streams(renderer):
+    """SURVEY 8(f)-1, format side: the three quantised vertex streams against the committed fixture (specials first)."""
+    z = np.load(os.path.join(GOLDEN, "vertex_streams_4096.npz"))
+    pos, nrm, uv = (torch.from_numpy(z[k]).cuda() for k in ("positions", "normals", "texcoords"))
+    qpos, qnrm, quv = renderer.quantize_vertex_streams(pos, nrm, uv)
+    torch.cuda.synchronize()
+    assert np.array_equal(qpos.cpu().numpy(), z["qpos"])
+    assert np.array_equal(qnrm.cpu().numpy(), z["qnrm"])
+    assert np.array_equal(quv.cpu().numpy(), z["quv"])
