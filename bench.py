@@ -317,6 +317,31 @@ def bench_vsm(args, r, dev, stream, rank, world, dist):
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """Host threads this process may actually run at once: the affinity mask, cut down by a cgroup CPU quota when the
+    container has one (a box can show 256 CPUs in the mask and still be limited to a few cores' worth of time)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2: "<quota|max> <period>"
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        cores = max(1, min(cores, int(quota + 0.999)))
+    return cores
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -718,10 +743,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_scene is not None:
         import oracle
 
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count() or 1
+        cores = usable_cores()
         cam = cpu_scene.cull_camera()
         t1c0 = time.perf_counter()
         oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=1)
