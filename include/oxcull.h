@@ -17,10 +17,16 @@
  * Vulkan consumer could bind the outputs unchanged.
  *
  * Conventions: POD structs only, no exceptions cross the ABI, every entry point returns an
- * oxc_status.  One context per device, externally synchronised (the reference calls these from
- * the main thread only, RenderContext.cpp:585-586).  All work is enqueued asynchronously on the
- * caller's hipStream_t (passed as void*); the only entry points that synchronise are
- * oxc_read_counters and oxc_reserve (when it has to grow scratch memory).
+ * oxc_status.  A context is externally synchronised (the reference calls these from the main thread
+ * only, RenderContext.cpp:585-586) and owns ONE set of scratch buffers (instance cache, survivor
+ * bitmaps, chunk counts), so its calls are ordered: a call on a different hipStream_t than the
+ * context's previous call first waits (hipStreamWaitEvent, on the device) for that previous call.
+ * Independent work that should overlap -- a main view and a shadow view, several frames in flight
+ * -- uses one context per stream.  All work is enqueued asynchronously on the caller's hipStream_t
+ * (passed as void*).  Entry points that synchronise the host: oxc_read_counters, oxc_debug_read_u32,
+ * oxc_profile_end, and any call that has to GROW scratch memory (oxc_reserve up front avoids that;
+ * while the stream is being captured into a HIP graph a call that would have to grow returns
+ * OXC_INVALID_ARG instead).
  */
 #ifndef OXCULL_H
 #define OXCULL_H
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OXC_ABI_VERSION 1u
+#define OXC_ABI_VERSION 2u
 
 typedef struct oxc_ctx oxc_ctx;
 
@@ -137,6 +143,18 @@ typedef struct oxc_cull_geometry_context {
    * 64 triangles per meshlet; 1 = wide index (id << 9) | (3t+k) for meshlets of up to 128 triangles
    * (at most 2^23 meshlet instances per call, reordered_indices_buffer >= N*128*3*4 bytes). */
   uint32_t wide_triangle_index;
+  /* Extension named by the north star ("per-triangle backface + small-triangle cull"); the reference has only the
+   * clip-z and backface tests (cull_triangles.slang:68-69, cull.slang:169-171).  0 (default) = reference behaviour,
+   * output byte-identical to a build without the flag.  1 = a triangle that passed both reference tests is ALSO
+   * dropped when its screen-space bounding box covers no pixel centre of a cull_camera.resolution target:
+   *   per corner (only when all three clip.w > 0, otherwise the triangle is kept):
+   *     s.x = ((clip.x / clip.w) * 0.5 + 0.5) * resolution.x,  s.y likewise     (IEEE binary32, no contraction)
+   *   lo = min over corners, hi = max over corners (per axis)
+   *   dropped iff floor(lo.x + 0.5) == floor(hi.x + 0.5) || floor(lo.y + 0.5) == floor(hi.y + 0.5)
+   * (pixel centres sit at k + 0.5: an interval [lo, hi] holds one iff the two roundings differ).  Not supported by
+   * the fused path of oxc_cull_geometry_batch (such elements are processed one after the other). */
+  uint32_t small_triangle_cull;
+  uint32_t _reserved0;
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */
@@ -198,7 +216,9 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
  * running cull_meshes (fills context->visibility_buffer = {total,0,0} and
  * cull_meshlets_cmd_buffer = {ceil(total/64),1,1}).  The reference always derives these from
  * cull_meshes; the synthetic benchmark configurations start from a given list.
- * Seeded buffers stay valid for 512 further seeds; per-call counter buffers for 512 further calls. */
+ * Counter buffers handed back in a context (visibility / cull_meshlets_cmd / cull_triangles_cmd /
+ * draw_geometry_cmd) are callee-owned slots of a ring: a seeded pair stays valid for 4096 further seeds, a
+ * per-call set for 4096 further cull_geometry / cull_terrain calls (a batched call uses one per element) on the same oxc_ctx. */
 oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* context, uint32_t total,
                                       void* hip_stream);
 
@@ -219,16 +239,22 @@ enum {
   OXC_K_PREPARE = 0,
   OXC_K_MESHES_SCAN = 1,
   OXC_K_MESHES_EXPAND = 2,
-  OXC_K_MESHLETS_TEST = 3,
+  OXC_K_MESHLETS_TEST = 3,  /* plain / early-pass variants */
   OXC_K_MESHLETS_EMIT = 4,
   OXC_K_TRIANGLES_TEST = 5,
   OXC_K_TRIANGLES_EMIT = 6,
   OXC_K_HIZ = 7,
-  OXC_K_COUNT = 8
+  OXC_K_MESHLETS_TEST_LATE = 8, /* the LatePass instantiations, timed apart: their candidate sets differ */
+  OXC_K_MESHLETS_EMIT_LATE = 9,
+  OXC_K_TRIANGLES_TEST_LATE = 10,
+  OXC_K_TRIANGLES_EMIT_LATE = 11,
+  OXC_K_MESHLETS_OCCLUSION = 12,      /* occlusion pass over the compacted frustum/cone survivors (use_hiz) */
+  OXC_K_MESHLETS_OCCLUSION_LATE = 13,
+  OXC_K_COUNT = 16
 };
 typedef struct oxc_kernel_times {
-  double total_ms[8];
-  uint32_t launches[8];
+  double total_ms[16];
+  uint32_t launches[16];
   double empty_pair_ms;
 } oxc_kernel_times;
 oxc_status oxc_profile_begin(oxc_ctx* ctx);

@@ -43,15 +43,37 @@ class MarginStats(C.Structure):
     _fields_ = [("meshlets_near_threshold", C.c_uint64), ("triangles_near_threshold", C.c_uint64)]
 
 
-_lib = None
+FAST_LIB_PATH = os.path.join(_HERE, "liboxcull_oracle_fast.so")
+_libs = {}
+_variant = "canonical"
+
+
+class variant:
+    """`with oracle.variant("fast"):` routes every wrapper below to liboxcull_oracle_fast.so -- the same source built
+    with -DORC_FAST_ENVELOPE (fused multiply-adds, reciprocal divisions: rewrites a fast-math shader compiler may
+    apply).  It is not a checker: it exists to count how many decisions of a scene such rewrites flip."""
+
+    def __init__(self, name: str):
+        assert name in ("canonical", "fast")
+        self.name = name
+
+    def __enter__(self):
+        global _variant
+        self.prev, _variant = _variant, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _variant
+        _variant = self.prev
 
 
 def lib() -> C.CDLL:
-    global _lib
+    path = FAST_LIB_PATH if _variant == "fast" else LIB_PATH
+    _lib = _libs.get(path)
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(path):
             build()
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
         l.orc_dequantize_half.argtypes = [C.c_uint16]
         l.orc_dequantize_half.restype = f32
@@ -108,7 +130,12 @@ def lib() -> C.CDLL:
         l.orc_build_meshlet_bounds.restype = None
         l.orc_quantize_vertex_streams.argtypes = [vp, vp, vp, u32, vp, vp, vp]
         l.orc_quantize_vertex_streams.restype = None
-        _lib = l
+        l.orc_test_triangle_small.argtypes = [vp, vp]
+        l.orc_cull_triangles_flags.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, C.c_int, C.c_int]
+        l.orc_cull_triangles_flags.restype = u32
+        l.orc_is_fast_envelope.restype = C.c_int
+        assert bool(l.orc_is_fast_envelope()) == (path == FAST_LIB_PATH)
+        _libs[path] = _lib = l
     return _lib
 
 
@@ -231,10 +258,18 @@ def cull_meshlets_hiz(scene, cam, meshlet_instances: torch.Tensor, cull_flags: i
                                        C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))
 
 
+def triangle_small(clip3x4, resolution) -> bool:
+    a, r = f32a(clip3x4), f32a(resolution)
+    return bool(lib().orc_test_triangle_small(_p(a), _p(r)))
+
+
 def cull_triangles(scene, cam, meshlet_instances: torch.Tensor, visible: torch.Tensor, first: int, count: int, nthreads: int = 1,
-                   stats: MarginStats = None, wide: bool = False) -> torch.Tensor:
+                   stats: MarginStats = None, wide: bool = False, small_triangle_cull: bool = False) -> torch.Tensor:
     out = torch.zeros(max(count, 1) * (384 if wide else 192), dtype=torch.int32)
-    if wide:
+    if small_triangle_cull:
+        n = lib().orc_cull_triangles_flags(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
+                                           _p(cam), _p(out), int(wide), 1)
+    elif wide:
         n = lib().orc_cull_triangles_wide(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
                                           _p(cam), _p(out))
     elif nthreads > 1:

@@ -32,7 +32,27 @@ static inline float u2f(uint32_t u) {
   memcpy(&f, &u, 4);
   return f;
 }
-static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+/* Canonical build (the oracle): IEEE binary32, left-to-right, no contraction, true division.
+ * -DORC_FAST_ENVELOPE builds liboxcull_oracle_fast.so instead: the SAME algorithm with the rewrites a
+ * SLANG_FLOATING_POINT_MODE_FAST / Vulkan driver compiler may legally apply (ResourceCompiler/private/
+ * Session.cpp:49-58) -- every a*b+c fused into one rounding, x/y as x * (1/y), normalisation by a reciprocal
+ * square root.  It is NOT a second oracle: it exists so the tests and the bench can report how many decisions
+ * of a scene such rewrites can flip (the "unpinned gap" of DESIGN.md section 2), next to orc_margin_stats. */
+#ifdef ORC_FAST_ENVELOPE
+#define MADD(a, b, c) fmaf((a), (b), (c))
+#define DIVF(a, b) ((a) * (1.0f / (b)))
+#else
+#define MADD(a, b, c) ((a) * (b) + (c))
+#define DIVF(a, b) ((a) / (b))
+#endif
+int orc_is_fast_envelope(void) {
+#ifdef ORC_FAST_ENVELOPE
+  return 1;
+#else
+  return 0;
+#endif
+}
+static inline float dot3(const float* a, const float* b) { return MADD(a[2], b[2], MADD(a[1], b[1], a[0] * b[0])); }
 static inline float len3(const float* a) { return sqrtf(dot3(a, a)); }
 static inline float min2(float a, float b) { return fminf(a, b); }
 static inline float max2(float a, float b) { return fmaxf(a, b); }
@@ -63,11 +83,11 @@ static inline int near_ulp(float a, float b, int k) {
 
 /* mul(M, v), rows left-to-right (A.0) */
 static inline void mul_mv4(const float* m, float x, float y, float z, float w, float* out) {
-  for (int i = 0; i < 4; i++) out[i] = ((M(m, i, 0) * x + M(m, i, 1) * y) + M(m, i, 2) * z) + M(m, i, 3) * w;
+  for (int i = 0; i < 4; i++) out[i] = MADD(M(m, i, 3), w, MADD(M(m, i, 2), z, MADD(M(m, i, 1), y, M(m, i, 0) * x)));
 }
 /* mul(M, float4(p, 1.0)): the last product M[i][3]*1.0 is exact, so it is written as an add */
 static inline void mul_mp(const float* m, const float* p, float* out) {
-  for (int i = 0; i < 4; i++) out[i] = ((M(m, i, 0) * p[0] + M(m, i, 1) * p[1]) + M(m, i, 2) * p[2]) + M(m, i, 3);
+  for (int i = 0; i < 4; i++) out[i] = MADD(M(m, i, 2), p[2], MADD(M(m, i, 1), p[1], M(m, i, 0) * p[0])) + M(m, i, 3);
 }
 
 /* mul(A, B) -- cull_meshlets.slang:40 `mul(camera.projection_view, transform.world)` */
@@ -75,7 +95,7 @@ void orc_mul_mat4(const float* a, const float* b, float* out) {
   float t[16];
   for (int c = 0; c < 4; c++)
     for (int r = 0; r < 4; r++)
-      M(t, r, c) = ((M(a, r, 0) * M(b, 0, c) + M(a, r, 1) * M(b, 1, c)) + M(a, r, 2) * M(b, 2, c)) + M(a, r, 3) * M(b, 3, c);
+      M(t, r, c) = MADD(M(a, r, 3), M(b, 3, c), MADD(M(a, r, 2), M(b, 2, c), MADD(M(a, r, 1), M(b, 1, c), M(a, r, 0) * M(b, 0, c))));
   memcpy(out, t, sizeof t);
 }
 
@@ -105,10 +125,10 @@ void orc_decode_bounds(const orc_meshlet_bounds* b, float* center, float* extent
 /* cull.slang:49-51 normalize_plane: all four components divided by length(xyz) */
 static inline void normalize_plane(const float* p, float* out) {
   float l = len3(p);
-  out[0] = p[0] / l;
-  out[1] = p[1] / l;
-  out[2] = p[2] / l;
-  out[3] = p[3] / l;
+  out[0] = DIVF(p[0], l);
+  out[1] = DIVF(p[1], l);
+  out[2] = DIVF(p[2], l);
+  out[3] = DIVF(p[3], l);
 }
 
 static void frustum_planes(const float* mvp, float planes[6][4]) {
@@ -159,7 +179,7 @@ int orc_test_frustum(const float* mvp, const float* center, const float* extent)
 static int test_cone_m(const float* center, float radius, const float* axis, float cutoff, const float* cam, int* near_out) {
   float d[3] = {center[0] - cam[0], center[1] - cam[1], center[2] - cam[2]};
   float lhs = dot3(d, axis);
-  float rhs = cutoff * len3(d) + radius;
+  float rhs = MADD(cutoff, len3(d), radius);
   if (near_out && near_ulp(lhs, rhs, 4)) *near_out = 1;
   return lhs >= rhs;
 }
@@ -223,10 +243,10 @@ static int project_aabb_m(const float* mvp, float near_clip, const float* c, con
   if (depth < near_clip) return 0;
   float vmin[3], vmax[3];
   for (int j = 0; j < 3; j++) {
-    float lo = P[7][j] / P[7][3];
+    float lo = DIVF(P[7][j], P[7][3]);
     float hi = lo;
     for (int k = 6; k >= 0; k--) {
-      float d = P[k][j] / P[k][3];
+      float d = DIVF(P[k][j], P[k][3]);
       lo = min2(d, lo);
       hi = max2(d, hi);
     }
@@ -316,7 +336,11 @@ static int backface_m(const float* cp, int* near_out) {
   float a = cp[0], b = cp[1], c = cp[3];
   float d = cp[4], e = cp[5], f = cp[7];
   float g = cp[8], h = cp[9], i = cp[11];
+#ifdef ORC_FAST_ENVELOPE
+  float det = fmaf(c, fmaf(d, h, -(e * g)), fmaf(a, fmaf(e, i, -(f * h)), -(b * fmaf(d, i, -(f * g)))));
+#else
   float det = (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+#endif
   if (near_out && near_ulp(det, 0.0001f, 4)) *near_out = 1;
   return det >= 0.0001f;
 }
@@ -446,7 +470,7 @@ static void eval_meshlet(const orc_mesh* meshes, const float* transforms, const 
   orc_normal_matrix(world, nm);
   mul_m3v(nm, axis, na);
   float l = len3(na);
-  float cone_axis[3] = {na[0] / l, na[1] / l, na[2] / l};
+  float cone_axis[3] = {DIVF(na[0], l), DIVF(na[1], l), DIVF(na[2], l)};
   float wc[4];
   mul_mp(world, ev->center, wc);
   float h[3] = {ev->extent[0] * 0.5f, ev->extent[1] * 0.5f, ev->extent[2] * 0.5f};
@@ -667,7 +691,7 @@ static inline uint32_t micro_index(const uint32_t* buf, uint32_t byte_offset) { 
 static uint32_t cull_triangles_impl(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                     const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                     uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats,
-                                    uint32_t max_tris, uint32_t corner_bits) {
+                                    uint32_t max_tris, uint32_t corner_bits, int small_triangle_cull) {
   const uint32_t corner_mask = (1u << corner_bits) - 1u;
   uint32_t n = 0;
   for (uint32_t s = 0; s < count; s++) {
@@ -696,6 +720,7 @@ static uint32_t cull_triangles_impl(const orc_mesh* meshes, const float* transfo
       int nr = 0;
       int passed = cp[2] >= 0.0f && cp[6] >= 0.0f && cp[10] >= 0.0f;
       passed = passed && !backface_m(cp, stats ? &nr : NULL);
+      if (passed && small_triangle_cull) passed = !orc_test_triangle_small(cp, cam->resolution);
       if (stats && nr) stats->triangles_near_threshold++;
       if (passed) {
         uint32_t base = mli_index << corner_bits; /* MESHLET_PRIMITIVE_BITS = 8 in the reference */
@@ -713,13 +738,37 @@ uint32_t orc_cull_triangles(const orc_mesh* meshes, const float* transforms, con
                             const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                             uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats) {
   /* one thread per triangle, 64 threads (defines.slang:9-11); 24+8 bit packing (visbuffer.slang:9-14) */
-  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, stats, 64u, 8u);
+  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, stats, 64u, 8u, 0);
+}
+
+/* The opt-in small-triangle cull (include/oxcull.h, oxc_cull_geometry_context::small_triangle_cull): no reference
+ * behaviour -- the north star names it, the reference's cull_triangles.slang:68-69 stops at clip-z + backface.
+ * clip3x4: 3 rows of xyzw.  Returns 1 when the triangle is to be dropped: all three w > 0 and the screen-space
+ * bounding box at `resolution` covers no pixel centre.  Canonical arithmetic: true divisions, left to right. */
+int orc_test_triangle_small(const float* cp, const float* resolution) {
+  float sx[3], sy[3];
+  for (int k = 0; k < 3; k++) {
+    float w = cp[k * 4 + 3];
+    if (!(w > 0.0f)) return 0;
+    sx[k] = ((cp[k * 4 + 0] / w) * 0.5f + 0.5f) * resolution[0];
+    sy[k] = ((cp[k * 4 + 1] / w) * 0.5f + 0.5f) * resolution[1];
+  }
+  float lox = min2(min2(sx[0], sx[1]), sx[2]), hix = max2(max2(sx[0], sx[1]), sx[2]);
+  float loy = min2(min2(sy[0], sy[1]), sy[2]), hiy = max2(max2(sy[0], sy[1]), sy[2]);
+  return floorf(lox + 0.5f) == floorf(hix + 0.5f) || floorf(loy + 0.5f) == floorf(hiy + 0.5f);
+}
+
+uint32_t orc_cull_triangles_flags(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                  const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                  uint32_t count, const orc_cull_camera* cam, uint32_t* out, int wide, int small_triangle_cull) {
+  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, NULL, wide ? 128u : 64u,
+                             wide ? 9u : 8u, small_triangle_cull);
 }
 
 uint32_t orc_cull_triangles_wide(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                  const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                  uint32_t count, const orc_cull_camera* cam, uint32_t* out) {
-  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, NULL, 128u, 9u);
+  return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, NULL, 128u, 9u, 0);
 }
 
 static void* mt_triangles(void* p) {

@@ -211,6 +211,16 @@ uint32_t orc_cull_triangles_wide(const orc_mesh* meshes, const float* transforms
                                  const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                  uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out);
 
+/* The opt-in small-triangle cull (include/oxcull.h: oxc_cull_geometry_context::small_triangle_cull; no reference
+ * behaviour, the north star names it).  orc_test_triangle_small: 1 = dropped. */
+int orc_test_triangle_small(const float* clip3x4, const float* resolution2);
+uint32_t orc_cull_triangles_flags(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                  const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                  uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out, int wide,
+                                  int small_triangle_cull);
+/* 1 when this library is the -DORC_FAST_ENVELOPE build (liboxcull_oracle_fast.so), see oxcull_oracle.c */
+int orc_is_fast_envelope(void);
+
 uint32_t orc_cull_triangles_mt(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out, uint32_t nthreads);

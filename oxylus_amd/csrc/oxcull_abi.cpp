@@ -23,7 +23,7 @@
 using namespace oxc;
 
 namespace {
-constexpr uint32_t kSlots = 1024;  // counter-slot ring; pointers stay valid for kSlots calls
+constexpr uint32_t kSlots = 8192;  // counter-slot ring (1 MiB): a slot is reused kSlots / 2 calls (or seeds) later -- include/oxcull.h states that lifetime
 constexpr uint32_t kMaxPackedInstances = 1u << 24;  // MESHLET_INSTANCE_ID_BITS, visbuffer.slang:9-10
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -67,7 +67,12 @@ struct oxc_ctx {
   uint32_t slot_cursor = 0;
   uint32_t seed_cursor = 0;
   uint32_t* sink = nullptr;
-  uint32_t seeded_total[1024] = {};  // per counter slot: list length given to oxc_seed_meshlet_instances (0: unknown)
+  std::vector<uint32_t> seeded_total = std::vector<uint32_t>(kSlots, 0u);  // per counter slot: list length given to oxc_seed_meshlet_instances (0: unknown)
+  // The context owns ONE set of scratch buffers, so its calls are ordered: a call on another stream than the previous
+  // call's first waits for that call on the device (order_stream).
+  hipStream_t last_stream = nullptr;
+  bool has_last_stream = false;
+  hipEvent_t order_event = nullptr;
   // profiling (oxc_profile_begin/end)
   bool profiling = false;
   struct Rec {
@@ -90,15 +95,46 @@ oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hi
   return st;
 }
 
+#define OXC_ORDER(ctx, stream)                                            \
+  do {                                                                    \
+    oxc_status _o = order_stream(ctx, static_cast<hipStream_t>(stream)); \
+    if (_o != OXC_OK) return _o;                                          \
+  } while (0)
+
 #define OXC_HIP(ctx, expr)                                        \
   do {                                                            \
     hipError_t _e = (expr);                                       \
     if (_e != hipSuccess) return fail(ctx, OXC_HIP_ERROR, #expr, _e); \
   } while (0)
 
-oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets, uint32_t views = 0, uint32_t lane_index = 0) {
+// Device-side ordering of a context's calls across streams (see oxc_ctx::last_stream).
+oxc_status order_stream(oxc_ctx* ctx, hipStream_t s) {
+  if (ctx->has_last_stream && ctx->last_stream != s) {
+    if (!ctx->order_event) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+    OXC_HIP(ctx, hipEventRecord(ctx->order_event, ctx->last_stream));
+    OXC_HIP(ctx, hipStreamWaitEvent(s, ctx->order_event, 0));
+  }
+  ctx->last_stream = s;
+  ctx->has_last_stream = true;
+  return OXC_OK;
+}
+
+bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+
+// Grows the lane's scratch arena when the call needs more than it holds: device sync + free + malloc (documented in
+// include/oxcull.h; oxc_reserve up front avoids it).  Never during stream capture: `s` = the calling stream.
+oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshlets, uint32_t views = 0, uint32_t lane_index = 0, hipStream_t s = nullptr) {
   oxc_ctx::Lane* L = &ctx->lane[lane_index];
   if (mesh_instances <= L->cap_mesh_instances && meshlets <= L->cap_meshlets && views <= L->cap_views && L->arena) return OXC_OK;
+  if (stream_is_capturing(s))
+    return fail(ctx, OXC_INVALID_ARG, "scratch memory must grow but the stream is being captured: call oxc_reserve (or one un-captured call of this size) first");
   const uint32_t Vw = std::max(views, L->cap_views);
   uint32_t M = std::max(std::max(mesh_instances, L->cap_mesh_instances), 1u);
   uint32_t N = std::max(std::max(meshlets, L->cap_meshlets), 1u);
@@ -216,9 +252,10 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
   const bool late = (c->cull_flags & OXC_CULL_LATE_PASS) != 0;
   if (c->use_hiz && do_meshlets) {
     if (!image_ok(c->hiz_attachment)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz without a hiz_attachment");
-    if (occl && N && (!f->meshlet_instance_visibility_mask_buffer.dptr))
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing");
+    if (occl && N && (!f->meshlet_instance_visibility_mask_buffer.dptr || f->meshlet_instance_visibility_mask_buffer.bytes < (uint64_t)cdiv(N, 32u) * 4u))
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing or < ceil(N/32)*4 bytes");
   }
+  if (c->small_triangle_cull > 1u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: small_triangle_cull must be 0 or 1");
   const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
   if (c->use_hpb && do_meshlets) {
     if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
@@ -285,6 +322,7 @@ void oxc_destroy(oxc_ctx* ctx) {
   if (ctx->raster_scratch) (void)hipFree(ctx->raster_scratch);
   if (ctx->comm) (void)oxc_comm_destroy(ctx);
   if (ctx->slots) (void)hipFree(ctx->slots);
+  if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
   delete ctx;
 }
 
@@ -293,7 +331,7 @@ const char* oxc_last_error(const oxc_ctx* ctx) { return ctx ? ctx->last_error.c_
 oxc_status oxc_reserve(oxc_ctx* ctx, uint32_t max_mesh_instances, uint32_t max_meshlet_instances) {
   if (!ctx) return OXC_INVALID_ARG;
   OXC_HIP(ctx, hipSetDevice(ctx->device));
-  return ensure_capacity(ctx, max_mesh_instances, max_meshlet_instances);
+  return ensure_capacity(ctx, max_mesh_instances, max_meshlet_instances);  // (synchronises the device when it has to grow)
 }
 
 oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* c, void* hip_stream) {
@@ -320,6 +358,7 @@ oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* c, vo
   if (!tiled && (uint64_t)a.w * a.h > 4096) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: extent must be a multiple of 64 or <= 4096 texels");
   if (tiled && (h.level_offset[0] & 15u)) return fail(ctx, OXC_INVALID_ARG, "generate_hiz: mip 0 must be 16-byte aligned");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   {
     KernelTimer t(ctx, OXC_K_HIZ, static_cast<hipStream_t>(hip_stream));
     launch_hiz(a, static_cast<hipStream_t>(hip_stream));
@@ -332,6 +371,7 @@ oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c
   if (!ctx) return OXC_INVALID_ARG;
   if (!c || c->struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "seed: bad context struct");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   uint32_t* slot = next_seed_slot(ctx);
   ctx->seeded_total[(slot - ctx->slots) / SLOT_U32S] = total;
   launch_seed_slot(slot, total, static_cast<hipStream_t>(hip_stream));
@@ -351,9 +391,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   const uint32_t M = ci.M, N = ci.N, views = ci.views;
   const bool do_meshes = ci.do_meshes, do_meshlets = ci.do_meshlets, do_tris = ci.do_tris, occl = ci.occl, late = ci.late;
   OXC_HIP(ctx, hipSetDevice(ctx->device));
-  oxc_status st = ensure_capacity(ctx, M, N, views);
-  if (st != OXC_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  oxc_status st = ensure_capacity(ctx, M, N, views, 0, s);
+  if (st != OXC_OK) return st;
+  OXC_ORDER(ctx, hip_stream);
 
   uint32_t* slot = next_slot(ctx);
   uint32_t* vis;
@@ -412,10 +453,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   if (do_meshes) {
     {
       KernelTimer t(ctx, OXC_K_MESHES_SCAN, s);
-      launch_scan_mesh_counts(ctx->lane[0].mesh_counts, ctx->lane[0].mesh_offsets, M, vis, meshlets_cmd, s);
+      launch_scan_mesh_counts(ctx->lane[0].mesh_counts, ctx->lane[0].mesh_offsets, M, N, vis, meshlets_cmd, s);
     }
     KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
-    launch_expand(ctx->lane[0].mesh_counts, ctx->lane[0].mesh_offsets, M, f->meshlet_instances_buffer.dptr, std::max(std::min(cdiv(M, 4), max_grid), 1u), s);
+    launch_expand(ctx->lane[0].mesh_counts, ctx->lane[0].mesh_offsets, M, N, f->meshlet_instances_buffer.dptr, std::max(std::min(cdiv(M, 4), max_grid), 1u), s);
   }
 
   // --- meshlet stage: CullGeometry.cpp:129-335
@@ -433,6 +474,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ha.dirty = static_cast<const uint32_t*>(c->vsm_clipmap_dirty_flags_buffer.dptr);
     ha.clipmap_count = views;
     ha.mesh_instance_count = M;
+    ha.n_cap = N;
     const oxc_image_array_u8& h = c->hpb_attachment;
     ha.hpb_data = static_cast<const uint8_t*>(h.dptr);
     ha.hpb_w = h.width;
@@ -447,6 +489,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     MeshletEmitArgs ea;
     ea.n_host = 0;
+    ea.n_cap = N;
     ea.count_meshlets = kMeshletChunk;  // the HPB test kernel publishes one count per 1024-meshlet block
     ea.bits = ctx->lane[0].bits;
     ea.chunk_counts = ctx->lane[0].m_chunk_counts;
@@ -460,6 +503,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     MeshletTestArgs ta;
     std::memset(&ta, 0, sizeof ta);
     ta.n_host = n_host;
+    ta.n_cap = N;
+    ta.mask_bits = (uint32_t)std::min<uint64_t>(f->meshlet_instance_visibility_mask_buffer.bytes / 4u * 32u, 0xFFFFFFFEull);
     ta.cache = ctx->lane[0].cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ta.vis = vis;
@@ -493,11 +538,12 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
     {
       {
-        KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
+        KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
         launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, s);
       }
       MeshletEmitArgs ea;
       ea.n_host = n_host;
+      ea.n_cap = N;
       ea.count_meshlets = c->use_hiz ? 64u * kHizGroupsPerWave : 64u * kPlainGroups;  // one count per wave step: 64 * groups per wave
       ea.bits = ctx->lane[0].bits;
       ea.chunk_counts = ctx->lane[0].m_chunk_counts;
@@ -505,7 +551,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ea.vis = vis;
       ea.tri_cmd = tri_cmd;
       ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
-      KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
+      KernelTimer t(ctx, late ? OXC_K_MESHLETS_EMIT_LATE : OXC_K_MESHLETS_EMIT, s);
       launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
     }
   }
@@ -521,9 +567,11 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.tri_masks = ctx->lane[0].tri_masks;
     tt.chunk_counts = ctx->lane[0].t_chunk_counts;
     tt.supers = ctx->lane[0].t_supers;
+    tt.resolution[0] = c->cull_camera.resolution[0];
+    tt.resolution[1] = c->cull_camera.resolution[1];
     {
-      KernelTimer t(ctx, OXC_K_TRIANGLES_TEST, s);
-      launch_tris_test(tt, late, c->wide_triangle_index != 0, std::min(t_chunks, max_grid), s);
+      KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, s);
+      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, max_grid), s);
     }
     TriEmitArgs te;
     te.tri_masks = ctx->lane[0].tri_masks;
@@ -534,7 +582,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     te.supers = ctx->lane[0].t_supers;
     te.draw_cmd = draw_cmd;
     te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
-    KernelTimer t(ctx, OXC_K_TRIANGLES_EMIT, s);
+    KernelTimer t(ctx, late ? OXC_K_TRIANGLES_EMIT_LATE : OXC_K_TRIANGLES_EMIT, s);
     launch_tris_emit(te, late, c->wide_triangle_index != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
   }
   OXC_HIP(ctx, hipGetLastError());
@@ -552,7 +600,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     oxc_status vst = check_call(ctx, &frames[e], &contexts[e], ci[e]);
     if (vst != OXC_OK) return vst;
     const oxc_cull_geometry_context& c = contexts[e];
-    fusable = !c.use_hiz && !c.use_hpb && !c.wide_triangle_index && !ci[e].late && ci[e].stages == ci[0].stages && ci[e].do_meshes == ci[0].do_meshes &&
+    fusable = !c.use_hiz && !c.use_hpb && !c.wide_triangle_index && !c.small_triangle_cull && !ci[e].late && ci[e].stages == ci[0].stages && ci[e].do_meshes == ci[0].do_meshes &&
               (c.init_cull_meshes != 0) == (contexts[0].init_cull_meshes != 0);
   }
   if (!fusable) {
@@ -564,10 +612,13 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   }
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   for (uint32_t e = 0; e < count; e++) {
-    oxc_status st = ensure_capacity(ctx, ci[e].M, ci[e].N, 0, e);
+    oxc_status st = ensure_capacity(ctx, ci[e].M, ci[e].N, 0, e, static_cast<hipStream_t>(hip_stream));
     if (st != OXC_OK) return st;
   }
+  OXC_ORDER(ctx, hip_stream);
   if (!ctx->batch_dev) {
+    if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry_batch: the first batched call allocates its argument block; make one un-captured call first");
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->batch_dev), sizeof(BatchElem) * kMaxBatch);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(batch argument block)", e);
     OXC_HIP(ctx, hipMemset(ctx->batch_dev, 0, sizeof(BatchElem) * kMaxBatch));  // fields no plain-pipeline block uses stay 0
@@ -630,6 +681,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     k.do_cull_meshes = do_meshes ? 1u : 0u;
     k.init_vis = c->init_cull_meshes ? 1u : 0u;
     k.n_host = n_host;
+    k.n_cap = N;
     k.count_meshlets = 64u * kPlainGroups;
     k.cam = c->cull_camera;
     g_prep = std::max(g_prep, std::min(cdiv(std::max(std::max(M * 8u, k.n_supers_tris), 1u), 256), max_grid));
@@ -703,6 +755,7 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   if (!ctx) return OXC_INVALID_ARG;
   if (!c || !out) return fail(ctx, OXC_INVALID_ARG, "read_counters: null argument");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   uint32_t vis[3] = {0, 0, 0}, mc[3] = {0, 0, 0}, tc[3] = {0, 0, 0}, dc[5] = {0, 0, 0, 0, 0};
   if (c->visibility_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(vis, c->visibility_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
@@ -797,9 +850,12 @@ oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc*
   if (d->quantized_positions.dptr && (!d->positions.dptr || d->quantized_positions.bytes < (uint64_t)d->vertex_count * 8u))
     return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: quantized_positions smaller than vertex_count u16x4");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   // scratch: [boxes: 24 B per meshlet][fold partials: 256 x 12 words][normals: 768 B per meshlet of one chunk][counts]
   const uint32_t want = std::max(d->meshlet_count, 1u);
   if (want > ctx->bounds_scratch_cap) {
+    if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
+      return fail(ctx, OXC_INVALID_ARG, "build_meshlet_bounds: scratch must grow but the stream is being captured; make one un-captured call of this size first");
     OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old scratch
     if (ctx->bounds_scratch) OXC_HIP(ctx, hipFree(ctx->bounds_scratch));
     ctx->bounds_scratch = nullptr;
@@ -835,6 +891,7 @@ oxc_status oxc_quantize_vertex_streams(oxc_ctx* ctx, const oxc_vertex_streams_de
   for (const Stream& st : streams)
     if (st.in->dptr && n && (!st.out->dptr || st.in->bytes < n * st.in_stride || st.out->bytes < n * st.out_stride)) return fail(ctx, OXC_INVALID_ARG, st.what);
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   launch_quantize_vertex_streams(static_cast<const float*>(d->positions.dptr), static_cast<const float*>(d->normals.dptr),
                                  static_cast<const float*>(d->texcoords.dptr), d->vertex_count, d->quantized_positions.dptr, d->quantized_normals.dptr,
                                  d->quantized_texcoords.dptr, ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
@@ -915,6 +972,7 @@ oxc_status oxc_generate_hpb(oxc_ctx* ctx, oxc_buffer page_table, const oxc_image
   for (uint32_t k = 0; k < h->levels; k++)
     if (h->level_offset[k] > 0xFFFFFFFFull) return fail(ctx, OXC_INVALID_ARG, "generate_hpb: level offsets must fit 32 bits");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   launch_generate_hpb(static_cast<const uint32_t*>(page_table.dptr), static_cast<uint8_t*>(h->dptr), h->width, h->height, h->layers, h->levels, h->level_offset,
                       static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
@@ -936,6 +994,7 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   const oxc_image& h = c->hiz_attachment;
   if (needs_hiz && (!h.dptr || h.levels == 0 || h.levels > 13 || h.width == 0 || h.height == 0)) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: TestOcclusion / LatePass need hiz_attachment");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   uint32_t* slot = next_slot(ctx);
   TerrainArgs a;
   std::memset(&a, 0, sizeof a);
@@ -984,7 +1043,10 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   if (dep.dptr && (dep.width != d->width || dep.height != d->height)) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: depth_attachment extent differs from the draw extent");
   if (d->visbuffer_attachment.dptr && d->visbuffer_attachment.bytes < n * 4u) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: visbuffer_attachment smaller than width*height u32");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   if (!ctx->raster_scratch) {
+    if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
+      return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: the first call allocates its scratch; make one un-captured call first");
     hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + 256);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster scratch)", e);
   }

@@ -308,7 +308,8 @@ OXC_DEV void scan_body(const ScanArgs& a) {
     }
   }
   if (threadIdx.x == 0) {
-    uint32_t total = s_carry;
+    // (a total beyond what the caller's buffers hold is cut off there: expand_body writes no record past `cap`)
+    uint32_t total = min(s_carry, a.cap);
     vis[0] = total;                       // visibility[0].total_visible_meshlet_instances
     meshlets_cmd[0] = (total + 63u) / 64u;  // atomic_max of ceil(new_total/64), cull_meshes.slang:68-70
   }
@@ -324,6 +325,8 @@ OXC_DEV void expand_body(const ExpandArgs& a) {
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t mi = wave; mi < n; mi += nwaves) {
     uint32_t cnt = counts[mi], off = offsets[mi];
+    if (off >= a.cap) continue;
+    cnt = min(cnt, a.cap - off);
     for (uint32_t k = lane; k < cnt; k += 64) {
       GpuMeshletInstance r;
       r.mesh_instance_index = mi;
@@ -343,6 +346,7 @@ OXC_DEV void expand_body(const ExpandArgs& a) {
 // Lanes whose (idx - lane) agree form a "run": lane l owns global bit (d + l), so a run is a
 // 64-bit window at bit offset d and touches at most three mask words.  Whole words are stored,
 // partial words use atomic and/or (disjoint bits from other waves).  cull_meshlets_hiz.slang:81-87.
+constexpr uint32_t kMaskNone = 0xFFFFFFFFu;  // "this lane has no bit in the caller's mask buffer"
 OXC_DEV void update_visibility_mask(uint32_t* __restrict__ mask, uint32_t idx, bool visible, bool active, int lane) {
   uint64_t rem = __ballot(active);
   const int32_t d_l = (int32_t)(idx - (uint32_t)lane);
@@ -400,7 +404,7 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
   constexpr uint32_t kWaves = kPlainBlockWaves;
   constexpr uint32_t kStep = kWaves * G * 64;  // meshlets per block iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
+  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kStep - 1) / kStep;
   const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
@@ -544,7 +548,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   __shared__ float s_hiz_top[kHizLdsTexels];
   __shared__ uint4 s_strip[OCCL_OR_LATE ? kWaves : 1][G * 64];  // occlusion candidates of one round, per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
+  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
   if (threadIdx.x < 13) {
@@ -607,9 +611,14 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
         bnd[j] = OXC_LOAD_BND(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
         mword[j] = 0xFFFFFFFFu;
         if (OCCL) {  // cull_meshlets_hiz.slang:45-51 (unconditional load: lanes of other instances re-read this instance's first word)
-          const uint32_t mi_bit = vis_offset + (mine[j] ? rec[j].y : 0u);
-          mask_idx[j] = mine[j] ? mi_bit : mask_idx[j];
+          // (a mask index beyond the caller's buffer -- inconsistent visibility offsets -- reads as "not visible" and is
+          // never written: kMaskNone)
+          uint32_t mi_bit = vis_offset + (mine[j] ? rec[j].y : 0u);
+          const bool in_mask = mi_bit < a.mask_bits;
+          mi_bit = in_mask ? mi_bit : 0u;
+          mask_idx[j] = mine[j] ? (in_mask ? mi_bit : kMaskNone) : mask_idx[j];
           mword[j] = load_global_u32(reinterpret_cast<uint64_t>(a.mask), mi_bit >> 5) >> (mi_bit & 31u);
+          mword[j] = in_mask ? mword[j] : 0u;
         }
       }
       // ---- phase 1: bounds decode + frustum
@@ -732,7 +741,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
 #ifndef OXC_ABL_NOMASKUPDATE
-      if (OCCL) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N, lane);
+      if (OCCL) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
 #endif
       const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
       const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
@@ -759,7 +768,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_level_off[13];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.vis[0];
+  const uint32_t N = min(a.vis[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
   if (threadIdx.x < 13) s_level_off[threadIdx.x] = a.hpb_level_off[threadIdx.x];
@@ -873,7 +882,7 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
   __shared__ uint32_t s_off[64];
   __shared__ uint64_t s_bits[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : gptr(a.vis)[0];
+  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nspans = (N + kMeshletSpan - 1) / kMeshletSpan;
   const uint32_t out_first = (HIZ && LATE) ? gptr(a.vis)[1] : 0u;  // late list follows the early one (:73)
@@ -933,7 +942,10 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 // (measured on config 3: 140 -> 121 us per launch on the same box, whole frame +5 %)
 #define OXC_TRI_LOAD_U32 load_stream_u32
 #define OXC_TRI_LOAD_U2 load_stream_u2
-template <bool LATE, bool WIDE>
+// SMALL (extension, include/oxcull.h small_triangle_cull): after the two reference tests, drop a triangle whose
+// screen-space bounding box covers no pixel centre.  The screen position is computed once per vertex (lane = vertex,
+// two IEEE divisions) and fetched per corner like the clip coordinates; with SMALL off none of it is compiled in.
+template <bool LATE, bool WIDE, bool SMALL>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
@@ -1033,6 +1045,13 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       const f2 czw = ((m_zw[0] * splat(px) + m_zw[1] * splat(py)) + m_zw[2] * splat(pz)) + m_zw[3];
       const float clx = cxy.x, cly = cxy.y, clw = czw.y;
       const uint64_t zok = __builtin_amdgcn_ballot_w64((uint32_t)lane < vertex_count && czw.x >= 0.0f);
+      float scx = 0.0f, scy = 0.0f;
+      uint64_t wok = 0;
+      if constexpr (SMALL) {
+        scx = ((clx / clw) * 0.5f + 0.5f) * a.resolution[0];
+        scy = ((cly / clw) * 0.5f + 0.5f) * a.resolution[1];
+        wok = __builtin_amdgcn_ballot_w64((uint32_t)lane < vertex_count && clw > 0.0f);
+      }
       // triangle phase: lane = triangle (two passes of 64 when WIDE)
 #pragma unroll
       for (int h = 0; h < H; h++) {
@@ -1046,7 +1065,16 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         const bool z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
         // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
         const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
-        const bool passed = t < tri_count && z_all && !(det >= 0.0001f);
+        bool passed = t < tri_count && z_all && !(det >= 0.0001f);
+        if constexpr (SMALL) {
+          const float x0 = bperm_f(l0, scx), x1 = bperm_f(l1, scx), x2 = bperm_f(l2, scx);
+          const float y0 = bperm_f(l0, scy), y1 = bperm_f(l1, scy), y2 = bperm_f(l2, scy);
+          const bool w_all = (((wok >> (l0 & 63)) & (wok >> (l1 & 63)) & (wok >> (l2 & 63))) & 1ull) != 0ull;
+          const float lox = fminf(fminf(x0, x1), x2), hix = fmaxf(fmaxf(x0, x1), x2);
+          const float loy = fminf(fminf(y0, y1), y2), hiy = fmaxf(fmaxf(y0, y1), y2);
+          const bool small = floorf(lox + 0.5f) == floorf(hix + 0.5f) || floorf(loy + 0.5f) == floorf(hiy + 0.5f);
+          passed = passed && !(w_all && small);
+        }
         const uint64_t mask = valid ? __builtin_amdgcn_ballot_w64(passed) : 0ull;
         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mlo[h]) : "s"(readfirst_u((uint32_t)mask)), "n"(j));
         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mhi[h]) : "s"(readfirst_u((uint32_t)(mask >> 32))), "n"(j));
@@ -1355,9 +1383,9 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
 #ifndef OXC_TRI_WAVES
 #define OXC_TRI_WAVES 8
 #endif
-template <bool LATE, bool WIDE>
-__global__ __launch_bounds__(256, WIDE ? 6 : OXC_TRI_WAVES) void k_cull_triangles_test(TriTestArgs a) {
-  tris_test_body<LATE, WIDE>(a);
+template <bool LATE, bool WIDE, bool SMALL>
+__global__ __launch_bounds__(256, (WIDE || SMALL) ? 6 : OXC_TRI_WAVES) void k_cull_triangles_test(TriTestArgs a) {
+  tris_test_body<LATE, WIDE, SMALL>(a);
 }
 template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
@@ -1411,7 +1439,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit_batch(const BatchEle
   meshlets_emit_body<false, false>(dev[blockIdx.y].emit);
 }
 __global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const BatchElem* __restrict__ dev) {
-  tris_test_body<false, false>(dev[blockIdx.y].ttest);
+  tris_test_body<false, false, false>(dev[blockIdx.y].ttest);
 }
 __global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchElem* __restrict__ dev) {
   tris_emit_body<false, false>(dev[blockIdx.y].temit);
@@ -1424,12 +1452,12 @@ void launch_prepare(const PrepareArgs& a, uint32_t grid, uint32_t views, hipStre
   hipLaunchKernelGGL(k_prepare_instances, dim3(grid, 1 + views), dim3(256), 0, s, a);
 }
 
-void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s) {
-  ScanArgs a{counts, offsets, n, vis, cmd};
+void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* vis, uint32_t* cmd, hipStream_t s) {
+  ScanArgs a{counts, offsets, n, cap, vis, cmd};
   hipLaunchKernelGGL(k_scan_mesh_counts, dim3(1), dim3(1024), 0, s, a);
 }
-void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, void* out, uint32_t grid, hipStream_t s) {
-  ExpandArgs a{counts, offsets, n, reinterpret_cast<GpuMeshletInstance*>(out)};
+void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, void* out, uint32_t grid, hipStream_t s) {
+  ExpandArgs a{counts, offsets, n, cap, reinterpret_cast<GpuMeshletInstance*>(out)};
   hipLaunchKernelGGL(k_expand_meshlet_instances, dim3(grid), dim3(256), 0, s, a);
 }
 void launch_prepare_batch(const BatchBlob& blob, BatchElem* dev, uint32_t grid, hipStream_t s) {
@@ -1496,16 +1524,19 @@ void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_
   else
     hipLaunchKernelGGL((k_cull_meshlets_emit<true, false>), g, b, 0, s, a);
 }
-void launch_tris_test(const TriTestArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {
+void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
-  if (late && wide)
-    hipLaunchKernelGGL((k_cull_triangles_test<true, true>), g, b, 0, s, a);
-  else if (late)
-    hipLaunchKernelGGL((k_cull_triangles_test<true, false>), g, b, 0, s, a);
-  else if (wide)
-    hipLaunchKernelGGL((k_cull_triangles_test<false, true>), g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL((k_cull_triangles_test<false, false>), g, b, 0, s, a);
+  const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
+  switch (v) {
+    case 0: hipLaunchKernelGGL((k_cull_triangles_test<false, false, false>), g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((k_cull_triangles_test<false, false, true>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_cull_triangles_test<false, true, false>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_cull_triangles_test<false, true, true>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_cull_triangles_test<true, false, false>), g, b, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_cull_triangles_test<true, false, true>), g, b, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((k_cull_triangles_test<true, true, false>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cull_triangles_test<true, true, true>), g, b, 0, s, a); break;
+  }
 }
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);

@@ -46,6 +46,7 @@ struct HpbTestArgs {
   const uint32_t* dirty;
   uint32_t clipmap_count;
   uint32_t mesh_instance_count;
+  uint32_t n_cap;  // frame.max_meshlet_instance_count: the device-side list length is clamped to what the buffers hold
   const uint8_t* hpb_data;
   uint32_t hpb_w, hpb_h, hpb_layers, hpb_levels;
   uint32_t hpb_level_off[13];
@@ -54,6 +55,8 @@ struct HpbTestArgs {
 
 struct MeshletTestArgs {
   uint32_t n_host;  // != 0: the list length is known on the host (seeded lists); skips the dependent load of vis[0]
+  uint32_t n_cap;   // frame.max_meshlet_instance_count: vis[0] is clamped to what the scratch and the output lists hold
+  uint32_t mask_bits;  // bits the visibility mask buffer holds; mask indices beyond it read as "not visible" and are never written
   const InstCache* cache;
   const GpuMeshletInstance* meshlet_instances;
   const uint32_t* vis;
@@ -72,6 +75,7 @@ struct MeshletTestArgs {
 
 struct MeshletEmitArgs {
   uint32_t n_host;
+  uint32_t n_cap;
   uint32_t count_meshlets;  // meshlets per published count (64 * groups-per-wave of the test kernel that ran)
   const uint64_t* bits;
   const uint32_t* chunk_counts;
@@ -90,6 +94,7 @@ struct TriTestArgs {
   uint64_t* tri_masks;
   uint32_t* chunk_counts;
   uint32_t* supers;
+  float resolution[2];  // cull_camera.resolution: read by the small-triangle variants only
 };
 
 struct TriEmitArgs {
@@ -107,6 +112,7 @@ struct ScanArgs {
   const uint32_t* counts;
   uint32_t* offsets;
   uint32_t n;
+  uint32_t cap;  // frame.max_meshlet_instance_count: the expansion stops there
   uint32_t* vis;
   uint32_t* meshlets_cmd;
 };
@@ -115,6 +121,7 @@ struct ExpandArgs {
   const uint32_t* counts;
   const uint32_t* offsets;
   uint32_t n;
+  uint32_t cap;
   GpuMeshletInstance* out;
 };
 
@@ -164,6 +171,7 @@ struct BatchCore {
   uint32_t do_cull_meshes;
   uint32_t init_vis;
   uint32_t n_host;
+  uint32_t n_cap;
   uint32_t count_meshlets;  // meshlets per published count of the test kernel (64 * groups per wave)
   oxc_cull_camera cam;
 };
@@ -209,10 +217,12 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   uint32_t* tri_cmd = c.slot + SLOT_TRI_CMD;
   uint32_t* draw_cmd = c.slot + SLOT_DRAW_CMD;
   prepare_args_of(c, e.prep);
-  e.scan = ScanArgs{c.mesh_counts, c.mesh_offsets, c.mesh_instance_count, c.vis, c.meshlets_cmd};
-  e.expand = ExpandArgs{c.mesh_counts, c.mesh_offsets, c.mesh_instance_count, c.meshlet_instances};
+  e.scan = ScanArgs{c.mesh_counts, c.mesh_offsets, c.mesh_instance_count, c.n_cap, c.vis, c.meshlets_cmd};
+  e.expand = ExpandArgs{c.mesh_counts, c.mesh_offsets, c.mesh_instance_count, c.n_cap, c.meshlet_instances};
   MeshletTestArgs& ta = e.test;
   ta.n_host = c.n_host;
+  ta.n_cap = c.n_cap;
+  ta.mask_bits = 0;
   ta.cache = c.cache;
   ta.meshlet_instances = c.meshlet_instances;
   ta.vis = c.vis;
@@ -228,6 +238,7 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   ta.cam_pos[2] = c.cam.position[2];
   MeshletEmitArgs& ea = e.emit;
   ea.n_host = c.n_host;
+  ea.n_cap = c.n_cap;
   ea.count_meshlets = c.count_meshlets;
   ea.bits = c.bits;
   ea.chunk_counts = c.m_chunk_counts;
@@ -244,6 +255,8 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   tt.tri_masks = c.tri_masks;
   tt.chunk_counts = c.t_chunk_counts;
   tt.supers = c.t_supers;
+  tt.resolution[0] = c.cam.resolution[0];
+  tt.resolution[1] = c.cam.resolution[1];
   TriEmitArgs& te = e.temit;
   te.tri_masks = c.tri_masks;
   te.visible = c.visible_out;
@@ -265,11 +278,11 @@ struct HizArgs {
 
 void launch_prepare(const PrepareArgs& a, uint32_t grid, uint32_t views, hipStream_t s);
 void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s);
-void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t* vis, uint32_t* cmd, hipStream_t s);
-void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, void* out, uint32_t grid, hipStream_t s);
+void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* vis, uint32_t* cmd, hipStream_t s);
+void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, void* out, uint32_t grid, hipStream_t s);
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, hipStream_t s);
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
-void launch_tris_test(const TriTestArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
+void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
 void launch_hiz(const HizArgs& a, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch

@@ -74,6 +74,7 @@ struct CullGeometryContext {
   Buffer cull_triangles_cmd_buffer = {};
   // extension: wide packed index for meshlets of up to 128 triangles
   bool wide_triangle_index = false;
+  bool small_triangle_cull = false;  // extension named by the north star; default OFF = reference behaviour
 };
 
 struct MainGeometryContext {
@@ -133,6 +134,7 @@ public:
     c.vsm_clipmap_dirty_flags_buffer = context.vsm_clipmap_dirty_flags_buffer;
     c.vsm_clipmap_count = context.vsm_clipmap_count;
     c.wide_triangle_index = context.wide_triangle_index;
+    c.small_triangle_cull = context.small_triangle_cull;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));

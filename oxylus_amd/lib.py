@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liboxcull.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 OXC_OK, OXC_INVALID_ARG, OXC_HIP_ERROR, OXC_RCCL_ERROR, OXC_OUT_OF_MEMORY = range(5)
+ABI_VERSION = 2  # OXC_ABI_VERSION of include/oxcull.h
 
 CULL_TEST_FRUSTUM = 1
 CULL_SELECT_LOD = 2
@@ -97,6 +98,8 @@ class CullGeometryContext(C.Structure):
         ("vsm_clipmap_dirty_flags_buffer", Buffer),
         ("vsm_clipmap_count", C.c_uint32),
         ("wide_triangle_index", C.c_uint32),
+        ("small_triangle_cull", C.c_uint32),
+        ("_reserved0", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),
@@ -266,19 +269,24 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path: str = None) -> C.CDLL:
+    """liboxcull.so with prototypes.  `path`: another build of the same library (tools/kbench.py compares kernel
+    variants built with different -D flags in one process)."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the cull path)"
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
+    lib.oxc_abi_version.restype = C.c_uint32
+    if lib.oxc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.oxc_abi_version()} != {ABI_VERSION} (stale build: run __graft_entry__.build())")
     vp = C.c_void_p
     lib.oxc_abi_version.restype = C.c_uint32
     lib.oxc_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -313,16 +321,19 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
             getattr(lib, name).restype = C.c_int
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("total_ms", C.c_double * 8), ("launches", C.c_uint32 * 8), ("empty_pair_ms", C.c_double)]
+    _fields_ = [("total_ms", C.c_double * 16), ("launches", C.c_uint32 * 16), ("empty_pair_ms", C.c_double)]
 
 
+# OXC_K_* (include/oxcull.h); the *_late entries are the LatePass instantiations, timed apart
 KERNEL_NAMES = ["prepare_instances", "cull_meshes_scan", "cull_meshes_expand", "cull_meshlets_test", "cull_meshlets_emit",
-                "cull_triangles_test", "cull_triangles_emit", "hiz"]
+                "cull_triangles_test", "cull_triangles_emit", "hiz", "cull_meshlets_test_late", "cull_meshlets_emit_late",
+                "cull_triangles_test_late", "cull_triangles_emit_late", "cull_meshlets_occlusion", "cull_meshlets_occlusion_late",
+                "_14", "_15"]
 
 
 class OxcError(RuntimeError):

@@ -151,6 +151,7 @@ class CullGeometryContext:
     vsm_clipmap_dirty_flags_buffer: Optional[torch.Tensor] = None  # int32 [V]
     vsm_clipmap_count: int = 0
     wide_triangle_index: bool = False  # extension: (id << 9) | (3t+k), meshlets of up to 128 triangles
+    small_triangle_cull: bool = False  # extension (north star): also drop triangles whose screen bbox covers no pixel centre
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -169,6 +170,7 @@ class CullGeometryContext:
         c.vsm_clipmap_dirty_flags_buffer = _buf(self.vsm_clipmap_dirty_flags_buffer)
         c.vsm_clipmap_count = self.vsm_clipmap_count
         c.wide_triangle_index = int(self.wide_triangle_index)
+        c.small_triangle_cull = int(self.small_triangle_cull)
         return c
 
 
@@ -182,8 +184,8 @@ class MainGeometryContext:
 class RendererInstance:
     """Owns one oxc_ctx on one device."""
 
-    def __init__(self, device_index: int = 0):
-        self._lib = L.load()
+    def __init__(self, device_index: int = 0, lib_path: str = None):
+        self._lib = L.load(lib_path)
         if not torch.cuda.is_available():
             raise RuntimeError("oxylus_amd.RendererInstance needs a GPU: the cull path has no CPU fallback")
         self.device_index = device_index

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(lib, name), f"liboxcull.so does not export {name}"
-    assert lib.oxc_abi_version() == 1
+    assert lib.oxc_abi_version() == L.ABI_VERSION == 2
 
 
 def test_struct_sizes_match_reference_layouts():
@@ -32,6 +32,23 @@ def test_struct_sizes_match_reference_layouts():
     assert ctypes.sizeof(L.Buffer) == 16
     assert ctypes.sizeof(L.Image) == 24 + 13 * 8
     assert ctypes.sizeof(L.Counters) == 24
+    assert ctypes.sizeof(L.KernelTimes) == 16 * 8 + 16 * 4 + 8
+
+
+def test_context_struct_matches_the_header(tmp_path):
+    """sizeof / offsetof of the ctypes mirror == what a C compiler makes of include/oxcull.h."""
+    import subprocess
+
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "oxcull.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(oxc_cull_geometry_context), '
+                   'offsetof(oxc_cull_geometry_context, small_triangle_cull), offsetof(oxc_cull_geometry_context, visibility_buffer), sizeof(oxc_kernel_times)); return 0; }\n')
+    exe = str(tmp_path / "sz")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    size, off_small, off_vis, kt = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert size == ctypes.sizeof(L.CullGeometryContext)
+    assert off_small == L.CullGeometryContext.small_triangle_cull.offset
+    assert off_vis == L.CullGeometryContext.visibility_buffer.offset
+    assert kt == ctypes.sizeof(L.KernelTimes)
 
 
 def test_product_path_never_imports_the_oracle():
