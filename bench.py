@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- meshlets/s culled on MI355X (BASELINE.json metric), one JSON line on rank 0.
+"""bench.py -- meshlets/s culled on MI355X (BASELINE.json metric); rank 0 prints ONE JSON line.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a torchrun environment: bench.py starts `python -m torch.distributed.run --nproc-per-node N` itself and
+   fails loudly when it cannot; under the driver's own torchrun launch it just joins the world.)
 
-A "step" is one RendererInstance::cull_geometry pass over one batch of synthetic input that is
-already resident in HBM.  Default workload = BASELINE.json configs[1]: 1M meshlets (1000 mesh
-instances x 1000 meshlets), one reversed-Z perspective camera, frustum + cone cull + ordered
-compaction (stages = cull_meshlets only).  The 24 MB working set would sit in the 256 MB Infinity
-Cache, so steps rotate over COPIES independent copies of the scene (>= 1 GB) to stay HBM-bound
-(SURVEY.md 8d).  `--workload config3` times the full pipeline (HiZ build + two-pass occlusion +
-triangle cull) on 10M meshlets instead; it is reported in the same format but is not the
-default line.  `--streams S` (default 3 for config 2) keeps S independent batches in flight: S contexts
-on S HIP streams inside one HIP graph -- a 1M-meshlet batch is launch/dependency-latency bound, so
-consecutive batches are overlapped the way independent views/frames would be; the one-stream figure is
-reported next to it as "single_stream".  `--batch B` (default 4) culls B independent frames per
-oxc_cull_geometry_batch call: every stage is one launch with grid.y = B (a HIP graph sustains only ~3 us
-per kernel node on this platform, tools/launch_rate.py, so launches per frame are what limits a
-1M-meshlet batch).  A step is still one frame (one 1M-meshlet batch of synthetic input).
+Default workload = BASELINE.json configs[2], the full north-star path on one GPU: 10M meshlet instances (10 000 mesh
+instances x 1000 meshlets, 64 vertices / 64 triangles each, unique geometry ~10 GB) + a 4096^2 HiZ (13 mips) built from a
+synthetic 8192^2 depth image.  One FRAME is the reference's sequence (RendererInstance.cpp:842-884 for a given depth and a
+given prior-visibility mask):
+    oxc_generate_hiz -> oxc_cull_geometry(TestAll)  [early: cull_meshlets_hiz + cull_triangles + compaction]
+                     -> oxc_cull_geometry(TestAll | LatePass)  [late]
+A frame takes well under a millisecond, so a STEP is `inner_reps` frames (stated in config) -- 20 steps are >= 0.5 s of GPU
+work and `value` is not launch latency.  All inputs are generated in HBM; the ABI takes device pointers (no PCIe in the loop).
 
-Extra objects on the line: "roofline" (dominant kernel: algorithmic bytes / HIP-event kernel
-time vs the 8 TB/s HBM peak) and "cpu_baseline" (the scalar C oracle over the same arrays on
-the host cores; a reported baseline, not the target).
+N > 1 = configs[3]: the meshlet-instance array shards by contiguous range, 12.5M per rank ("100M sharded 8 ways"; weak
+scaling), shard-local ids and outputs.  Rank 0 builds the pyramid and broadcasts it over RCCL/xGMI; the per-rank counters
+{emitted, early, late, index_count} are all-gathered every frame.  The HiZ a frame culls against is the PRIOR frame's, so its
+build + broadcast run one frame ahead on a second stream (double-buffered pyramid) and overlap the cull.
+
+The configs[1] result (1M meshlets, frustum + cone only) rides along as the nested object "configs1" (batched x16 on three
+streams, AND one call per frame on one stream).  `--workload config2` prints it as the main line instead; `--workload
+config1` is the reference's CPU-runnable case (BASELINE configs[0], host cores only); bounds | loop | vsm | config5 live in
+tools/bench_aux.py.
+
+Extra objects: "roofline" (dominant kernel: algorithmic bytes of SURVEY 8d / HIP-event kernel time, averaged over >= 50
+launches, vs the 8 TB/s HBM peak; every kernel in "kernels", the whole frame in "stage_frac") and "cpu_baseline" (the scalar
+C checker, oracle/, running the same sequence over a bounded prefix of the same arrays on the host; a reported baseline,
+not the target).
 """
 import argparse
 import ctypes as C
@@ -36,285 +42,103 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from oxylus_amd import lib as L  # noqa: E402
-from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame, RendererInstance  # noqa: E402
+from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, PreparedFrame, RendererInstance  # noqa: E402
 from oxylus_amd.synth import SceneSpec, make_depth, make_scene  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+K_MESHLETS_PER_MESH = 1000
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9600)
-    ap.add_argument("--warmup", type=int, default=960)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "bounds", "loop", "vsm"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config1", "config5", "bounds", "loop", "vsm"])
+    ap.add_argument("--inner-reps", type=int, default=0, help="frames per step (default: 48 for config3, 9600 for config2)")
     ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses the wide packed index extension (<= 8M meshlets)")
+    ap.add_argument("--small-triangle-cull", action="store_true", help="config3: turn the opt-in small-triangle cull on (default off = reference behaviour)")
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
-    ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 1M / 10M)")
-    ap.add_argument("--copies", type=int, default=0, help="independent scene copies rotated through (default: >= 1.1 GB)")
-    ap.add_argument("--streams", type=int, default=3, help="independent batches in flight: S contexts on S HIP streams (config2 only)")
-    ap.add_argument("--batch", type=int, default=16, help="frames per oxc_cull_geometry_batch call (1 = one call per step; max 16)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a HIP graph even with >= 8 frames per launch (default there: eager launches on real streams, which overlap "
-                         "the small prepare/emit kernels of one call with the test kernel of another; measured 1.94e11 vs 1.73e11)")
+    ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 10M; 12.5M per rank when N > 1; 1M for config2)")
+    ap.add_argument("--copies", type=int, default=0, help="config2: independent scene copies rotated through (default: >= 1.1 GB)")
+    ap.add_argument("--streams", type=int, default=3, help="config2: independent batches in flight (contexts on their own HIP streams)")
+    ap.add_argument("--batch", type=int, default=16, help="config2 / config5: frames (views) per oxc_cull_geometry_batch call (max 16)")
+    ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: build + broadcast the pyramid on the cull stream instead of one frame ahead on a second stream")
     ap.add_argument("--native-comm", action="store_true",
-                    help="multi-GPU: run the two exchanges of the path (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
+                    help="N > 1: run the two exchanges (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
                          "(oxc_exchange_counts / oxc_broadcast_hiz) instead of torch.distributed; the rendezvous stays torch.distributed")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    ap.add_argument("--cpu-prefix", type=int, default=1000, help="config3 cpu_baseline / bit_match sample: the first this-many mesh instances")
+    ap.add_argument("--entities", type=int, default=1000, help="config1: entity count")
     return ap.parse_args()
 
 
-class Step:
-    """One pre-marshalled cull_geometry call (C structs built once; the hot loop only calls into
-    liboxcull.so)."""
+# ------------------------------------------------------------------------------------------------------------------
+# process / world setup
+# ------------------------------------------------------------------------------------------------------------------
+def respawn_under_torchrun(args):
+    """`bench.py --gpus N` outside a torchrun environment: become the launcher."""
+    import socket
+    import subprocess
 
-    def __init__(self, r: RendererInstance, scene, stages, use_hiz=False, hiz=None, with_triangles=False, wide=False):
-        self.scene = scene
-        self.frame = PreparedFrame.create(scene, with_triangles=with_triangles, max_tris=128 if wide else 64)
-        self.cframe = self.frame.c()
-        self.ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL,
-                                       cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=stages, wide_triangle_index=wide)
-        r.prepared_frame = self.frame
-        r.seed_meshlet_instances(self.ctx, scene.n_meshlet_instances)
-        self.cctx = self.ctx.c()
-        self.pf, self.pc = C.byref(self.cframe), C.byref(self.cctx)
-
-
-def bench_bounds(args, r, dev, stream, rank, world, dist):
-    """--workload bounds: the asset-side meshlet bounds producer (oxc_build_meshlet_bounds) over a
-    procedural terrain cut into 8x4-quad patches (64 triangles, 45 vertices per meshlet, vertices not shared
-    between patches).  A step = one call over all meshlets of this GPU."""
-    import math
-
-    P = args.meshlets or 1_000_000
-    steps, warmup = min(args.steps, 50), min(args.warmup, 5)
-    with torch.cuda.stream(stream):
-        side = int(math.ceil(math.sqrt(P)))
-        p = torch.arange(P, device=dev, dtype=torch.int64)
-        pi, pj = (p // side).to(torch.float32), (p % side).to(torch.float32)
-        v = torch.arange(45, device=dev)
-        lu, lv = (v % 9).to(torch.float32), (v // 9).to(torch.float32)
-        x = (pj[:, None] * 8 + lu[None, :]) * 0.05
-        z = (pi[:, None] * 4 + lv[None, :]) * 0.05
-        g = torch.Generator(device=dev).manual_seed(99 + rank)
-        y = 0.6 * torch.sin(1.7 * x) * torch.cos(1.3 * z) + 0.02 * torch.randn(x.shape, generator=g, device=dev)
-        positions = torch.stack([x, y, z], -1).reshape(-1, 3).contiguous()
-        del x, y, z
-        corners = []
-        for qv in range(4):
-            for qu in range(8):
-                a, b = qv * 9 + qu, qv * 9 + qu + 1
-                d, e = (qv + 1) * 9 + qu, (qv + 1) * 9 + qu + 1
-                corners += [a, d, b, b, d, e]
-        micro = torch.tensor(corners, dtype=torch.uint8, device=dev).repeat(P).contiguous()
-        vidx = torch.arange(45 * P, device=dev, dtype=torch.int32)
-        meshlets = torch.stack([p * 45, p * 192, torch.full_like(p, 45), torch.full_like(p, 64)], 1).to(torch.int32).contiguous()
-    torch.cuda.synchronize()
-    with torch.cuda.stream(stream):
-        for _ in range(warmup):
-            out = r.build_meshlet_bounds(positions, meshlets, vidx, micro, stream=stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        for _ in range(steps):
-            out = r.build_meshlet_bounds(positions, meshlets, vidx, micro, stream=stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    value = P * world * steps / dt
-    # algorithmic bytes per meshlet: Meshlet 16 + 45 vertex ids 180 + 192 micro bytes + 45 float3 540 read,
-    # MeshletBounds 16 + {min,max} scratch 24 written and 24 read again by the mesh fold; quantised positions:
-    # 540 read + 45 * 8 written
-    bytes_per_meshlet = (16 + 180 + 192 + 540 + 16 + 24 + 24) + (540 + 360)
-    achieved = bytes_per_meshlet * P * steps / dt / 1e9
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-
-        n = min(P, 20_000)
-        cp, cm, cv, cmi = positions[: 45 * n].cpu(), meshlets[:n].cpu(), vidx[: 45 * n].cpu(), micro[: 192 * n].cpu()
-        tc = time.perf_counter()
-        want = oracle.build_meshlet_bounds(cp, cm, cv, cmi)
-        t_cal = time.perf_counter() - tc
-        reps = int(max(1, min(args.cpu_seconds / max(t_cal, 1e-3), 1000)))
-        tc = time.perf_counter()
-        for _ in range(reps):
-            oracle.build_meshlet_bounds(cp, cm, cv, cmi)
-        dtc = time.perf_counter() - tc
-        ok = bool(torch.equal(want[0], out[0][:n].cpu()) and torch.equal(want[2], out[2][: 45 * n].cpu()))
-        cpu_baseline = {"value": round(n * reps / dtc, 1), "unit": "meshlets/s", "cores": 1, "kind": "port",
-                        "sample": f"{reps} passes over the first {n} meshlets of the same arrays, oracle/oxcull_oracle.c orc_build_meshlet_bounds "
-                                  f"(sequential), {dtc:.1f} s; GPU records of that range byte-identical: {ok}"}
-    if rank == 0:
-        print(json.dumps({
-            "metric": "meshlets/s bounded (asset-side producer)", "value": round(value, 1), "unit": "meshlets/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SURVEY 8f-1: oxc_build_meshlet_bounds over a procedural terrain, 64-triangle / 45-vertex patches",
-                       "meshlets_per_gpu": P, "vertices": 45 * P, "quantize_positions": True},
-            "roofline": {"bound": "hbm", "kernel": "build_meshlet_bounds (quantize_positions + meshlet_bounds + mesh fold)", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "algorithmic_bytes_per_meshlet": bytes_per_meshlet},
-            "cpu_baseline": cpu_baseline}))
-    if dist is not None:
-        dist.destroy_process_group()
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to report a {n_dev}-GPU number as {args.gpus}")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc)
 
 
-def bench_loop(args, r, dev, stream, rank, world, dist):
-    """--workload loop: the closed two-pass frame of RendererInstance::render (RendererInstance.cpp:842-884) without a
-    graphics queue -- early cull (last frame's mask) -> oxc_draw_visbuffer -> depth -> oxc_generate_hiz -> late cull ->
-    draw on top -- on a static scene (steady state: the early pass draws everything, the late pass finds nothing new)."""
-    n_meshlets = args.meshlets or 2_000_000
-    K = 1000
-    M = max(1, n_meshlets // K)
-    n_meshlets = M * K
-    W = H = 2048
-    steps, warmup = min(args.steps, 30), min(max(args.warmup, 2), 5)
-    with torch.cuda.stream(stream):
-        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 9 + rank), dev)
-        r.reserve(M, n_meshlets)
-        frame = PreparedFrame.create(scene, with_triangles=True)
-        r.prepared_frame = frame
-        cam = scene.cull_camera()
-        pv = [cam.projection_view[i] for i in range(16)]
-        hiz = ImageAttachment.hiz(W // 2, H // 2, dev)
-        depth = ImageAttachment.depth(torch.zeros((H, W), dtype=torch.float32, device=dev))
-        visdepth = torch.zeros((H, W), dtype=torch.int64, device=dev)
-        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=cam, hiz_attachment=hiz, stages=L.STAGE_ALL)
-        r.seed_meshlet_instances(ctx, n_meshlets)
-    from oxylus_amd.renderer import MainGeometryContext
-
-    mg = MainGeometryContext(depth_attachment=depth, hiz_attachment=hiz)
-    counts = {}
-
-    def one_frame(record=False):
-        ctx.cull_flags = L.CULL_TEST_ALL
-        r.cull_geometry(ctx, stream=stream)
-        if record:
-            c = r.read_counters(ctx, stream=stream)
-            counts["early"], counts["early_indices"] = c.cull_triangles_cmd_x, c.draw_index_count
-        r.draw_visbuffer(ctx, pv, W, H, visdepth, clear=True, depth=depth, stream=stream)
-        r.generate_hiz(mg, stream=stream)
-        ctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
-        r.cull_geometry(ctx, stream=stream)
-        if record:
-            c = r.read_counters(ctx, stream=stream)
-            counts["late"], counts["late_indices"] = c.cull_triangles_cmd_x, c.draw_index_count
-        r.draw_visbuffer(ctx, pv, W, H, visdepth, clear=False, depth=depth, stream=stream)
-
-    with torch.cuda.stream(stream):
-        for _ in range(warmup):
-            one_frame()
-        one_frame(record=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        for _ in range(steps):
-            one_frame()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    covered = float((visdepth != 0).float().mean().item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "meshlets/s through the closed two-pass frame (cull + draw + HiZ)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SURVEY 8f-2 loop: early cull -> draw -> depth -> HiZ -> late cull -> draw, static scene, steady state",
-                       "meshlets_per_gpu": n_meshlets, "target": [W, H], "hiz": [W // 2, H // 2], "tris_per_meshlet": 64,
-                       "steady_state_counts": counts, "covered_pixel_fraction": round(covered, 4)},
-            "roofline": None, "cpu_baseline": None}))
-    if dist is not None:
-        dist.destroy_process_group()
+class Env:
+    pass
 
 
-def bench_vsm(args, r, dev, stream, rank, world, dist):
-    """--workload vsm: the virtual-shadow-map cull of draw_virtual_shadowmap (Passes/Shadowmaps.cpp:331-366,433-463):
-    oxc_generate_hpb from a page table, then oxc_cull_geometry(use_hpb) = cull_meshes against the coarsest clipmap +
-    cull_meshlets_hpb over the 10 dirty clipmap views ("visible if any view's pages want it")."""
-    import numpy as np
-    from oxylus_amd.renderer import HpbAttachment
-    from oxylus_amd.synth import pack_clipmaps, virtual_shadow_matrices
+def setup(args) -> Env:
+    e = Env()
+    e.rank = int(os.environ.get("RANK", "0"))
+    e.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    e.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != e.world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={e.world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible (the cull path has no CPU fallback; --workload config1 is the CPU-only case)")
+    torch.cuda.set_device(e.local_rank)
+    e.dev = torch.device("cuda", e.local_rank)
+    e.dist = None
+    if e.world > 1:
+        import torch.distributed as dist
 
-    n_meshlets = args.meshlets or 10_000_000
-    K = 1000
-    M = max(1, n_meshlets // K)
-    n_meshlets = M * K
-    steps, warmup = min(args.steps, 50), min(max(args.warmup, 2), 5)
-    light = np.array([0.3, -1.0, 0.2])
-    light /= np.linalg.norm(light)
-    mats, offs, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], light, 500.0, 10.0, 10)
-    with torch.cuda.stream(stream):
-        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=False, lod_count=2, seed=0x0A1DE5 + 11 + rank), dev)
-        r.reserve(M, n_meshlets)
-        frame = PreparedFrame.create(scene, with_triangles=False, expand=False)
-        r.prepared_frame = frame
-        clip = pack_clipmaps(mats, offs, zn).to(dev)
-        g = torch.Generator(device=dev).manual_seed(3 + rank)
-        pt = torch.randint(0, 7, (10, 64, 64), generator=g, device=dev, dtype=torch.int32)
-        pt[torch.rand((10, 64, 64), generator=g, device=dev) < 0.15] = 7
-        hpb = HpbAttachment.create(64, 64, 10, 7, dev)
-        dirty = torch.ones(10, dtype=torch.int32, device=dev)
-        cam = scene.cull_camera()
-        for i in range(16):
-            cam.projection_view[i] = float(mats[9][i])
-        for i in range(3):
-            cam.position[i] = float(-light[i])
-        cam.near_clip = zn
-        ctx = CullGeometryContext(use_hpb=True, init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM, cull_camera=cam, hpb_attachment=hpb,
-                                  vsm_clipmaps_buffer=clip, vsm_clipmap_dirty_flags_buffer=dirty, vsm_clipmap_count=10,
-                                  stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+        dist.init_process_group("nccl", device_id=e.dev)  # RCCL over xGMI
+        e.dist = dist
+    e.r = RendererInstance(e.local_rank)
+    e.stream = torch.cuda.Stream(device=e.dev)
+    e.native_comm = bool(args.native_comm and e.dist is not None)
+    if e.native_comm:
+        box = [e.r.comm_unique_id() if e.rank == 0 else None]
+        e.dist.broadcast_object_list(box, src=0)
+        e.r.comm_init(box[0], e.rank, e.world)
+    return e
 
-    def one():
-        r.generate_hpb(pt, hpb, stream=stream)
-        r.cull_geometry(ctx, stream=stream)
 
-    with torch.cuda.stream(stream):
-        for _ in range(warmup):
-            one()
-    torch.cuda.synchronize()
-    c = r.read_counters(ctx, stream)
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        for _ in range(steps):
-            one()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "meshlets/s culled against 10 clipmap views (VSM page pyramid)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SURVEY 8a-14 + 8f-3: generate_hpb + cull_meshes + cull_meshlets_hpb, 10 dirty clipmaps of 64x64 pages, 15 % pages wanted",
-                       "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "after_cull_meshes": c.total_visible_meshlet_instances,
-                       "visible": c.cull_triangles_cmd_x},
-            "roofline": None, "cpu_baseline": None}))
-    if dist is not None:
-        dist.destroy_process_group()
+def barrier(e):
+    if e.dist is not None:
+        e.dist.barrier()
+
+
+def max_over_ranks(e, seconds: float) -> float:
+    if e.dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=e.dev)
+    e.dist.all_reduce(t, op=e.dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def usable_cores() -> int:
@@ -342,414 +166,544 @@ def usable_cores() -> int:
     return cores
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
+def ramp_clocks(e, seconds=0.75):
+    """Not steps: a fresh box idles at low DPM clocks; the first ~0.5 s of work runs 2-3x slower and would be measured
+    instead of the kernels."""
+    ramp = torch.empty(256 << 20, dtype=torch.uint8, device=e.dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        with torch.cuda.stream(e.stream):
+            for _ in range(20):
+                e.r.stream_read_probe(ramp, e.stream)
+        torch.cuda.synchronize()
+    del ramp
 
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    r = RendererInstance(local_rank)
-    lib, ctxp = r._lib, r._ctx
-    stream = torch.cuda.Stream(device=dev)
-    native_comm = bool(args.native_comm and dist is not None)
-    if native_comm:
-        box = [r.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        r.comm_init(box[0], rank, world)
-    if args.workload == "bounds":
-        return bench_bounds(args, r, dev, stream, rank, world, dist)
-    if args.workload == "loop":
-        return bench_loop(args, r, dev, stream, rank, world, dist)
-    if args.workload == "vsm":
-        return bench_vsm(args, r, dev, stream, rank, world, dist)
-    sp = C.c_void_p(stream.cuda_stream)
-    n_streams = max(1, args.streams) if args.workload == "config2" else 1
-    # extra contexts/streams for independent batches in flight (each context owns its scratch)
-    renderers = [r] + [RendererInstance(local_rank) for _ in range(n_streams - 1)]
-    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
-    sps = [C.c_void_p(s_.cuda_stream) for s_ in streams]
+def stream_read_ceiling(e) -> float:
+    """Measured streaming-read ceiling of this GPU (plain 16 B/lane loads over 2 GiB), GB/s."""
+    probe = torch.empty(2 << 30, dtype=torch.uint8, device=e.dev)
+    probe.random_(0, 255)
+    with torch.cuda.stream(e.stream):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:  # the memory clock needs sustained streaming before the rate settles
+            for _ in range(30):
+                e.r.stream_read_probe(probe, e.stream)
+            e.stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(e.stream)
+        for _ in range(30):
+            e.r.stream_read_probe(probe, e.stream)
+        e1.record(e.stream)
+    torch.cuda.synchronize()
+    gbps = 30 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del probe
+    return gbps
 
-    full = args.workload == "config3"
-    multiview = args.workload == "config5"
-    n_meshlets = args.meshlets or (10_000_000 if (full or multiview) else 1_000_000)
-    wide = full and args.tris > 64
+
+def timed_steps(e, run_step, steps: int, warmup: int) -> float:
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize pairs; max over ranks, seconds."""
+    with torch.cuda.stream(e.stream):
+        for i in range(warmup):
+            run_step(i)
+    torch.cuda.synchronize()
+    barrier(e)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(e.stream):
+        for i in range(steps):
+            run_step(i)
+    torch.cuda.synchronize()
+    barrier(e)
+    return max_over_ranks(e, time.perf_counter() - t0)
+
+
+def profile_kernels(e, renderers, run, n: int) -> dict:
+    """Instrumented pass: every kernel of `n` calls of run(i) bracketed by a HIP-event pair on the stream it runs on
+    (oxc_profile_begin/end).  Raw event-to-event time per launch (what rocprofv3's kernel duration also spans: dispatch +
+    run); the cost of an empty pair is reported, not subtracted."""
+    for rr in renderers:
+        rr.profile_begin()
+    with torch.cuda.stream(e.stream):
+        for i in range(n):
+            run(i)
+    acc, empty = {}, 0.0
+    for rr in renderers:
+        p = rr.profile_end()
+        empty = max(empty, p["empty_pair_ms"])
+        for name, k in p["kernels"].items():
+            a = acc.setdefault(name, {"launches": 0, "total_ms": 0.0})
+            a["launches"] += k["launches"]
+            a["total_ms"] += k["total_ms"]
+    out = {name: {"launches": k["launches"], "avg_us": k["total_ms"] / k["launches"] * 1e3} for name, k in acc.items()}
+    out["_empty_event_pair_us"] = round(empty * 1e3, 3)
+    return out
+
+
+def pmc_traffic(profile_name: str, match) -> tuple:
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate
+    passes, as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", profile_name)) as f:
+            pm = json.load(f)
+        vals = [cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0) for k, cs in pm.get("pmc", {}).items() if match(k) and "hbm_read_bytes_corrected" in cs]
+        if vals:
+            return round(sum(vals) / len(vals)), f"profiles/{profile_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2] (N = 1) / configs[3] (N > 1): HiZ build + two-pass occlusion cull + triangle cull + compaction
+# ------------------------------------------------------------------------------------------------------------------
+def hiz_algorithmic_bytes(w: int, h: int, levels: int) -> int:
+    """one depth texel read per mip-0 texel, every level written, the 64x64-tile level read again by the tail."""
+    written = sum(max(1, w >> k) * max(1, h >> k) for k in range(levels)) * 4
+    return 4 * w * h + written + (4 * max(1, w >> 6) * max(1, h >> 6) if levels > 7 else 0)
+
+
+def bench_config3(args, e):
+    r, dev, stream, rank, world, dist = e.r, e.dev, e.stream, e.rank, e.world, e.dist
+    lib, ctxp, sp = r._lib, r._ctx, C.c_void_p(stream.cuda_stream)
+    K = K_MESHLETS_PER_MESH
+    wide = args.tris > 64
+    n_meshlets = args.meshlets or (10_000_000 if world == 1 else 12_500_000)
     if wide:
         n_meshlets = min(n_meshlets, 8_000_000)  # 23-bit instance id of the wide index (SURVEY A.7)
-    K = 1000
     M = max(1, n_meshlets // K)
     n_meshlets = M * K
-    spec = SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=full, seed=0x0A1DE5 + 2 + rank,
-                     tris_per_meshlet=(args.tris if full else 64), lod_count=3 if multiview else 1)
-    with torch.cuda.stream(stream):
-        base = make_scene(spec, dev)
-        bytes_per_copy = n_meshlets * 24 + (M * 212)
-        if full or multiview:
-            copies = args.copies or 1  # 10M meshlets (+ geometry ~10 GB): far beyond the Infinity Cache already
-        else:
-            copies = args.copies or max(2, -(-1_150_000_000 // bytes_per_copy))
-        scenes = [base] + [base.clone() for _ in range(copies - 1)]
-        for rr in renderers:
-            rr.reserve(M, n_meshlets)
-        hiz = depth = None
-        if full:
-            depth = ImageAttachment.depth(make_depth(8192, 8192, 64, seed=3, device=dev))
-            hiz = ImageAttachment.hiz(4096, 4096, dev)
-        stages = L.STAGE_ALL if full else (L.STAGE_MESHES | L.STAGE_MESHLETS if multiview else L.STAGE_MESHLETS)
-        steps = [Step(renderers[i % n_streams], s, stages, use_hiz=full, hiz=hiz, with_triangles=full, wide=wide) for i, s in enumerate(scenes)]
-        if full:
-            g = torch.Generator(device=dev).manual_seed(5)
-            for st in steps:  # random prior-visibility mask, p = 0.3 (config 3 restatement)
-                words = st.frame.meshlet_instance_visibility_mask_buffer.numel()
-                bits = (torch.rand((words, 32), generator=g, device=dev) < 0.3).to(torch.int64)
-                st.frame.meshlet_instance_visibility_mask_buffer.copy_((bits << torch.arange(32, device=dev)).sum(1).to(torch.int32))
-            mask0 = [st.frame.meshlet_instance_visibility_mask_buffer.clone() for st in steps]
-    torch.cuda.synchronize()
+    inner = args.inner_reps or 48
+    HW = 4096
 
     def check(st):
         if st != L.OXC_OK:
             raise RuntimeError(lib.oxc_last_error(ctxp).decode())
 
-    if full:
+    with torch.cuda.stream(stream):
+        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2 + rank, tris_per_meshlet=args.tris), dev)
+        r.reserve(M, n_meshlets)
+        frame = PreparedFrame.create(scene, with_triangles=True, max_tris=128 if wide else 64)
+        depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))  # the same image on every rank
+        hiz = [ImageAttachment.hiz(HW, HW, dev) for _ in range(2 if (world > 1 and not args.no_overlap) else 1)]
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz[0],
+                                  stages=L.STAGE_ALL, wide_triangle_index=wide, small_triangle_cull=args.small_triangle_cull)
+        r.prepared_frame = frame
+        r.seed_meshlet_instances(ctx, n_meshlets)
+        # random prior-visibility mask, p = 0.3 (SURVEY 8d); every frame starts from it again
+        g = torch.Generator(device=dev).manual_seed(5 + rank)
+        words = frame.meshlet_instance_visibility_mask_buffer.numel()
+        bits = (torch.rand((words, 32), generator=g, device=dev) < 0.3).to(torch.int64)
+        mask0 = (bits << torch.arange(32, device=dev)).sum(1).to(torch.int32)
+        del bits
+        mask = frame.meshlet_instance_visibility_mask_buffer
+    torch.cuda.synchronize()
+    cframe = frame.c()
+    pf = C.byref(cframe)
+    cctx = [ctx.c()]
+    for hz in hiz[1:]:  # one pre-marshalled context per pyramid buffer (same sequence buffers)
+        c2 = L.CullGeometryContext()
+        C.memmove(C.byref(c2), C.byref(cctx[0]), C.sizeof(L.CullGeometryContext))
+        c2.hiz_attachment = hz.c()
+        cctx.append(c2)
+    mgs = []
+    for hz in hiz:
         mg = L.MainGeometryContext()
         mg.struct_size = C.sizeof(L.MainGeometryContext)
-        mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
-        pmg = C.byref(mg)
+        mg.depth_attachment, mg.hiz_attachment = depth.c(), hz.c()
+        mgs.append(mg)
+    hiz_bytes = hiz[0].data.numel() * 4
 
-    view_cams = []
-    if multiview:
-        # config 5: orthographic cascade views with doubling extents around the camera
-        # (Shadowmaps.cpp:9-63 generalised to `--views` levels), per-view LOD select (cull_meshes)
-        from oxylus_amd.synth import virtual_shadow_matrices
+    # ---- multi-GPU plumbing: second context + stream for the pyramid producer, events, counter all-gather ----
+    overlap = world > 1 and not args.no_overlap
+    r_hiz, comm_stream, ev_ready, ev_free = r, stream, None, None
+    if overlap:
+        r_hiz = RendererInstance(e.local_rank)  # its own context: the producer runs beside the cull (one context = one ordered queue)
+        if e.native_comm:  # ... and its own communicator: the broadcast must not queue behind the cull context's calls
+            box = [r_hiz.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            r_hiz.comm_init(box[0], rank, world)
+        comm_stream = torch.cuda.Stream(device=dev)
+        ev_ready = [torch.cuda.Event() for _ in hiz]
+        ev_free = [torch.cuda.Event() for _ in hiz]
+    if world > 1:
+        my_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        gathered = torch.zeros(world * 4, dtype=torch.int32, device=dev)
+    csp = C.c_void_p(comm_stream.cuda_stream)
 
-        mats, _, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], [0.3, -1.0, 0.2], 500.0, 2.0, args.views)
-        for v in range(args.views):
-            cam = base.cull_camera()
-            for k in range(16):
-                cam.projection_view[k] = float(mats[v][k])
-            cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
-            cam.near_clip = zn
-            view_cams.append(cam)
-
-    single_stream = [False]  # instrumented pass: every context on stream 0, so kernels do not overlap
-    batch = max(1, min(16, args.batch)) if args.workload == "config2" else 1
-    groups = []  # (context index k, C arrays) : `batch` copies of the same context culled by ONE batched call
-    if batch > 1:
-        per_ctx = [[st for i, st in enumerate(steps) if i % n_streams == k] for k in range(n_streams)]
-        for k, lst in enumerate(per_ctx):
-            for j in range(0, len(lst) - len(lst) % batch, batch):
-                grp = lst[j:j + batch]
-                cf = (L.PreparedFrame * batch)(*[g_.cframe for g_ in grp])
-                cc = (L.CullGeometryContext * batch)(*[g_.cctx for g_ in grp])
-                groups.append((k, cf, cc))
-        assert groups, "--batch needs at least `batch` copies per stream"
-    steps_per_call = batch
-
-    def run_group(gi, n=None):
-        k, cf, cc = groups[gi % len(groups)]
-        check(lib.oxc_cull_geometry_batch(renderers[k]._ctx, n or batch, cf, cc, sps[0] if single_stream[0] else sps[k]))
-
-    # config 5: the views are independent cull_geometry calls over the same scene; `--batch` of them go through one
-    # oxc_cull_geometry_batch call (each element has its own outputs and its own mesh_instances copy: cull_meshes
-    # writes lod_index per view)
-    view_batch = max(1, min(16, args.batch)) if multiview else 1
-    view_groups = []
-    if multiview:
-        import dataclasses
-
-        with torch.cuda.stream(stream):
-            lanes = [steps[0]] + [Step(r, dataclasses.replace(base, mesh_instances=base.mesh_instances.clone()), stages) for _ in range(view_batch - 1)]
-            r.reserve(M, n_meshlets)
-        for v0 in range(0, args.views, view_batch):
-            cams = view_cams[v0:v0 + view_batch]
-            cc = (L.CullGeometryContext * len(cams))()
-            cf = (L.PreparedFrame * len(cams))()
-            for e, cam in enumerate(cams):
-                lanes[e].cctx.init_cull_meshes = 1
-                lanes[e].cctx.cull_flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
-                lanes[e].cctx.cull_camera = cam
-                C.memmove(C.byref(cc, e * C.sizeof(L.CullGeometryContext)), lanes[e].pc, C.sizeof(L.CullGeometryContext))
-                C.memmove(C.byref(cf, e * C.sizeof(L.PreparedFrame)), lanes[e].pf, C.sizeof(L.PreparedFrame))
-            view_groups.append((len(cams), cf, cc))
-
-    def run_step(i):
-        st = steps[i % copies]
-        if multiview:
-            for n, cf, cc in view_groups:
-                if n == 1:
-                    check(lib.oxc_cull_geometry(ctxp, cf, cc, sp))
-                else:
-                    check(lib.oxc_cull_geometry_batch(ctxp, n, cf, cc, sp))
-            # the counters read below come from view 0's context
-            C.memmove(st.pc, C.byref(view_groups[0][2], 0), C.sizeof(L.CullGeometryContext))
-            return
-        if not full:
-            k = (i % copies) % n_streams  # copy -> context/stream
-            check(lib.oxc_cull_geometry(renderers[k]._ctx, st.pf, st.pc, sps[0] if single_stream[0] else sps[k]))
-            return
-        # config 3: HiZ build, then early + late pass against it (render order of
-        # RendererInstance.cpp:882-884 restated for a given depth + given mask)
-        st.frame.meshlet_instance_visibility_mask_buffer.copy_(mask0[i % copies], non_blocking=True)
-        # multi-GPU (configs[3]): depth is produced where rasterisation happens -- rank 0 builds the
-        # pyramid and broadcasts it over RCCL/xGMI (89.5 MB); every rank culls its own shard against it
-        if world == 1 or rank == 0:
-            check(lib.oxc_generate_hiz(ctxp, pmg, sp))
+    def produce_hiz(b):
+        """Rank 0 builds pyramid buffer b from the depth image; everybody receives it (RCCL broadcast over xGMI)."""
+        if rank == 0:
+            st = r_hiz._lib.oxc_generate_hiz(r_hiz._ctx, C.byref(mgs[b]), csp)
+            if st != L.OXC_OK:
+                raise RuntimeError(r_hiz._lib.oxc_last_error(r_hiz._ctx).decode())
         if dist is not None:
-            if native_comm:
-                r.broadcast_hiz(hiz, 0, stream)
+            if e.native_comm:
+                r_hiz.broadcast_hiz(hiz[b], 0, comm_stream)
             else:
-                dist.broadcast(hiz.data, src=0)
-        st.cctx.cull_flags = L.CULL_TEST_ALL
-        check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
-        st.cctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
-        check(lib.oxc_cull_geometry(ctxp, st.pf, st.pc, sp))
+                with torch.cuda.stream(comm_stream):
+                    dist.broadcast(hiz[b].data, src=0)
 
-    # ---- parity of what is being timed: copy 0 against the CPU oracle (rank 0) ----
-    bit_match = None
-    counts = {}
-    with torch.cuda.stream(stream):
-        run_step(0)
-    torch.cuda.synchronize()
-    c0 = r.read_counters(steps[0].ctx, stream)
-    counts = {"total": c0.total_visible_meshlet_instances, "early": c0.early_visible_meshlet_instances,
-              "late": c0.late_visible_meshlet_instances, "emitted": c0.cull_triangles_cmd_x, "index_count": c0.draw_index_count}
-    visible_fraction = (c0.cull_triangles_cmd_x if not full else c0.early_visible_meshlet_instances + c0.late_visible_meshlet_instances) / n_meshlets
-    units_per_step = n_meshlets * (args.views if multiview else 1)
-    cpu_scene = None
-    if rank == 0 and not full and not multiview:
-        import oracle  # checker only
-
-        oracle.build()
-        cpu_scene = base.to("cpu")
-        want = oracle.cull_meshlets(cpu_scene, cpu_scene.cull_camera(), cpu_scene.meshlet_instances, nthreads=os.cpu_count() or 1)
-        got = steps[0].frame.visible_meshlet_instances_indices_buffer[: c0.cull_triangles_cmd_x].cpu()
-        bit_match = bool(want.numel() == got.numel() and torch.equal(want, got))
-
-    # ---- clock ramp (not steps: a fresh box idles at low DPM clocks; the first ~0.5 s of work runs
-    # 2-3x slower and would be measured instead of the kernels), then the W warmup steps ----
-    ramp = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.75:
-        with torch.cuda.stream(stream):
-            for _ in range(20):
-                r.stream_read_probe(ramp, stream)
-        torch.cuda.synchronize()
-    del ramp
-    # a "unit" is one host call: one step, or `batch` steps through oxc_cull_geometry_batch
-    def run_unit(u):
-        if batch > 1:
-            run_group(u)
-        else:
-            run_step(u)
-
-    units_per_rotation = len(groups) if batch > 1 else copies
-    with torch.cuda.stream(stream):
-        for u in range(-(-args.warmup // steps_per_call)):
-            run_unit(u)
-    torch.cuda.synchronize()
-
-    # ---- optional HIP graph over one rotation through the copies ----
-    graph = None
-    per_replay = units_per_rotation * steps_per_call
-    # a HIP graph pays when the loop is launch-bound (few frames per launch); at >= 8 frames per launch there are three
-    # launches per ~100 us and the graph executor only gets in the way of cross-stream overlap
-    want_graph = not args.no_graph and (args.graph or steps_per_call < 8)
-    if want_graph and not full and not multiview and args.steps >= per_replay:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            for s_ in streams[1:]:
-                s_.wait_stream(stream)  # fork: the side streams join the capture
-            for u in range(units_per_rotation):
-                run_unit(u)
-            for s_ in streams[1:]:
-                stream.wait_stream(s_)  # join
-        with torch.cuda.stream(stream):
-            for _ in range(max(1, args.warmup // per_replay)):
-                graph.replay()
-        torch.cuda.synchronize()
-
-    gathered = None
-    if dist is not None:
-        my_counts = torch.tensor([counts["emitted"], counts["early"], counts["late"], counts["index_count"]], dtype=torch.int32, device=dev)
-        gathered = torch.zeros(world * 4, dtype=torch.int32, device=dev)  # flat all-gather target, [world, 4] counters
-
-    def gather_counts():
-        if native_comm:
+    def gather_counts(c):
+        # {emitted, early, late, index_count} of this rank's last call -> every rank (north star's all-gather); packed on the
+        # device out of the call's counter slot, no host round trip
+        check(lib.oxc_pack_counters(ctxp, C.byref(c), C.c_void_p(my_counts.data_ptr()), sp))
+        if e.native_comm:
             check(lib.oxc_exchange_counts(ctxp, C.c_void_p(my_counts.data_ptr()), C.c_void_p(gathered.data_ptr()), sp))
         else:
             dist.all_gather_into_tensor(gathered, my_counts)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    frame_no = [0]
 
-    # ---- timed region: EXACTLY args.steps steps ----
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        done = 0
-        if graph is not None:
-            for _ in range(args.steps // per_replay):
-                graph.replay()
-                done += per_replay
-                if dist is not None:  # per-rank visible counts -> every rank (north star's all-gather), bucketed per rotation
-                    gather_counts()
-        while args.steps - done >= steps_per_call:
-            run_unit(done // steps_per_call)
-            done += steps_per_call
-            if dist is not None and graph is None and (done // steps_per_call) % units_per_rotation == 0:
-                gather_counts()  # same cadence as the graph path: once per rotation through the copies
-        if batch > 1 and 1 < args.steps - done:  # remainder smaller than a batch: one shorter batched call
-            run_group(done // steps_per_call, args.steps - done)
-            done = args.steps
-        while done < args.steps:
-            run_step(done)
-            done += 1
-        if dist is not None and graph is None:
-            gather_counts()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed_s = float(elapsed.item())
-    value = units_per_step * world * args.steps / elapsed_s
-    ms_per_step = elapsed_s * 1e3 / args.steps
+    def run_frame(record=None):
+        f = frame_no[0]
+        frame_no[0] += 1
+        b = f % len(hiz)
+        mask.copy_(mask0, non_blocking=True)  # restore the synthetic prior-visibility mask (1.25 MB copy)
+        if overlap:
+            if f == 0:
+                produce_hiz(0)
+                ev_ready[0].record(comm_stream)
+            # next frame's pyramid: produced now, on the side stream, into the other buffer (free once frame f-1 has culled)
+            nb = (f + 1) % len(hiz)
+            if f >= 1:
+                comm_stream.wait_event(ev_free[nb])
+            produce_hiz(nb)
+            ev_ready[nb].record(comm_stream)
+            stream.wait_event(ev_ready[b])
+        else:
+            produce_hiz(b)  # (comm_stream is the cull stream here)
+        c = cctx[b]
+        c.cull_flags = L.CULL_TEST_ALL
+        check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
+        if record is not None:
+            record("early", c)
+        c.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
+        check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
+        if record is not None:
+            record("late", c)
+        if overlap:
+            ev_free[b].record(stream)
+        if world > 1:
+            gather_counts(c)
 
-    # ---- secondary figure: the same steps with ONE batch in flight (one stream, dependent launches) ----
-    single = None
-    if n_streams > 1 and not full and not multiview and args.steps >= per_replay:
-        single_stream[0] = True
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, stream=stream):
-            for u in range(units_per_rotation):
-                run_unit(u)
-        reps1 = max(2, min(args.steps // per_replay, 20))
-        with torch.cuda.stream(stream):
-            g1.replay()
+    def run_step(_i):
+        for _ in range(inner):
+            run_frame()
+
+    # ---- one checked frame: counters + parity of what is being timed against the CPU checker (rank 0) ----
+    snap = {}
+
+    def record(tag, c):
         torch.cuda.synchronize()
-        t0s = time.perf_counter()
-        with torch.cuda.stream(stream):
-            for _ in range(reps1):
-                g1.replay()
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t0s
-        single = {"value": round(n_meshlets * reps1 * per_replay / dts, 1), "ms_per_step": round(dts * 1e3 / (reps1 * per_replay), 6),
-                  "steps": reps1 * per_replay}
-        single_stream[0] = False
-        del g1
+        out = L.Counters()
+        check(lib.oxc_read_counters(ctxp, C.byref(c), C.byref(out), sp))
+        first = out.early_visible_meshlet_instances if tag == "late" else 0
+        snap[tag] = {"emitted": out.cull_triangles_cmd_x, "index_count": out.draw_index_count, "first": first,
+                     "early": out.early_visible_meshlet_instances, "late": out.late_visible_meshlet_instances, "total": out.total_visible_meshlet_instances}
+        if rank == 0:
+            lim = min(args.cpu_prefix, M) * K  # the checker's sample: ids below `lim` (ascending lists: a prefix of each list)
+            vis = frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x]
+            nv = int(torch.searchsorted(vis, torch.tensor([lim], dtype=torch.int32, device=dev)).item())
+            # packed (id << 8 | corner) values are u32: search an upper-bounded head of the list as int64
+            shift = 9 if wide else 8
+            head = frame.reordered_indices_buffer[:min(out.draw_index_count, nv * (384 if wide else 192))].to(torch.int64) & 0xFFFFFFFF
+            ni = int(torch.searchsorted(head, torch.tensor([lim << shift], dtype=torch.int64, device=dev)).item())
+            snap[tag]["visible_prefix"] = vis[:nv].cpu()
+            snap[tag]["indices_prefix"] = frame.reordered_indices_buffer[:ni].cpu()
 
-    # ---- instrumented pass: per-kernel HIP-event times on the same stream, same workload ----
-    prof_units = max(1, min(args.steps, max(2 * copies, 96)) // steps_per_call)
-    prof_steps = prof_units * steps_per_call
-    single_stream[0] = True
-    for rr in renderers:
-        rr.profile_begin()
     with torch.cuda.stream(stream):
-        for u in range(prof_units):
-            run_unit(u)
-    prof = {"kernels": {}, "empty_pair_ms": 0.0}
-    for rr in renderers:
-        p_ = rr.profile_end()
-        prof["empty_pair_ms"] = max(prof["empty_pair_ms"], p_["empty_pair_ms"])
-        for name, k in p_["kernels"].items():
-            acc = prof["kernels"].setdefault(name, {"launches": 0, "total_ms": 0.0})
-            acc["launches"] += k["launches"]
-            acc["total_ms"] += k["total_ms"]
-    single_stream[0] = False
-    kernels = {}
-    for name, k in prof["kernels"].items():
-        # raw event-to-event time per launch (what rocprofv3's kernel duration also spans: dispatch + run);
-        # the cost of an empty event pair is reported separately, not subtracted
-        avg_us = (k["total_ms"] / k["launches"]) * 1e3
-        kernels[name] = {"launches_per_step": k["launches"] / prof_steps, "avg_us": round(avg_us, 3)}
-    kernels["_empty_event_pair_us"] = round(prof["empty_pair_ms"] * 1e3, 3)
-
-    # measured streaming-read ceiling of this GPU (16 B/lane sum kernel over 2 GiB)
-    probe = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
-    probe.random_(0, 255)
-    with torch.cuda.stream(stream):
-        t_probe = time.perf_counter()  # the memory clock needs sustained streaming before the rate settles (a short --steps run
-        while time.perf_counter() - t_probe < 0.3:  # leaves the GPU idling at low clocks by the time it gets here: 2.0 instead of 6.0 TB/s)
-            for _ in range(30):
-                r.stream_read_probe(probe, stream)
-            stream.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(30):
-            r.stream_read_probe(probe, stream)
-        e1.record(stream)
+        run_frame(record)
     torch.cuda.synchronize()
-    stream_read_gbps = 30 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del probe
+    mask_after = mask[: (min(args.cpu_prefix, M) * K + 31) // 32].cpu() if rank == 0 else None
+    counts = {"total": snap["late"]["total"], "early": snap["late"]["early"], "late": snap["late"]["late"],
+              "early_index_count": snap["early"]["index_count"], "late_index_count": snap["late"]["index_count"]}
+    v_early, v_late = counts["early"], counts["late"]
+    t_early, t_late = counts["early_index_count"] // 3, counts["late_index_count"] // 3
 
-    # ---- roofline of the dominant kernel ----
-    if not full:
-        dom = "cull_meshlets_test"  # (config5: one launch per view; bytes are per launch over the LOD-selected list)
-        # 8 B MeshletInstance + 16 B MeshletBounds read per meshlet + per-mesh tables
-        # 212/K B + 4*v B of visible indices written (the write is done by cull_meshlets_emit; it is
-        # charged to the stage, i.e. to this launch, as 8(d) does).
-        bytes_per_unit = 24.0 + 212.0 / K + 4.0 * visible_fraction
-        units = n_meshlets * steps_per_call  # one launch covers `batch` frames
-    else:
-        dom = "cull_triangles_test"
-        v_tot = counts["early"] + counts["late"]
-        bytes_per_unit = 4 + 8 + 16 + (3 * args.tris + 3) // 4 * 4 + 4 * 64 + 8 * 64  # 988 B per visible meshlet (V=64, T=64; 1168 B at T=124), SURVEY 8(d) a11
-        units = v_tot / 2.0  # two launches (early, late) share the visible set
-    dom_us = (kernels.get(dom) or {}).get("avg_us")
+    ramp_clocks(e)
+    elapsed = timed_steps(e, run_step, args.steps, args.warmup)
+    frames = args.steps * inner
+    ms_per_frame = elapsed * 1e3 / frames
+    value = n_meshlets * world * frames / elapsed
+
+    # ---- per-kernel times (>= 50 launches each) and rooflines: algorithmic bytes of SURVEY 8d ----
+    n_prof = max(50, min(inner, 96))
+    renderers = [r] + ([r_hiz] if r_hiz is not r else [])
+    kern = profile_kernels(e, renderers, lambda i: run_frame(), n_prof)
+    tri_bytes_per_meshlet = 4 + 8 + 16 + (3 * args.tris + 3) // 4 * 4 + 4 * 64 + 8 * 64  # 988 B (V=64, T=64), SURVEY 8d a11
+    H = 2 if wide else 1
+    alg = {  # per launch
+        "hiz": hiz_algorithmic_bytes(HW, HW, hiz[0].levels),
+        "prepare_instances": M * (212 + 384),
+        # 8 B MeshletInstance + 16 B MeshletBounds per meshlet + the mask word read and written (1/8 B each); the 16*f B of HiZ
+        # taps of SURVEY 8d are left out (f is not observable from the counters): a lower bound, so frac is conservative
+        "cull_meshlets_test": n_meshlets * (24.0 + 0.25),
+        "cull_meshlets_test_late": n_meshlets * (24.0 + 0.25),
+        "cull_meshlets_emit": n_meshlets / 8.0 + 4.0 * v_early,
+        "cull_meshlets_emit_late": n_meshlets / 8.0 + 4.0 * v_late,
+        "cull_triangles_test": v_early * (tri_bytes_per_meshlet + 8.0 * H),
+        "cull_triangles_test_late": v_late * (tri_bytes_per_meshlet + 8.0 * H),
+        "cull_triangles_emit": v_early * (8.0 * H + 4.0) + 12.0 * t_early,
+        "cull_triangles_emit_late": v_late * (8.0 * H + 4.0) + 12.0 * t_late,
+    }
+    kernels, frame_alg, frame_kernel_us = {}, 0.0, 0.0
+    for name, k in kern.items():
+        if name.startswith("_"):
+            kernels[name] = k
+            continue
+        per_frame = k["launches"] / n_prof
+        ent = {"launches_per_frame": round(per_frame, 3), "launches_timed": k["launches"], "avg_us": round(k["avg_us"], 3)}
+        b = alg.get(name)
+        if b is None and name == "cull_meshlets_occlusion":
+            b = 0.0
+        if b is not None:
+            ent["algorithmic_bytes_per_launch"] = round(b)
+            ent["achieved_GBps"] = round(b / (k["avg_us"] * 1e-6) / 1e9, 1)
+            ent["frac"] = round(b / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+            frame_alg += b * per_frame
+        frame_kernel_us += k["avg_us"] * per_frame
+        kernels[name] = ent
+    # dominant kernel: the triangle test (both instantiations: early + late launch of a frame)
+    tt = [kern[n] for n in ("cull_triangles_test", "cull_triangles_test_late") if n in kern]
     roofline = None
-    if dom_us and dom_us > 0:
-        achieved = bytes_per_unit * units / (dom_us * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
-                    "algorithmic_bytes_per_launch": round(bytes_per_unit * units), "kernel_avg_us": dom_us,
-                    "measured_stream_read_GBps": round(stream_read_gbps, 1),  # plain 16 B/lane loads; `nt` loads stream at 6.8-7.1 TB/s
-                    "frac_of_measured_stream_read": round(achieved / stream_read_gbps, 4)}  # (profiles/r01_bw_probe.txt)
+    stream_gbps = stream_read_ceiling(e)
+    if tt:
+        dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
+        dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic("r02_config3_pmc.json", lambda k: "k_cull_triangles_test" in k)
+        roofline = {"bound": "hbm", "kernel": "k_cull_triangles_test (early + late launch of a frame, averaged)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
+                    "launches_averaged": sum(k["launches"] for k in tt), "measured_stream_read_GBps": round(stream_gbps, 1),
+                    "frac_of_measured_stream_read": round(achieved / stream_gbps, 4)}
+    stage = {"algorithmic_bytes_per_frame": round(frame_alg), "ms_per_frame": round(ms_per_frame, 6),
+             "achieved_GBps": round(frame_alg / (ms_per_frame * 1e-3) / 1e9, 1), "stage_frac": round(frame_alg / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "sum_of_kernel_us_per_frame": round(frame_kernel_us, 1),
+             "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures, HiZ taps excluded"}
 
-    # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary (collected in its own
-    # passes, FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 as MI355X_MICROARCH.md prescribes); PMC counters
-    # cannot be read from inside this process.
-    if roofline is not None:
-        try:
-            prof_name = {"config2": "r01_config2_pmc.json", "config3": "r01_config3_pmc.json", "config5": "r01_config5_pmc.json"}[args.workload]
-            with open(os.path.join(ROOT, "profiles", prof_name)) as fpm:
-                pm = json.load(fpm)
-            per_variant = []  # config3 launches the early and the late instantiation once each per step:
-            for kname, cs in pm.get("pmc", {}).items():  # kernel_avg_us averages both, so does traffic
-                ok_variant = args.workload != "config2" or ("_batch" in kname) == (steps_per_call > 1) and ("_batch" in kname or "<false, false, false" in kname)
-                if dom in kname and ok_variant and "hbm_read_bytes_corrected" in cs:
-                    per_variant.append(cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0))
-                    if args.workload == "config2":
-                        break
-            if per_variant:
-                roofline["traffic"] = round(sum(per_variant) / len(per_variant))
-                roofline["traffic_source"] = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, per launch)"
-        except (OSError, KeyError, ValueError):
-            pass
+    # ---- CPU checker on a bounded prefix of the SAME arrays: bit_match + cpu_baseline (rank 0, N = 1) ----
+    bit_match, cpu_baseline, hiz_match = None, None, None
+    if rank == 0:
+        import oracle  # checker only
 
-    # ---- CPU baseline: the scalar C oracle over the same arrays, all host cores ----
+        oracle.build()
+        m0 = min(args.cpu_prefix, M)
+        sub = scene.prefix(m0, "cpu")
+        cam = sub.cull_camera()
+        hz_cpu = hiz[0].data.cpu()
+        if world == 1 and not args.no_cpu_baseline:  # the checker builds the pyramid itself from the same depth image
+            dcpu = depth.data.view(2 * HW, 2 * HW).cpu()
+            own = torch.zeros_like(hz_cpu)
+            t_h0 = time.perf_counter()
+            oracle.generate_hiz(dcpu, own, HW, HW, hiz[0].levels, hiz[0].level_offset)
+            t_hiz_cpu = time.perf_counter() - t_h0
+            hiz_match = bool(torch.equal(own.view(torch.int32), hz_cpu.view(torch.int32)))
+            del dcpu, own
+        hz = oracle.make_hiz(hz_cpu, HW, HW, hiz[0].levels, hiz[0].level_offset)
+        mask_cpu0 = mask0[: (m0 * K + 31) // 32].cpu()
+
+        def cpu_sequence():
+            v = oracle.Visibility(m0 * K, 0, 0)
+            out = torch.zeros(m0 * K, dtype=torch.int32)
+            mk = mask_cpu0.clone()
+            res = {}
+            for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+                n_e = oracle.cull_meshlets_hiz(sub, cam, sub.meshlet_instances, flags, hz, v, mk, out)
+                first = v.early if tag == "late" else 0
+                res[tag] = (out[first:first + n_e].clone(),
+                            oracle.cull_triangles(sub, cam, sub.meshlet_instances, out, first, n_e, wide=wide, small_triangle_cull=args.small_triangle_cull))
+            return res, mk
+
+        t_c0 = time.perf_counter()
+        want, mask_want = cpu_sequence()
+        t_seq = time.perf_counter() - t_c0
+        bit_match = bool(all(torch.equal(want[t][0], snap[t]["visible_prefix"]) and torch.equal(want[t][1], snap[t]["indices_prefix"]) for t in ("early", "late"))
+                         and torch.equal(mask_want, mask_after))
+        if world == 1 and not args.no_cpu_baseline:
+            reps = int(max(1, min(args.cpu_seconds / max(t_seq, 1e-3), 200)))
+            t_c0 = time.perf_counter()
+            for _ in range(reps):
+                cpu_sequence()
+            dt = (time.perf_counter() - t_c0) / reps
+            share = t_hiz_cpu * (m0 * K) / n_meshlets  # the pyramid build serves all N meshlets: its share for the sample
+            cpu_baseline = {"value": round(m0 * K / (dt + share), 1), "unit": "meshlets/s", "cores": 1, "kind": "port",
+                            "sample": f"{reps} runs of the same sequence (cull_meshlets_hiz early + cull_triangles, late + cull_triangles; oracle/oxcull_oracle.c, scalar, "
+                                      f"one thread) over the first {m0 * K} meshlet instances of the same arrays ({dt:.2f} s per run) + that sample's share of the "
+                                      f"scalar 4096^2 pyramid build ({t_hiz_cpu:.2f} s for the whole image)",
+                            "hiz_build_s": round(t_hiz_cpu, 3), "sequence_s_per_run": round(dt, 3)}
+
+    line = {
+        "metric": "meshlets/s culled", "value": round(value, 1), "unit": "meshlets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": ("configs[2]: 10M meshlets + 4096^2 prior-frame HiZ (13 mips, built from an 8192^2 depth): HiZ build + early/late occlusion cull + "
+                         "per-triangle cull + ordered compaction into the indirect-draw buffers" if world == 1 else
+                         f"configs[3]: {n_meshlets * world} meshlets sharded {world} ways by contiguous range (the configs[2] pipeline per rank): rank 0 builds the "
+                         "4096^2 pyramid and broadcasts it over RCCL/xGMI, per-rank counters all-gathered every frame, shard-local ids and outputs"),
+            "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris, "verts_per_meshlet": 64,
+            "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
+            "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
+            "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": world, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else "torch.distributed nccl (RCCL)",
+                                                         "hiz_broadcast_bytes_per_frame": hiz_bytes, "hiz_one_frame_ahead_on_second_stream": overlap,
+                                                         "counters_all_gather_bytes_per_rank": 16},
+        },
+        "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
+        "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    # free the 25 GB of this workload before the nested one
+    del scene, frame, depth, hiz, mask0
+    torch.cuda.empty_cache()
+    return line
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[1]: 1M meshlets, one camera, frustum + cone cull + ordered compaction
+# ------------------------------------------------------------------------------------------------------------------
+def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
+    """A step = one 1M-meshlet frame (one RendererInstance::cull_geometry over one scene copy).  The 24 MB working set would sit
+    in the 256 MB Infinity Cache, so frames rotate over >= 1.1 GB of independent copies.  A single call is three
+    dependent launches of ~26 us in total, so it is measured twice: `batched` (16 frames per oxc_cull_geometry_batch launch, three
+    contexts on three streams, eager) and `one_call_per_frame` (oxc_cull_geometry per frame, ONE stream, replayed from a HIP graph
+    so the host is out of the picture)."""
+    r, dev, stream, rank, world, dist = e.r, e.dev, e.stream, e.rank, e.world, e.dist
+    lib = r._lib
+    K = K_MESHLETS_PER_MESH
+    n_meshlets = args.meshlets if (args.meshlets and args.workload == "config2") else 1_000_000
+    M = max(1, n_meshlets // K)
+    n_meshlets = M * K
+    n_streams = max(1, args.streams)
+    batch = max(1, min(16, args.batch))
+    renderers = [r] + [RendererInstance(e.local_rank) for _ in range(n_streams - 1)]
+    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    sps = [C.c_void_p(s_.cuda_stream) for s_ in streams]
+    bytes_per_copy = n_meshlets * 24 + M * 212
+    copies = args.copies or max(n_streams * batch, -(-1_150_000_000 // bytes_per_copy))
+    copies = -(-copies // (n_streams * batch)) * (n_streams * batch)
+
+    class Step:
+        def __init__(self, rr, scene):
+            self.frame = PreparedFrame.create(scene, with_triangles=False)
+            self.cframe = self.frame.c()
+            self.ctx = CullGeometryContext(use_hiz=False, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), stages=L.STAGE_MESHLETS)
+            rr.prepared_frame = self.frame
+            rr.seed_meshlet_instances(self.ctx, scene.n_meshlet_instances)
+            self.cctx = self.ctx.c()
+            self.pf, self.pc = C.byref(self.cframe), C.byref(self.cctx)
+
+    with torch.cuda.stream(stream):
+        base = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=False, seed=0x0A1DE5 + 2 + rank), dev)
+        scenes = [base] + [base.clone() for _ in range(copies - 1)]
+        for rr in renderers:
+            rr.reserve(M, n_meshlets)
+        st_ = [Step(renderers[i % n_streams], s) for i, s in enumerate(scenes)]
+    torch.cuda.synchronize()
+
+    def check(rr, st):
+        if st != L.OXC_OK:
+            raise RuntimeError(lib.oxc_last_error(rr._ctx).decode())
+
+    groups = []
+    for k in range(n_streams):
+        lst = [s for i, s in enumerate(st_) if i % n_streams == k]
+        for j in range(0, len(lst), batch):
+            grp = lst[j:j + batch]
+            groups.append((k, (L.PreparedFrame * batch)(*[g_.cframe for g_ in grp]), (L.CullGeometryContext * batch)(*[g_.cctx for g_ in grp])))
+    one_stream = [False]
+
+    def run_group(gi):
+        k, cf, cc = groups[gi % len(groups)]
+        check(renderers[k], lib.oxc_cull_geometry_batch(renderers[k]._ctx, batch, cf, cc, sps[0] if one_stream[0] else sps[k]))
+
+    # parity of what is timed: copy 0 against the checker
+    with torch.cuda.stream(stream):
+        check(r, lib.oxc_cull_geometry(r._ctx, st_[0].pf, st_[0].pc, sps[0]))
+    torch.cuda.synchronize()
+    c0 = r.read_counters(st_[0].ctx, stream)
+    visible_fraction = c0.cull_triangles_cmd_x / n_meshlets
+    bit_match, cpu_scene = None, None
+    if rank == 0:
+        import oracle
+
+        oracle.build()
+        cpu_scene = base.to("cpu")
+        want = oracle.cull_meshlets(cpu_scene, cpu_scene.cull_camera(), cpu_scene.meshlet_instances, nthreads=os.cpu_count() or 1)
+        got = st_[0].frame.visible_meshlet_instances_indices_buffer[: c0.cull_triangles_cmd_x].cpu()
+        bit_match = bool(want.numel() == got.numel() and torch.equal(want, got))
+
+    ramp_clocks(e, 0.5)
+    # ---- (a) batched: `batch` frames per launch, n_streams contexts/streams, eager; a step = one frame ----
+    inner = args.inner_reps if (args.inner_reps and args.workload == "config2") else 9600
+    inner = max(batch, inner // batch * batch)
+
+    def run_step(_i):
+        for u in range(inner // batch):
+            run_group(u)
+
+    def fork_join_step(i):  # the side streams start after / are joined into the timing stream
+        for s_ in streams[1:]:
+            s_.wait_stream(stream)
+        run_step(i)
+        for s_ in streams[1:]:
+            stream.wait_stream(s_)
+
+    elapsed = timed_steps(e, fork_join_step, steps, warmup)
+    value = n_meshlets * world * steps * inner / elapsed
+    batched = {"value": round(value, 1), "ms_per_frame": round(elapsed * 1e3 / (steps * inner), 6), "frames_per_launch": batch, "streams": n_streams,
+               "frames_timed": steps * inner, "seconds": round(elapsed, 3)}
+
+    # ---- (b) one call per frame, one stream: a HIP graph of one rotation through the copies ----
+    one_stream[0] = True
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1, stream=stream):
+        for s in st_:
+            check(r, lib.oxc_cull_geometry(r._ctx, s.pf, s.pc, sps[0]))
+    reps1 = max(2, (steps * inner // 4) // copies)
+
+    def replay(_i):
+        for _ in range(reps1):
+            g1.replay()
+
+    el1 = timed_steps(e, replay, 1, 1)
+    single = {"value": round(n_meshlets * world * reps1 * copies / el1, 1), "ms_per_frame": round(el1 * 1e3 / (reps1 * copies), 6), "frames_per_launch": 1, "streams": 1,
+              "hip_graph": True, "frames_timed": reps1 * copies, "seconds": round(el1, 3)}
+    del g1
+
+    # ---- per-kernel times on one stream (>= 50 batched launches) and the roofline of the dominant kernel ----
+    n_prof = max(50, min(len(groups), 96))
+    kern = profile_kernels(e, renderers, run_group, n_prof)
+    one_stream[0] = False
+    kernels = {}
+    for name, k in kern.items():
+        kernels[name] = k if name.startswith("_") else {"launches_timed": k["launches"], "avg_us": round(k["avg_us"], 3)}
+    stream_gbps = stream_read_ceiling(e)
+    roofline = None
+    if "cull_meshlets_test" in kern:
+        # SURVEY 8d: 8 B MeshletInstance + 16 B MeshletBounds per meshlet + per-mesh tables 212/K B; the 4*v B of index writes are
+        # done by cull_meshlets_emit and are NOT charged to this kernel (its ballots: 1/8 B per meshlet written)
+        bytes_per_launch = n_meshlets * batch * (24.0 + 212.0 / K + 0.125)
+        us = kern["cull_meshlets_test"]["avg_us"]
+        achieved = bytes_per_launch / (us * 1e-6) / 1e9
+        traffic, src = pmc_traffic("r02_config2_pmc.json", lambda k: "k_cull_meshlets_test_batch" in k)
+        if traffic is None:
+            traffic, src = pmc_traffic("r01_config2_pmc.json", lambda k: "k_cull_meshlets_test_batch" in k)
+        roofline = {"bound": "hbm", "kernel": f"k_cull_meshlets_test_batch ({batch} frames per launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    "kernel_avg_us": round(us, 3), "launches_averaged": kern["cull_meshlets_test"]["launches"], "measured_stream_read_GBps": round(stream_gbps, 1),
+                    "frac_of_measured_stream_read": round(achieved / stream_gbps, 4)}
+        stage_bytes = n_meshlets * (24.0 + 212.0 / K + 4.0 * visible_fraction)
+        batched["stage_frac"] = round(stage_bytes / (batched["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        single["stage_frac"] = round(stage_bytes / (single["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_scene is not None:
+    if with_cpu and rank == 0 and world == 1 and cpu_scene is not None:
         import oracle
 
         cores = usable_cores()
         cam = cpu_scene.cull_camera()
-        t1c0 = time.perf_counter()
+        t0 = time.perf_counter()
         oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=1)
-        dt1 = time.perf_counter() - t1c0
-        # calibrate on a short multi-threaded run (thread scaling on the box is not known in advance),
-        # then size the sample to ~cpu_seconds of wall time
+        dt1 = time.perf_counter() - t0
         cal = 8
         while True:  # grow the calibration run until thread start-up no longer dominates it
             tc = time.perf_counter()
@@ -759,52 +713,106 @@ def main():
                 break
             cal *= 4
         passes = int(min(max(1, args.cpu_seconds / (t_cal / cal)), 1_000_000))
-        t_cpu0 = time.perf_counter()
+        t0 = time.perf_counter()
         oracle.cull_meshlets(cpu_scene, cam, cpu_scene.meshlet_instances, nthreads=cores, passes=passes)
-        dt = time.perf_counter() - t_cpu0
+        dt = time.perf_counter() - t0
         cpu_baseline = {"value": round(n_meshlets * passes / dt, 1), "unit": "meshlets/s", "cores": cores, "kind": "port",
-                        "sample": f"{passes} passes over the same {n_meshlets}-meshlet scene (copy 0), oracle/oxcull_oracle.c "
-                                  f"orc_cull_meshlets_mt_passes, static range split over {cores} pthreads, {dt:.1f} s",
-                        "single_thread_value": round(n_meshlets / dt1, 1)}
-
-    if rank == 0:
-        line = {
-            "metric": "meshlets/s culled",
-            "value": round(value, 1),
-            "unit": "meshlets/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 6),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": ("configs[1]: 1M meshlets, one camera, frustum+cone cull + ordered compaction (cull_meshlets stage)"
-                             if not (full or multiview) else
-                             "configs[2]: 10M meshlets + 4096^2 HiZ (13 mips) from 8192^2 depth: hiz build + early/late occlusion cull + triangle cull + compaction"
-                             if full else
-                             f"configs[4]: 10M meshlets x {args.views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"),
-                "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris if full else None,
-                "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
-                "hip_graph": graph is not None, "streams": n_streams, "frames_per_launch": (view_batch if multiview else steps_per_call), "visible_fraction": round(visible_fraction, 4),
-                "sharding": (f"contiguous range per rank x{world}; all-gather of per-rank counters"
-                             + ("; HiZ built on rank 0 and broadcast" if full else "")) if world > 1 else "single GPU",
-            },
-            "bit_match": bit_match,
-            "single_stream": single,
-            "counts": counts,
-            "kernels": kernels,
-            "roofline": roofline,
-            "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
-    for rr in renderers:
+                        "sample": f"{passes} passes over the same {n_meshlets}-meshlet scene (copy 0), oracle/oxcull_oracle.c orc_cull_meshlets_mt_passes, "
+                                  f"static range split over {cores} pthreads, {dt:.1f} s", "single_thread_value": round(n_meshlets / dt1, 1)}
+    for rr in renderers[1:]:
         rr.close()
+    return {
+        "workload": "configs[1]: 1M meshlets, one camera, frustum + cone cull + ordered compaction (cull_meshlets stage)",
+        "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
+        "visible_fraction": round(visible_fraction, 4), "bit_match": bit_match, "batched": batched, "one_call_per_frame": single, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[0]: ~1k entities, ECS transform update + host AABB frustum test (CPU only, the reference's own runnable case)
+# ------------------------------------------------------------------------------------------------------------------
+def bench_config1(args):
+    """BASELINE configs[0].  No GPU: the engine's coarse cull is host code (Scene.cpp:1690-1740 world-matrix chain through
+    parents, BoundingVolume.cpp:32-53 AABB::get_transformed, :72-88 AABB::is_on_frustum against Camera::get_frustum,
+    Camera.cpp:57-74).  The scalar C restatement (oracle/) IS the implementation measured here -- there is no HIP path for
+    1 000 entities (one launch costs more than the whole update) -- so this line carries no roofline.  All-core figure: one
+    independent 1 000-entity scene per host thread."""
+    import threading
+
+    import numpy as np
+
+    import oracle
+    from oxylus_amd.synth import camera_frustum_planes, make_entities
+
+    oracle.build()
+    n = args.entities
+    trs, parent, aabb = make_entities(n, depth=3)
+    planes = camera_frustum_planes([0.0, 2.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], 60.0, 16.0 / 9.0, 0.1, 1000.0)
+    _, vis, nvis = oracle.entities_update_and_cull(trs, parent, aabb, planes)
+    t0 = time.perf_counter()
+    oracle.entities_update_and_cull(trs, parent, aabb, planes, passes=200)
+    per_pass = (time.perf_counter() - t0) / 200
+    passes = int(max(200, min(args.cpu_seconds / 2 / per_pass, 5_000_000)))
+    t0 = time.perf_counter()
+    oracle.entities_update_and_cull(trs, parent, aabb, planes, passes=passes)
+    dt1 = time.perf_counter() - t0
+    cores = usable_cores()
+    threads = [threading.Thread(target=oracle.entities_update_and_cull, args=(trs.copy(), parent.copy(), aabb.copy(), planes), kwargs={"passes": passes}) for _ in range(cores)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dtn = time.perf_counter() - t0
+    one, allc = n * passes / dt1, n * passes * cores / dtn
+    print(json.dumps({
+        "metric": "entities/s (ECS transform update + AABB frustum test, host)", "value": round(allc, 1), "unit": "entities/s", "n_gpus": 0, "steps": passes,
+        "warmup": 200, "ms_per_step": round(dtn / passes * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[0]: {n} entities in parent chains of depth 3: world = parent * T*R*S, world AABB = baked.get_transformed(world), "
+                               "AABB::is_on_frustum against Camera::get_frustum (60 deg, 16:9, 0.1..1000)", "entities": n, "visible": nvis, "threads": cores,
+                   "scenes_in_flight": cores},
+        "single_thread_value": round(one, 1), "roofline": None,
+        "cpu_baseline": {"value": round(one, 1), "unit": "entities/s", "cores": 1, "kind": "port",
+                         "sample": f"{passes} updates of the same {n}-entity scene, oracle/oxcull_oracle.c orc_entities_update_and_cull, one thread, {dt1:.1f} s"}}))
+
+
+def main():
+    args = parse()
+    if args.workload == "config1":
+        return bench_config1(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
+    e = setup(args)
+    if args.workload in ("bounds", "loop", "vsm", "config5"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_aux
+
+        fn = {"bounds": bench_aux.bench_bounds, "loop": bench_aux.bench_loop, "vsm": bench_aux.bench_vsm, "config5": bench_aux.bench_config5}[args.workload]
+        if args.steps == 20 and args.warmup == 5:  # these workloads cap their own step counts; keep the old defaults
+            args.steps, args.warmup = 50, 5
+        return fn(args, e.r, e.dev, e.stream, e.rank, e.world, e.dist)
+    if args.workload == "config2":
+        res = bench_config2(args, e, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)
+        if e.rank == 0:
+            b = res["batched"]
+            print(json.dumps({
+                "metric": "meshlets/s culled", "value": b["value"], "unit": "meshlets/s", "n_gpus": e.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(b["seconds"] * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "config": {"workload": res["workload"], "inner_reps": b["frames_timed"] // args.steps, **{k: res[k] for k in
+                                                ("meshlets_per_gpu", "mesh_instances", "copies_rotated", "working_set_MB", "visible_fraction")},
+                                                "frames_per_launch": b["frames_per_launch"], "streams": b["streams"]},
+                "bit_match": res["bit_match"], "batched": b, "one_call_per_frame": res["one_call_per_frame"], "kernels": res["kernels"], "roofline": res["roofline"],
+                "cpu_baseline": res["cpu_baseline"]}))
+    else:
+        line = bench_config3(args, e)
+        if e.world == 1 and not args.no_configs1:
+            line["configs1"] = bench_config2(args, e, steps=8, warmup=1, with_cpu=not args.no_cpu_baseline)
+        if e.rank == 0:
+            print(json.dumps(line))
+    if e.dist is not None:
+        e.dist.destroy_process_group()
+    e.r.close()
 
 
 if __name__ == "__main__":

@@ -432,6 +432,10 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* frame, con
 oxc_status oxc_comm_unique_id(oxc_ctx* ctx, void* id128_host_out);
 oxc_status oxc_comm_init(oxc_ctx* ctx, const void* id128_host, uint32_t rank, uint32_t world);
 oxc_status oxc_comm_destroy(oxc_ctx* ctx);
+/* Packs the counters of `context`'s last oxc_cull_geometry call -- {meshlets emitted (cull_triangles_cmd.x), early, late
+ * (visibility_buffer), index_count (draw_geometry_cmd)} -- into counts4_dptr (device, u32[4]) on the stream: the input of
+ * oxc_exchange_counts, without a host round trip.  Usable on one GPU as well. */
+oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* context, void* counts4_dptr, void* hip_stream);
 /* all-gather of 4 u32 per rank: counts4_dptr (this rank's {emitted, early, late, index_count}) -> all_counts_dptr[world][4] */
 oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all_counts_dptr, void* hip_stream);
 /* broadcast of every level of `hiz` from rank `root` (in place) */

@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
         l.orc_cull_triangles_mt.restype = u32
         l.orc_entities_update_and_cull.argtypes = [u32, vp, vp, vp, vp, vp, vp]
         l.orc_entities_update_and_cull.restype = u32
+        l.orc_entities_update_and_cull_passes.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32]
+        l.orc_entities_update_and_cull_passes.restype = u32
         l.orc_draw_visbuffer.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, u32, u32, vp]
         l.orc_draw_visbuffer.restype = None
         l.orc_resolve_visbuffer.argtypes = [vp, u32, u32, vp, vp]
@@ -279,6 +281,16 @@ def cull_triangles(scene, cam, meshlet_instances: torch.Tensor, visible: torch.T
         n = lib().orc_cull_triangles(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
                                      _p(cam), _p(out), C.c_void_p(C.addressof(stats)) if stats is not None else C.c_void_p(None))
     return out[:n].clone()
+
+
+def entities_update_and_cull(trs10: np.ndarray, parent: np.ndarray, aabb6: np.ndarray, planes24: np.ndarray, passes: int = 1):
+    """BASELINE configs[0] harness (Scene.cpp:1690-1711 world-matrix chain, BoundingVolume.cpp:32-53,72-88): returns
+    (world f32 [n,16], visible u8 [n], count).  The ctypes call releases the GIL, so Python threads scale it."""
+    n = trs10.shape[0]
+    world = np.zeros((n, 16), dtype=np.float32)
+    vis = np.zeros(n, dtype=np.uint8)
+    cnt = lib().orc_entities_update_and_cull_passes(n, _p(trs10), _p(parent), _p(aabb6), _p(planes24), _p(world), _p(vis), max(1, passes))
+    return world, vis, int(cnt)
 
 
 def make_hpb(data: torch.Tensor, width: int, height: int, layers: int, levels: int, level_offset_bytes) -> Hpb:

@@ -867,6 +867,14 @@ uint32_t orc_entities_update_and_cull(uint32_t n, const float* trs10, const int3
   return nvis;
 }
 
+/* `passes` repetitions of the whole update (timing loop of bench.py --workload config1; results identical). */
+uint32_t orc_entities_update_and_cull_passes(uint32_t n, const float* trs10, const int32_t* parent, const float* aabb6,
+                                             const float* planes24, float* world_out, uint8_t* visible_out, uint32_t passes) {
+  uint32_t nvis = 0;
+  for (uint32_t p = 0; p < (passes ? passes : 1u); p++) nvis = orc_entities_update_and_cull(n, trs10, parent, aabb6, planes24, world_out, visible_out);
+  return nvis;
+}
+
 /* ------------------------------------------------------------------------------------------
  * meshlet bounds producer.  See the header for provenance (meshoptimizer v1.2 is a
  * third-party dependency absent from /root/reference; its published algorithm is restated).

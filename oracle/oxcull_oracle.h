@@ -229,6 +229,8 @@ uint32_t orc_cull_triangles_mt(const orc_mesh* meshes, const float* transforms, 
 uint32_t orc_entities_update_and_cull(uint32_t n, const float* trs10 /* t3 q4 s3 */, const int32_t* parent,
                                       const float* aabb_min_max6, const float* frustum_planes24, float* world_out16,
                                       uint8_t* visible_out);
+uint32_t orc_entities_update_and_cull_passes(uint32_t n, const float* trs10, const int32_t* parent, const float* aabb_min_max6,
+                                             const float* frustum_planes24, float* world_out16, uint8_t* visible_out, uint32_t passes);
 
 /* ---- meshlet bounds producer (asset side) --------------------------------------
  * Restates the loop body of Oxylus/src/Asset/AssetManager_GLTF.cpp:573-578 (position quantisation) and

@@ -1154,6 +1154,17 @@ oxc_status oxc_comm_destroy(oxc_ctx* ctx) {
   return OXC_OK;
 }
 
+oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, void* counts4_dptr, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!c || c->struct_size != sizeof(oxc_cull_geometry_context) || !counts4_dptr) return fail(ctx, OXC_INVALID_ARG, "pack_counters: bad context struct or null output");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
+  launch_pack_counters(static_cast<const uint32_t*>(c->visibility_buffer.dptr), static_cast<const uint32_t*>(c->cull_triangles_cmd_buffer.dptr),
+                       static_cast<const uint32_t*>(c->draw_geometry_cmd_buffer.dptr), static_cast<uint32_t*>(counts4_dptr), static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
 oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all_counts_dptr, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   if (!ctx->comm) return fail(ctx, OXC_INVALID_ARG, "exchange_counts: oxc_comm_init has not been called");

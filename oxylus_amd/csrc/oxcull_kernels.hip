@@ -1327,6 +1327,15 @@ __global__ __launch_bounds__(256) void k_seed_slot(uint32_t* slot, uint32_t tota
   }
 }
 
+__global__ __launch_bounds__(64) void k_pack_counters(const uint32_t* vis, const uint32_t* tri_cmd, const uint32_t* draw_cmd, uint32_t* out4) {
+  if (threadIdx.x == 0) {
+    out4[0] = tri_cmd ? tri_cmd[0] : 0u;
+    out4[1] = vis ? vis[1] : 0u;
+    out4[2] = vis ? vis[2] : 0u;
+    out4[3] = draw_cmd ? draw_cmd[0] : 0u;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ p, uint64_t n16, uint32_t* sink) {
   uint32_t acc = 0;
   // one contiguous 16 KiB tile per block iteration: four independent 16 B loads in flight per lane
@@ -1560,6 +1569,9 @@ void launch_hiz(const HizArgs& a, hipStream_t s) {
   }
 }
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s) { hipLaunchKernelGGL(k_seed_slot, dim3(1), dim3(64), 0, s, slot, total); }
+void launch_pack_counters(const uint32_t* vis, const uint32_t* tri_cmd, const uint32_t* draw_cmd, uint32_t* out4, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_counters, dim3(1), dim3(64), 0, s, vis, tri_cmd, draw_cmd, out4);
+}
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(p), bytes / 16, sink);
 }

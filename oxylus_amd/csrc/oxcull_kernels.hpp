@@ -294,6 +294,7 @@ void launch_meshlets_emit_batch(const BatchElem* dev, uint32_t count, uint32_t g
 void launch_tris_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
 void launch_tris_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
+void launch_pack_counters(const uint32_t* vis, const uint32_t* tri_cmd, const uint32_t* draw_cmd, uint32_t* out4, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
 struct DebugProjectArgs {

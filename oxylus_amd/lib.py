@@ -254,6 +254,7 @@ EXPORTS = [
     "oxc_comm_unique_id",
     "oxc_comm_init",
     "oxc_comm_destroy",
+    "oxc_pack_counters",
     "oxc_exchange_counts",
     "oxc_broadcast_hiz",
     "oxc_debug_read_u32",
@@ -314,6 +315,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_comm_unique_id.argtypes = [vp, vp]
     lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     lib.oxc_comm_destroy.argtypes = [vp]
+    lib.oxc_pack_counters.argtypes = [vp, C.POINTER(CullGeometryContext), vp, vp]
     lib.oxc_exchange_counts.argtypes = [vp, vp, vp, vp]
     lib.oxc_broadcast_hiz.argtypes = [vp, C.POINTER(Image), C.c_uint64, C.c_uint32, vp]
     lib.oxc_debug_project_aabb.argtypes = [vp, C.POINTER(C.c_float), C.c_float, vp, C.c_uint32, vp, vp]

@@ -384,6 +384,10 @@ class RendererInstance:
     def comm_destroy(self):
         self._check(self._lib.oxc_comm_destroy(self._ctx))
 
+    def pack_counters(self, context: CullGeometryContext, counts4: torch.Tensor, stream=None):
+        """{emitted, early, late, index_count} of the context's last call -> counts4 (int32 [4], device), on the stream."""
+        self._check(self._lib.oxc_pack_counters(self._ctx, C.byref(context._c), C.c_void_p(counts4.data_ptr()), self._stream(stream)))
+
     def exchange_counts(self, counts4: torch.Tensor, stream=None) -> torch.Tensor:
         """counts4: int32 [4] on the device -> int32 [world, 4] (all-gather on the stream)."""
         out = torch.empty((self._comm_world, 4), dtype=torch.int32, device=counts4.device)

@@ -133,6 +133,35 @@ class Scene:
     def clone(self) -> "Scene":
         return self.to(self.device)
 
+    def prefix(self, m: int, device=None) -> "Scene":
+        """The sub-scene made of the first `m` mesh instances with everything they reference, copied to `device`
+        (default: this scene's).  Needs one mesh per instance (share_meshes == 0): the blob arrays are mesh-major, so the
+        sub-scene is a prefix of every array and all offsets stay valid.  bench.py uses it to hand the CPU checker a
+        bounded sample of the very arrays the GPU culls."""
+        assert self.spec.share_meshes == 0 and 0 < m <= self.n_mesh_instances
+        device = torch.device(device) if device is not None else self.device
+        L, K, t = self.spec.lod_count, self.spec.meshlets_per_mesh, self._lod_tables
+        full = m == self.n_meshes
+
+        def end(table, per, total):
+            return int(total) if full else int(table[m * per].item())
+
+        n_meshlets = end(t["meshlet_start"], L, self.bounds.shape[0])
+        if self.spec.with_geometry:
+            n_vidx, n_micro = end(t["vidx_start"], L, self.vidx.shape[0]), end(t["micro_start"], L, self.micro.shape[0])
+            n_pos = end(t["mesh_vertex_start"], 1, self.positions.shape[0])
+        else:
+            n_vidx, n_micro, n_pos = self.vidx.shape[0], self.micro.shape[0], self.positions.shape[0]
+        cp = lambda x: x.to(device).contiguous().clone()  # noqa: E731
+        tables = {"meshlet_start": t["meshlet_start"][: m * L], "vidx_start": t["vidx_start"][: m * L], "micro_start": t["micro_start"][: m * L],
+                  "mesh_vertex_start": t["mesh_vertex_start"][:m]}
+        spec = SceneSpec(**{**self.spec.__dict__, "n_mesh_instances": m})
+        s = Scene(spec=spec, device=device, bounds=cp(self.bounds[:n_meshlets]), meshlets=cp(self.meshlets[:n_meshlets]), micro=cp(self.micro[:n_micro]),
+                  vidx=cp(self.vidx[:n_vidx]), positions=cp(self.positions[:n_pos]), lods=cp(self.lods[: m * L]), meshes=cp(self.meshes[:m]),
+                  transforms=cp(self.transforms[:m]), mesh_instances=cp(self.mesh_instances[:m]), meshlet_instances=cp(self.meshlet_instances[: m * K]),
+                  camera=self.camera, n_meshes=m, lod_meshlet_counts=self.lod_meshlet_counts, _lod_tables=tables)
+        return s.bind()
+
     def algorithmic_bytes_meshlet_stage(self, visible_fraction: float) -> float:
         """8 B MeshletInstance + 16 B MeshletBounds read, 4*v B written, per-mesh
         tables (20+64+64+64 B) amortised over K meshlets."""
@@ -320,6 +349,47 @@ def make_scene(spec: SceneSpec, device="cpu") -> Scene:
                   meshlet_instances=meshlet_instances, camera=camera, n_meshes=n_meshes,
                   lod_meshlet_counts=lod_counts, _lod_tables=tables)
     return scene.bind()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[0]: ~1k entities, ECS transform update + host AABB frustum test (harness input)
+# ---------------------------------------------------------------------------------------------
+def camera_frustum_planes(position, forward, right, up, fov_deg: float, aspect: float, near: float, far: float):
+    """Camera::get_frustum (Oxylus/src/Render/Camera.cpp:57-74) -> float32 [6, 4] {unit normal, distance = dot(normal, point)}
+    (Frustum.hpp:7-18) in the order top, bottom, right, left, far, near."""
+    import numpy as np
+
+    p, f, r, u = (np.asarray(v, dtype=np.float64) for v in (position, forward, right, up))
+    half_v = far * math.tan(math.radians(fov_deg) * 0.5)
+    half_h = half_v * aspect
+    ff = far * f
+    faces = [(p, np.cross(r, ff - u * half_v)), (p, np.cross(ff + u * half_v, r)), (p, np.cross(ff - r * half_h, u)), (p, np.cross(u, ff + r * half_h)),
+             (p + ff, -f), (p + near * f, f)]
+    out = np.zeros((6, 4), dtype=np.float32)
+    for i, (pt, n) in enumerate(faces):
+        n = n / np.linalg.norm(n)
+        out[i, :3], out[i, 3] = n, float(n @ pt)
+    return out
+
+
+def make_entities(n: int = 1000, depth: int = 3, seed: int = 0x0A1DE5 + 1):
+    """`n` entities in parent chains of length `depth` (entity i's parent is i - 1 unless i starts a chain), each with a
+    TransformComponent {translation, quaternion wxyz, scale} (Scene.cpp:1690-1711) and a baked AABB {min, max}.
+    Returns (trs10 f32 [n,10], parent i32 [n], aabb6 f32 [n,6]) -- numpy, host memory (this path never touches the GPU)."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    trs = np.zeros((n, 10), dtype=np.float32)
+    root = (np.arange(n) % depth) == 0
+    trs[:, 0:3] = np.where(root[:, None], rng.uniform(-150.0, 150.0, (n, 3)) * np.array([1.0, 0.3, 1.0]), rng.uniform(-4.0, 4.0, (n, 3)))
+    q = rng.standard_normal((n, 4))
+    trs[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    trs[:, 7:10] = rng.uniform(0.5, 2.0, (n, 1))
+    parent = np.where(root, -1, np.arange(n) - 1).astype(np.int32)
+    half = rng.uniform(0.25, 2.0, (n, 3)).astype(np.float32)
+    centre = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    aabb = np.concatenate([centre - half, centre + half], axis=1).astype(np.float32)
+    return np.ascontiguousarray(trs), parent, np.ascontiguousarray(aabb)
 
 
 # ---------------------------------------------------------------------------------------------
