@@ -361,7 +361,7 @@ oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* c, vo
   OXC_ORDER(ctx, hip_stream);
   {
     KernelTimer t(ctx, OXC_K_HIZ, static_cast<hipStream_t>(hip_stream));
-    launch_hiz(a, static_cast<hipStream_t>(hip_stream));
+    launch_hiz(a, ctx->num_cus, static_cast<hipStream_t>(hip_stream));
   }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;

@@ -10,6 +10,7 @@
 // the partial-word updates of the persistent visibility mask.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "oxcull_device.hpp"
@@ -1558,8 +1559,13 @@ void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid,
   else
     hipLaunchKernelGGL((k_cull_triangles_emit<false, false>), g, b, 0, s, a);
 }
-void launch_hiz(const HizArgs& a, hipStream_t s) {
+void launch_hiz(const HizArgs& a, uint32_t num_cus, hipStream_t s) {
   if (a.w % 64 == 0 && a.h % 64 == 0) {
+    // (A persistent form -- blocks walking tiles with the next tile's loads issued before the current tile's stores, one barrier
+    // per tile -- was measured in round 2: 81 us against 77 us, byte-identical.  tools/hiz_probe.hip shows why nothing of that kind
+    // helps: reading every other row of an 8192^2 image that is not cache-resident runs at ~4.5 TB/s of line traffic (30 us) in
+    // EVERY tile shape, whole rows included; the rest of the kernel is its 90 MB of stores.)
+    (void)num_cus;
     hipLaunchKernelGGL(k_hiz_tile, dim3(a.w / 64, a.h / 64), dim3(256), 0, s, a);
     if (a.levels > 7) hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, s, a, 6u);
   } else {

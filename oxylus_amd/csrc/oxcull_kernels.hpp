@@ -284,7 +284,7 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
 void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
-void launch_hiz(const HizArgs& a, hipStream_t s);
+void launch_hiz(const HizArgs& a, uint32_t num_cus, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch
 void launch_prepare_batch(const BatchBlob& blob, BatchElem* dev, uint32_t grid, hipStream_t s);
 void launch_scan_batch(const BatchElem* dev, uint32_t count, hipStream_t s);
