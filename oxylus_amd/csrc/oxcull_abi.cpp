@@ -52,11 +52,6 @@ struct oxc_ctx {
     uint64_t* tri_masks = nullptr;
     uint32_t* t_chunk_counts = nullptr;
     uint32_t* t_supers = nullptr;
-    // hand-over buffers of the two-launch HiZ meshlet path (lane 0 only: the batched path is plain-pipeline only)
-    uint4* cand_rec = nullptr;
-    uint64_t* bits2 = nullptr;
-    uint2* group_desc = nullptr;
-    uint32_t* mask_index = nullptr;
   };
   Lane lane[kMaxBatch];
   BatchElem* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call (kMaxBatch elements)
@@ -160,8 +155,6 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
-  const uint64_t groups = cdiv(N, 64), hz = lane_index == 0 ? 1u : 0u;
-  const uint64_t o_rec = carve(hz * groups * 64 * 16), o_bits2 = carve(hz * groups * 8), o_gdesc = carve(hz * groups * 8), o_midx = carve(hz * groups * 64 * 4);
   OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old arena
   if (L->arena) OXC_HIP(ctx, hipFree(L->arena));
   L->arena = nullptr;
@@ -183,10 +176,6 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
   L->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
-  L->cand_rec = reinterpret_cast<uint4*>(b + o_rec);
-  L->bits2 = reinterpret_cast<uint64_t*>(b + o_bits2);
-  L->group_desc = reinterpret_cast<uint2*>(b + o_gdesc);
-  L->mask_index = reinterpret_cast<uint32_t*>(b + o_midx);
   L->cap_mesh_instances = M;
   L->cap_meshlets = N;
   return OXC_OK;
@@ -548,27 +537,14 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
     {
-      const bool split = c->use_hiz && meshlets_hiz_is_split(occl, late);
-      if (split) {  // frustum + cone over the whole list, then occlusion over the candidates only
-        ta.cand_rec = ctx->lane[0].cand_rec;
-        ta.bits2 = ctx->lane[0].bits2;
-        ta.group_desc = ctx->lane[0].group_desc;
-        ta.mask_index = ctx->lane[0].mask_index;
-        {
-          KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
-          launch_meshlets_pre(ta, occl, late, std::min(m_chunks, max_grid), s);
-        }
-        KernelTimer t(ctx, late ? OXC_K_MESHLETS_OCCLUSION_LATE : OXC_K_MESHLETS_OCCLUSION, s);
-        launch_meshlets_occlusion(ta, occl, late, m_chunks, ctx->num_cus, s);
-      } else {
+      {
         KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
         launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, s);
       }
       MeshletEmitArgs ea;
       ea.n_host = n_host;
       ea.n_cap = N;
-      // meshlets per published count: the occlusion kernel publishes one per 1024-meshlet chunk, the one-launch kernels one per wave step
-      ea.count_meshlets = split ? kMeshletChunk : (c->use_hiz ? 64u * kHizGroupsPerWave : 64u * kPlainGroups);
+      ea.count_meshlets = c->use_hiz ? 64u * kHizGroupsPerWave : 64u * kPlainGroups;  // one count per wave step: 64 * groups per wave
       ea.bits = ctx->lane[0].bits;
       ea.chunk_counts = ctx->lane[0].m_chunk_counts;
       ea.supers = ctx->lane[0].m_supers;

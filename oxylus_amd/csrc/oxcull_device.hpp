@@ -54,13 +54,6 @@ OXC_DEV uint4 load_global_u4(uint64_t base, uint32_t index) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-OXC_DEV void store_global_u2(uint64_t base, uint32_t index, uint2 v) {
-  reinterpret_cast<u32x2_t __attribute__((address_space(1)))*>(base)[index] = u32x2_t{v.x, v.y};
-}
-OXC_DEV void store_global_u4(uint64_t base, uint32_t index, uint4 v) {
-  reinterpret_cast<u32x4_t __attribute__((address_space(1)))*>(base)[index] = u32x4_t{v.x, v.y, v.z, v.w};
-}
-
 // Streamed-once variants (`nt`: the line is not kept in the caches; tools/bw_probe.hip measures 7.0 vs 6.2 TB/s for
 // pure streaming reads on this chip).
 OXC_DEV uint32_t load_stream_u32(uint64_t base, uint32_t index) {

@@ -576,32 +576,13 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   const uint32_t last_index = N ? N - 1u : 0u;
   const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
 
-#ifdef OXC_HIZ_PREFETCH
-  // This kernel's residency is bounded by its LDS (pyramid top + strips), not by registers, and a wave step is a chain of four
-  // dependent memory round trips (records -> row -> bounds / mask -> pyramid taps): the next step's MeshletInstance records are
-  // fetched one step ahead (8 spare VGPRs), which takes the first round trip off the chain.
-  uint2 rec_next[G];
-#pragma unroll
-  for (int j = 0; j < G; j++) rec_next[j] = OXC_LOAD_MLI(mlis, min(((blockIdx.x * 16 + wave * G) + j) * 64 + lane, last_index));
-#endif
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint32_t group0 = chunk * 16 + wave * G;
     uint2 rec[G];
     uint32_t st[G];        // bit 0: still to be decided, bit 1: visible, bit 2: was_visible
     uint32_t mask_idx[G];  // bit index into the persistent visibility mask
-#ifdef OXC_HIZ_PREFETCH
-    {
-      const uint32_t ngroup0 = (chunk + gridDim.x) * 16 + wave * G;  // (clamped: the last step of a block re-reads the list's tail)
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        rec[j] = rec_next[j];
-        rec_next[j] = OXC_LOAD_MLI(mlis, min((ngroup0 + j) * 64 + lane, last_index));
-      }
-    }
-#else
 #pragma unroll
     for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
-#endif
 #pragma unroll
     for (int j = 0; j < G; j++) {
       st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
@@ -773,293 +754,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       gptr(a.chunk_counts)[wchunk] = cnt;
       if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Meshlet stage, HiZ variants with TestOcclusion and / or LatePass, as TWO launches (passes/cull_meshlets_hiz.slang:19-88).
-// The fused kernel above carries the occlusion code (8 projected corners, 24 divisions, 4 pyramid taps) in every wave:
-// 97-111 VGPRs, 4 waves per SIMD, for a phase only the frustum / cone survivors (8-26 % of the lanes) run -- it streams the
-// MeshletInstance + bounds arrays at ~2.1-2.6 TB/s.  Split:
-//   k_cull_meshlets_pre        the plain kernel's phases (decode, frustum, cone) + the mask bit lookup, 8 waves per SIMD, over
-//                              the whole list.  Per 64-meshlet group it writes the candidate ballot, the candidates' boxes
-//                              compacted in lane order (16 B each: what the occlusion test needs, so the second launch never
-//                              touches the big arrays again), and how the group's lanes map to mask bits.
-//   k_cull_meshlets_occlusion  per 1024-meshlet chunk: the chunk's candidates in dense lanes through project_aabb +
-//                              test_occlusion (pyramid top in LDS), then back in meshlet order: visible = candidate & !occluded,
-//                              the mask update (cull_meshlets_hiz.slang:81-87), the emit ballot and the chunk count.
-// Same arithmetic in the same order per meshlet as the fused kernel (which is the same as the checker's): same bits.
-// ------------------------------------------------------------------------------------------
-#ifndef OXC_PRE_G
-#define OXC_PRE_G 4
-#endif
-template <bool OCCL, bool LATE, int G>
-OXC_DEV void meshlets_pre_body(const MeshletTestArgs& a) {
-  set_half_denorm_flush();
-  constexpr uint32_t kWaves = 4;
-  constexpr uint32_t kStep = kWaves * G * 64;  // meshlets per block iteration
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
-  const uint32_t nwords = (N + 63u) / 64u;
-  const uint32_t nchunks = (N + kStep - 1) / kStep;
-  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
-  const uint32_t last_index = N ? N - 1u : 0u;
-  const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
-
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t group0 = (chunk * kWaves + wave) * G;
-    uint2 rec[G];
-    uint32_t st[G];   // bit 0: still to be decided, bit 1: occlusion candidate, bit 2: was_visible
-    uint32_t box[G][3];  // the candidate record of this lane: {centre.xy, centre.z | extent.z << 16, extent.xy}
-    uint32_t midx[G];    // bit index into the persistent visibility mask (kMaskNone: none)
-#pragma unroll
-    for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
-      box[j][0] = box[j][1] = box[j][2] = 0u;
-      midx[j] = kMaskNone;
-    }
-    for (;;) {
-      uint32_t mi_u = 0;
-      bool found = false;
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        const uint64_t p = __builtin_amdgcn_ballot_w64((st[j] & 1u) != 0u);
-        if (!found && p) {
-          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)p) - 1);
-          found = true;
-        }
-      }
-      if (!found) break;
-      const kconst32p row = const_row(a.cache, mi_u);
-      const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
-      const uint32_t vis_offset = row[kRowVisOffset];
-      uint4 bnd[G];
-      bool mine[G];
-      uint32_t mword[G];
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
-        bnd[j] = OXC_LOAD_BND(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
-        mword[j] = 1u;
-        if (OCCL) {  // cull_meshlets_hiz.slang:45-51
-          uint32_t mi_bit = vis_offset + (mine[j] ? rec[j].y : 0u);
-          const bool in_mask = mi_bit < a.mask_bits;
-          mi_bit = in_mask ? mi_bit : 0u;
-          midx[j] = mine[j] ? (in_mask ? mi_bit : kMaskNone) : midx[j];
-          mword[j] = load_global_u32(reinterpret_cast<uint64_t>(a.mask), mi_bit >> 5) >> (mi_bit & 31u);
-          mword[j] = in_mask ? mword[j] : 0u;
-        }
-      }
-      // ---- phase 1: bounds decode + frustum
-      uint32_t need[G];
-      uint64_t any_need = 0;
-      {
-        float pl[24], sg[18];
-#pragma unroll
-        for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
-#pragma unroll
-        for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint4 b = bnd[j];
-          const bool was_visible = (mword[j] & 1u) != 0u;
-          need[j] = 0u;
-          if (!LATE && __builtin_amdgcn_ballot_w64(mine[j] && was_visible) == 0) {
-            // early pass and no meshlet of this group was visible last frame: they all return before any test (:45-51)
-            st[j] = mine[j] ? 0u : st[j];
-            continue;
-          }
-          const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16), cz = dequantize_half(b.y & 0xFFFFu);
-          const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16), ez = dequantize_half(b.w & 0xFFFFu);
-          bool vis = mine[j] & (LATE ? true : was_visible);
-          vis = vis & test_frustum_planes(pl, sg, cx, cy, cz, ex, ey, ez);
-          const bool nc = vis & (((int32_t)b.w >> 24) != 127);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
-          need[j] = nc ? 1u : 0u;
-          any_need |= __builtin_amdgcn_ballot_w64(nc);
-          st[j] = mine[j] ? ((vis ? 2u : 0u) | (was_visible ? 4u : 0u)) : st[j];
-          box[j][0] = mine[j] ? b.x : box[j][0];
-          box[j][1] = mine[j] ? ((b.y & 0xFFFFu) | (b.w << 16)) : box[j][1];
-          box[j][2] = mine[j] ? b.z : box[j][2];
-          if (j == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // ---- phase 2: normal cone (decodes again from the 16-byte record: see meshlets_plain_body)
-      if (any_need) {
-        ConeU cu;
-#pragma unroll
-        for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
-#pragma unroll
-        for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
-#pragma unroll
-        for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
-        cu.scale_max = asf(row[kRowScale]);
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
-          uint4 b = bnd[j];
-          asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-          const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
-          const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-          const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
-          const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
-          const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
-          bool cone_ok = tier1 == 1;
-          if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-            const bool exact = cone_visible(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
-            cone_ok = tier1 == 2 ? exact : cone_ok;
-          }
-          st[j] = (need[j] != 0u && !cone_ok) ? (st[j] & ~2u) : st[j];
-        }
-      }
-    }
-    // ---- hand-over to k_cull_meshlets_occlusion, per 64-meshlet group
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      const uint32_t group = group0 + j;
-      if (group >= nwords) continue;  // wave-uniform
-      const bool in_range = group * 64 + lane < N;
-      const bool is_cand = (st[j] & 2u) != 0u;
-      const uint64_t cand = __builtin_amdgcn_ballot_w64(is_cand);
-      const uint64_t was = __builtin_amdgcn_ballot_w64((st[j] & 4u) != 0u);
-      if (lane == 0) {
-        gptr(a.bits)[group] = cand;
-        if (LATE) gptr(a.bits2)[group] = was;
-      }
-      if (is_cand) {
-        const uint32_t slot = group * 64 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cand >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cand, 0u));
-        store_global_u4(reinterpret_cast<uint64_t>(a.cand_rec), slot, make_uint4(box[j][0], box[j][1], box[j][2], rec[j].x));
-      }
-      if (OCCL) {
-        // lane l's mask bit is (d + l) for every lane of a group in the usual case (consecutive meshlets of one instance, or of
-        // instances whose visibility offsets follow each other): then two dwords describe the group
-        const uint32_t d = midx[j] - (uint32_t)lane;
-        const uint64_t inr = __builtin_amdgcn_ballot_w64(in_range);
-        const uint32_t d0 = readlane_u(d, __ffsll((unsigned long long)inr) - 1);
-        const bool uniform = __builtin_amdgcn_ballot_w64(in_range && (midx[j] == kMaskNone || d != d0)) == 0ull;
-        if (lane == 0) store_global_u2(reinterpret_cast<uint64_t>(a.group_desc), group, make_uint2(d0, uniform ? 1u : 0u));
-        if (!uniform) gptr(a.mask_index)[group * 64 + lane] = in_range ? midx[j] : kMaskNone;
-      }
-    }
-  }
-}
-
-template <bool OCCL, bool LATE>
-OXC_DEV void meshlets_occlusion_body(const MeshletTestArgs& a) {
-  set_half_denorm_flush();
-  constexpr uint32_t kGroups = kMeshletChunk / 64;  // 16 groups per chunk
-  __shared__ uint32_t s_level_off[13];
-  __shared__ uint32_t s_lds_off[13];
-  __shared__ float s_hiz_top[kHizLdsTexels];
-  __shared__ uint32_t s_base[kGroups + 1];
-  __shared__ uint8_t s_occ[kMeshletChunk];
-  __shared__ uint32_t s_red[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
-  const uint32_t nwords = (N + 63u) / 64u;
-  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
-  if (threadIdx.x < 13) {
-    s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
-    s_lds_off[threadIdx.x] = a.hiz_lds_off[threadIdx.x];
-  }
-  for (uint32_t k = a.hiz_lds_first; k < a.hiz_levels; k++) {  // the top of the pyramid, once per block
-    const uint32_t n = mip_dim(a.hiz_w, k) * mip_dim(a.hiz_h, k);
-    const float* src = a.hiz_data + a.hiz_level_off[k];
-    float* dst = s_hiz_top + a.hiz_lds_off[k];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-  }
-  __syncthreads();
-  HizView hiz;
-  hiz.data = a.hiz_data;
-  hiz.width = a.hiz_w;
-  hiz.height = a.hiz_h;
-  hiz.levels = a.hiz_levels;
-  hiz.lds = s_hiz_top;
-  hiz.lds_off = s_lds_off;
-  hiz.lds_first = a.hiz_lds_first;
-  const uint64_t bits_base = reinterpret_cast<uint64_t>(a.bits);
-
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t G0 = chunk * kGroups;
-    // ---- candidates per group -> exclusive bases
-    if (wave == 0) {
-      uint32_t c = 0;
-      if (lane < (int)kGroups && G0 + lane < nwords) {
-        const uint2 w = load_global_u2(bits_base, G0 + lane);
-        c = (uint32_t)__popc(w.x) + (uint32_t)__popc(w.y);
-      }
-      const uint32_t incl = wave_incl_scan(c, lane);
-      if (lane < (int)kGroups) s_base[lane + 1] = incl;
-      if (lane == 0) s_base[0] = 0;
-    }
-    __syncthreads();
-    const uint32_t total = s_base[kGroups];
-    // ---- the chunk's candidates in dense lanes: project_aabb + test_occlusion (cull_meshlets_hiz.slang:56-66)
-    for (uint32_t t0 = (uint32_t)wave * 64u; t0 < total; t0 += 256u) {
-      const uint32_t t = t0 + (uint32_t)lane;
-      const bool act = t < total;
-      const uint32_t tt = act ? t : total - 1u;
-      uint32_t g = 0;
-#pragma unroll
-      for (uint32_t k = 1; k < kGroups; k++) g += (s_base[k] <= tt) ? 1u : 0u;
-      const uint4 r = load_global_u4(reinterpret_cast<uint64_t>(a.cand_rec), (G0 + g) * 64u + (tt - s_base[g]));
-      const float qx = dequantize_half(r.x & 0xFFFFu), qy = dequantize_half(r.x >> 16), qz = dequantize_half(r.y & 0xFFFFu);
-      const float rx = dequantize_half(r.z & 0xFFFFu), ry = dequantize_half(r.z >> 16), rz = dequantize_half(r.y >> 16);
-      bool occluded = false;
-      uint64_t pending = __builtin_amdgcn_ballot_w64(act);
-      while (pending) {  // one round per mesh instance among the wave's candidates: mvp travels through scalar loads
-        const uint32_t mi_u = readlane_u(r.w, __ffsll((unsigned long long)pending) - 1);
-        const bool mine = act && r.w == mi_u;
-        const kconst32p row = const_row(a.cache, mi_u);
-        float mvp[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) mvp[k] = asf(row[kRowMvp + k]);
-        const bool o = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, mine);
-        occluded = mine ? o : occluded;
-        pending &= ~__builtin_amdgcn_ballot_w64(mine);
-      }
-      if (act) s_occ[t] = occluded ? 1 : 0;
-    }
-    __syncthreads();
-    // ---- back in meshlet order: visibility, mask, emit ballot
-    uint32_t cnt = 0;
-#pragma unroll 1
-    for (uint32_t jj = 0; jj < kGroups / 4; jj++) {
-      const uint32_t g = (uint32_t)wave * (kGroups / 4) + jj, group = G0 + g;
-      if (group >= nwords) break;  // wave-uniform
-      const uint2 cw = load_global_u2(bits_base, group);
-      const uint64_t cand = (uint64_t)cw.x | ((uint64_t)cw.y << 32);
-      const bool in_range = group * 64 + lane < N;
-      const bool c = ((cand >> lane) & 1ull) != 0ull;
-      const uint32_t rank = s_base[g] + __builtin_amdgcn_mbcnt_hi(cw.y, __builtin_amdgcn_mbcnt_lo(cw.x, 0u));
-      const bool visible = c && s_occ[c ? rank : 0u] == 0;
-      if (OCCL) {
-        const uint2 desc = load_global_u2(reinterpret_cast<uint64_t>(a.group_desc), group);
-        uint32_t idx = desc.x + (uint32_t)lane;
-        if (desc.y == 0u) idx = gptr(a.mask_index)[group * 64 + lane];  // wave-uniform branch
-        update_visibility_mask(a.mask, idx, visible, in_range && idx != kMaskNone, lane);
-      }
-      bool emit = visible;
-      if (LATE) {
-        const uint2 ww = load_global_u2(reinterpret_cast<uint64_t>(a.bits2), group);
-        const uint64_t was = (uint64_t)ww.x | ((uint64_t)ww.y << 32);
-        emit = visible && ((was >> lane) & 1ull) == 0ull;
-      }
-      const uint64_t fin = __builtin_amdgcn_ballot_w64(emit);
-      if (lane == 0) gptr(a.bits)[group] = fin;
-      cnt += (uint32_t)__popcll((unsigned long long)fin);
-    }
-    if (lane == 0) s_red[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      gptr(a.chunk_counts)[chunk] = c;
-      if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();  // s_base / s_occ / s_red are rewritten by the next chunk
   }
 }
 
@@ -1685,23 +1379,12 @@ __global__ __launch_bounds__(1024) void k_scan_mesh_counts(ScanArgs a) { scan_bo
 __global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) { expand_body(a); }
 // (Capping SGPRs at 80 for 8 waves/SIMD -- the compiler otherwise keeps ~106 live -- was measured:
 // plain kernel 36.7 -> 38.8 us per 4M meshlets, HiZ variant 183 -> 175 us; not kept.)
-#ifndef OXC_HIZ_WAVES
-#define OXC_HIZ_WAVES 1
-#endif
 template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
-__global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? OXC_HIZ_WAVES : 1) void k_cull_meshlets_test(MeshletTestArgs a) {
+__global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
   if constexpr (!HIZ)
     meshlets_plain_body<G>(a);
   else
     meshlets_hiz_body<OCCL, LATE, G>(a);
-}
-template <bool OCCL, bool LATE>
-__global__ __launch_bounds__(256) void k_cull_meshlets_pre(MeshletTestArgs a) {
-  meshlets_pre_body<OCCL, LATE, OXC_PRE_G>(a);
-}
-template <bool OCCL, bool LATE>
-__global__ __launch_bounds__(256) void k_cull_meshlets_occlusion(MeshletTestArgs a) {
-  meshlets_occlusion_body<OCCL, LATE>(a);
 }
 template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
@@ -1839,37 +1522,6 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
   } else {
     static const uint32_t cap = resident_grid(k_cull_meshlets_test<true, false, false, kHizGroups>, hb, num_cus);
     hipLaunchKernelGGL((k_cull_meshlets_test<true, false, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
-  }
-}
-bool meshlets_hiz_is_split(bool occl, bool late) {
-#ifdef OXC_HIZ_FUSED
-  (void)occl;
-  (void)late;
-  return false;
-#else
-  return occl || late;
-#endif
-}
-void launch_meshlets_pre(const MeshletTestArgs& a, bool occl, bool late, uint32_t grid, hipStream_t s) {
-  const dim3 g(grid * (4 / OXC_PRE_G)), b(256);
-  if (occl && late)
-    hipLaunchKernelGGL((k_cull_meshlets_pre<true, true>), g, b, 0, s, a);
-  else if (occl)
-    hipLaunchKernelGGL((k_cull_meshlets_pre<true, false>), g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL((k_cull_meshlets_pre<false, true>), g, b, 0, s, a);
-}
-void launch_meshlets_occlusion(const MeshletTestArgs& a, bool occl, bool late, uint32_t chunks, uint32_t num_cus, hipStream_t s) {
-  const dim3 b(256);
-  if (occl && late) {
-    static const uint32_t cap = resident_grid(k_cull_meshlets_occlusion<true, true>, 256, num_cus);
-    hipLaunchKernelGGL((k_cull_meshlets_occlusion<true, true>), dim3(std::min(chunks, cap)), b, 0, s, a);
-  } else if (occl) {
-    static const uint32_t cap = resident_grid(k_cull_meshlets_occlusion<true, false>, 256, num_cus);
-    hipLaunchKernelGGL((k_cull_meshlets_occlusion<true, false>), dim3(std::min(chunks, cap)), b, 0, s, a);
-  } else {
-    static const uint32_t cap = resident_grid(k_cull_meshlets_occlusion<false, true>, 256, num_cus);
-    hipLaunchKernelGGL((k_cull_meshlets_occlusion<false, true>), dim3(std::min(chunks, cap)), b, 0, s, a);
   }
 }
 void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s) { hipLaunchKernelGGL(k_cull_meshlets_hpb_test, dim3(grid), dim3(256), 0, s, a); }

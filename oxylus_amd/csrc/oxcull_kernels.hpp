@@ -71,11 +71,6 @@ struct MeshletTestArgs {
   uint32_t hiz_lds_off[13];   // float offset of each staged level inside the LDS tile
   float near_clip;
   float cam_pos[3];
-  // two-launch HiZ path (k_cull_meshlets_pre -> k_cull_meshlets_occlusion): hand-over buffers in the context's scratch
-  uint4* cand_rec;      // [groups * 64]: per 64-meshlet group, its occlusion candidates compacted in lane order: {centre.xy, centre.z | extent.z << 16, extent.xy, mesh instance}
-  uint64_t* bits2;      // [groups]: LatePass: ballot of was_visible
-  uint2* group_desc;    // [groups]: {mask index of lane 0 (index - lane), 1 = every in-range lane of the group has index = .x + lane}
-  uint32_t* mask_index; // [groups * 64]: per-lane mask indices of the groups that are not uniform (kMaskNone = no bit)
 };
 
 struct MeshletEmitArgs {
@@ -286,10 +281,6 @@ void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s);
 void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* vis, uint32_t* cmd, hipStream_t s);
 void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, void* out, uint32_t grid, hipStream_t s);
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, hipStream_t s);
-// the two-launch HiZ path (TestOcclusion and / or LatePass): frustum + cone over the whole list, then occlusion over the candidates
-bool meshlets_hiz_is_split(bool occl, bool late);
-void launch_meshlets_pre(const MeshletTestArgs& a, bool occl, bool late, uint32_t grid, hipStream_t s);
-void launch_meshlets_occlusion(const MeshletTestArgs& a, bool occl, bool late, uint32_t chunks, uint32_t num_cus, hipStream_t s);
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
 void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
