@@ -1,0 +1,320 @@
+"""GPU parity, round 2: the BASELINE configurations that had no HIP-path test (configs[2] at full size with the triangle stage,
+configs[4] multi-view with per-view LOD), the opt-in small-triangle cull, and the robustness rules the ABI states (calls of one
+context on different streams are ordered, scratch never grows inside a stream capture, device-side list lengths are clamped
+to the caller's buffers)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oxylus_amd import lib as L
+from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame, RendererInstance
+from oxylus_amd.synth import SceneSpec, make_depth, make_scene, virtual_shadow_matrices
+
+from util import assert_same, gpu_frame, oracle_frame, oracle_hiz
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2]: the whole north-star path at FULL size against the checker, every output, bit for bit
+# ------------------------------------------------------------------------------------------------------------------
+def test_config3_full_size_every_output_bit_exact(renderer, oracle_lib):
+    """10M meshlets with unique geometry (~10 GB) + 4096^2 HiZ from an 8192^2 depth + prior mask p = 0.3: HiZ build, early
+    and late meshlet passes, both triangle passes.  The checker runs the same sequence over the WHOLE scene (host copy); the
+    pyramid, both visible lists (1.08M meshlets), both packed index lists (35M triangles), the mask and every counter must be
+    byte-identical, unsorted."""
+    K, M, HW = 1000, 10_000, 4096
+    gpu = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2), "cuda")
+    N = gpu.n_meshlet_instances
+    depth = make_depth(2 * HW, 2 * HW, 64, seed=3, device="cuda")
+    hiz = ImageAttachment.hiz(HW, HW, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    words = (N + 31) // 32
+    bits = (torch.rand((words, 32), generator=g, device="cuda") < 0.3).to(torch.int64)
+    mask0 = (bits << torch.arange(32, device="cuda")).sum(1).to(torch.int32)
+    del bits
+    frame = PreparedFrame.create(gpu, with_triangles=True)
+    frame.meshlet_instance_visibility_mask_buffer.copy_(mask0)
+    renderer.prepared_frame = frame
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
+    ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
+    renderer.seed_meshlet_instances(ctx, N)
+    got = {}
+    for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+        ctx.cull_flags = flags
+        renderer.cull_geometry(ctx)
+        c = renderer.read_counters(ctx)
+        first = c.early_visible_meshlet_instances if tag == "late" else 0
+        got[tag] = (frame.visible_meshlet_instances_indices_buffer[first:first + c.cull_triangles_cmd_x].cpu(), frame.reordered_indices_buffer[:c.draw_index_count].cpu(),
+                    (c.total_visible_meshlet_instances, c.early_visible_meshlet_instances, c.late_visible_meshlet_instances, c.cull_triangles_cmd_x))
+    got_mask = frame.meshlet_instance_visibility_mask_buffer.cpu()
+    got_hiz = hiz.data.cpu()
+    # ---- the checker, whole scene
+    cpu = gpu.to("cpu")
+    del gpu, frame
+    torch.cuda.empty_cache()
+    want_hiz, levels, offs = oracle_hiz(depth.cpu(), HW, HW)
+    assert torch.equal(want_hiz.view(torch.int32), got_hiz.view(torch.int32)), "pyramid differs"
+    hz = oracle.make_hiz(want_hiz, HW, HW, levels, offs)
+    cam = cpu.cull_camera()
+    v = oracle.Visibility(N, 0, 0)
+    out = torch.zeros(N, dtype=torch.int32)
+    mask = mask0.cpu().clone()
+    for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+        n_e = oracle.cull_meshlets_hiz(cpu, cam, cpu.meshlet_instances, flags, hz, v, mask, out)
+        first = v.early if tag == "late" else 0
+        want_vis = out[first:first + n_e]
+        assert got[tag][2] == (N, v.early, v.late, n_e), (tag, got[tag][2], (N, v.early, v.late, n_e))
+        assert torch.equal(got[tag][0], want_vis), f"{tag}: visible list differs"
+        want_idx = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, out, first, n_e, nthreads=16)
+        assert torch.equal(got[tag][1], want_idx), f"{tag}: packed triangle indices differ ({got[tag][1].numel()} vs {want_idx.numel()})"
+    assert torch.equal(got_mask, mask)
+    assert v.early + v.late > 1_000_000  # more than a million visible meshlets went through the triangle stage
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[4]: 16 orthographic cascade views, per-view cull_meshes (frustum + LOD select), one batched call
+# ------------------------------------------------------------------------------------------------------------------
+def _cascade_cameras(scene, views):
+    mats, _, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], [0.3, -1.0, 0.2], 500.0, 2.0, views)  # Shadowmaps.cpp:9-63, doubling extents
+    cams = []
+    for v in range(views):
+        cam = scene.cull_camera()
+        for k in range(16):
+            cam.projection_view[k] = float(mats[v][k])
+        cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
+        cam.near_clip = zn
+        cams.append(cam)
+    return cams
+
+
+def _run_views_batched(renderer, scene, cams, flags):
+    import dataclasses
+
+    frames = [PreparedFrame.create(scene if e == 0 else dataclasses.replace(scene, mesh_instances=scene.mesh_instances.clone()), with_triangles=False, expand=False)
+              for e in range(len(cams))]
+    ctxs = [CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cam, stages=L.STAGE_MESHES | L.STAGE_MESHLETS) for cam in cams]
+    renderer.cull_geometry_batch(frames, ctxs)
+    out = []
+    for f, c in zip(frames, ctxs):
+        cnt = renderer.read_counters(c)
+        out.append({"total": cnt.total_visible_meshlet_instances, "visible": f.visible_meshlet_instances_indices_buffer[:cnt.cull_triangles_cmd_x].cpu(),
+                    "mli": f.meshlet_instances_buffer[:cnt.total_visible_meshlet_instances].cpu(), "lod": f.scene.mesh_instances[:, 1].cpu()})
+    return out
+
+
+def test_config5_cascade_views_per_view_lod_vs_oracle(renderer, oracle_lib):
+    """16 orthographic cascades over a 4-LOD scene: per view the expanded MeshletInstance list (LOD-selected), the lod_index
+    column and the visible list must equal the checker's; the views must differ from each other (several LODs, different counts)."""
+    views = 16
+    cpu = make_scene(SceneSpec(n_mesh_instances=1500, meshlets_per_mesh=96, lod_count=4, seed=0x0A1DE5 + 4, with_geometry=False), "cpu")
+    gpu = cpu.to("cuda")
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+    got = _run_views_batched(renderer, gpu, _cascade_cameras(gpu, views), flags)
+    totals, lods_seen = [], set()
+    for v, cam in enumerate(_cascade_cameras(cpu, views)):
+        s = cpu.clone()  # cull_meshes writes lod_index
+        mli, _ = oracle.cull_meshes(s, cam, flags)
+        vis = oracle.cull_meshlets(s, cam, mli)
+        assert got[v]["total"] == mli.shape[0], f"view {v}"
+        assert torch.equal(got[v]["mli"], mli), f"view {v}: expansion differs"
+        assert torch.equal(got[v]["visible"], vis), f"view {v}: visible list differs"
+        emitted = torch.unique(mli[:, 0].to(torch.int64))
+        assert torch.equal(got[v]["lod"][emitted], s.mesh_instances[emitted, 1]), f"view {v}: lod_index differs"
+        totals.append(mli.shape[0])
+        lods_seen |= set(s.mesh_instances[emitted, 1].tolist())
+    assert len(set(totals)) > 4 and len(lods_seen) > 1, (totals, lods_seen)
+
+
+def test_config5_full_size_properties(renderer, oracle_lib):
+    """configs[4] at full size (10M LOD-0 meshlets x 16 views, one batched call): per view the list is ascending, counts are
+    consistent, the expansion is complete (every record is (instance, 0..count-1) in order) and the batched call equals single
+    calls for two of the views."""
+    views = 16
+    gpu = make_scene(SceneSpec(n_mesh_instances=10_000, meshlets_per_mesh=1000, lod_count=3, seed=0x0A1DE5 + 4, with_geometry=False), "cuda")
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+    cams = _cascade_cameras(gpu, views)
+    got = _run_views_batched(renderer, gpu, cams, flags)
+    lod_counts = torch.tensor(gpu.lod_meshlet_counts)
+    for v in range(views):
+        r = got[v]
+        vis, mli = r["visible"], r["mli"]
+        assert r["total"] == mli.shape[0] and vis.numel() <= r["total"] <= gpu.n_meshlet_instances
+        if vis.numel() > 1:
+            assert bool((vis[1:] > vis[:-1]).all()) and int(vis[-1]) < r["total"]
+        if mli.shape[0]:
+            inst, k = mli[:, 0].to(torch.int64), mli[:, 1].to(torch.int64)
+            assert bool((inst[1:] >= inst[:-1]).all())
+            start = torch.ones_like(inst, dtype=torch.bool)
+            start[1:] = inst[1:] != inst[:-1]
+            assert bool((k[start] == 0).all()) and bool((k[~start] == k[torch.nonzero(~start).squeeze(1) - 1] + 1).all())
+            uniq, cnt = torch.unique_consecutive(inst, return_counts=True)
+            assert torch.equal(cnt, lod_counts[r["lod"][uniq].to(torch.int64)]), "every emitted instance carries all meshlets of its selected LOD"
+    assert got[0]["total"] < got[views - 1]["total"]  # the smallest cascade sees fewer instances than the largest
+    for v in (0, views - 1):
+        frame = PreparedFrame.create(gpu, with_triangles=False, expand=False)
+        renderer.prepared_frame = frame
+        ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cams[v], stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+        renderer.cull_geometry(ctx)
+        c = renderer.read_counters(ctx)
+        assert c.total_visible_meshlet_instances == got[v]["total"]
+        assert torch.equal(frame.visible_meshlet_instances_indices_buffer[:c.cull_triangles_cmd_x].cpu(), got[v]["visible"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# opt-in small-triangle cull (include/oxcull.h: oxc_cull_geometry_context::small_triangle_cull)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("spec,res", [(SceneSpec(n_mesh_instances=40, meshlets_per_mesh=120, seed=31), 256), (SceneSpec(n_mesh_instances=9, meshlets_per_mesh=300, seed=33, ragged=True), 64),
+                                      (SceneSpec(n_mesh_instances=16, meshlets_per_mesh=64, seed=35, nonuniform_scale=True), 4096)], ids=["res256", "ragged-res64", "res4096"])
+def test_small_triangle_cull_on_and_off(renderer, oracle_lib, spec, res):
+    spec.resolution = res
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    cam = cpu.cull_camera()
+    vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances)
+    want_off = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, vis, 0, vis.numel())
+    want_on = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, vis, 0, vis.numel(), small_triangle_cull=True)
+    res_ = {}
+    for on in (False, True):
+        frame = PreparedFrame.create(gpu)
+        renderer.prepared_frame = frame
+        ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), small_triangle_cull=on)
+        renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
+        renderer.cull_geometry(ctx)
+        c = renderer.read_counters(ctx)
+        res_[on] = frame.reordered_indices_buffer[:c.draw_index_count].cpu()
+    assert torch.equal(res_[False], want_off), "flag off must be the reference behaviour"
+    assert torch.equal(res_[True], want_on)
+    assert want_on.numel() < want_off.numel() or res == 4096
+    # what the flag drops is a subset of what the reference keeps
+    assert set(want_on.view(-1, 3)[:, 0].tolist()) <= set(want_off.view(-1, 3)[:, 0].tolist())
+
+
+def test_small_triangle_flag_off_matches_the_round1_fixture(renderer, oracle_lib):
+    """Byte-identical to the committed round-1 fixture (generated before the flag existed) with the flag explicitly off."""
+    from util import scene_from_golden
+
+    s, z = scene_from_golden(os.path.join(HERE, "golden", "pipeline_12x40.npz"), "cuda")
+    frame = PreparedFrame.create(s, expand=False)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_ALL, cull_camera=s.cull_camera(), small_triangle_cull=False)
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    got = frame.reordered_indices_buffer[:c.draw_index_count].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), np.asarray(z["plain_indices"]).view(np.uint32))
+    ctx2 = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_ALL, cull_camera=s.cull_camera(), small_triangle_cull=True)
+    renderer.cull_geometry(ctx2)
+    assert renderer.read_counters(ctx2).draw_index_count <= c.draw_index_count
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ABI rules
+# ------------------------------------------------------------------------------------------------------------------
+def test_calls_of_one_context_on_two_streams_are_ordered(renderer, oracle_lib):
+    """generate_hiz on stream A, then cull_geometry(use_hiz) on stream B with no host or event synchronisation in between: the
+    context orders its own calls on the device (include/oxcull.h, "Conventions")."""
+    spec = SceneSpec(n_mesh_instances=400, meshlets_per_mesh=250, seed=41, with_geometry=False)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    depth_cpu = make_depth(2048, 2048, 48, seed=41)
+    hz_cpu, levels, offs = oracle_hiz(depth_cpu, 1024, 1024)
+    hizd = {"data": hz_cpu, "w": 1024, "h": 1024, "levels": levels, "offs": offs}
+    mask0 = torch.zeros((cpu.n_meshlet_instances + 31) // 32, dtype=torch.int32)
+    want = oracle_frame(cpu, use_hiz=True, hiz=hizd, mask=mask0, two_pass=True, with_triangles=False)
+    depth = ImageAttachment.depth(depth_cpu.cuda())
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(6):
+        hiz = ImageAttachment.hiz(1024, 1024, "cuda")  # zeros: a cull that overtook the build would see an empty pyramid
+        frame = PreparedFrame.create(gpu, with_triangles=False)
+        renderer.prepared_frame = frame
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_MESHLETS)
+        torch.cuda.synchronize()
+        renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances, stream=sa)
+        renderer.generate_hiz(MainGeometryContext(depth, hiz), stream=sa)
+        renderer.cull_geometry(ctx, stream=sb)
+        ctx.cull_flags = L.CULL_TEST_ALL | L.CULL_LATE_PASS
+        renderer.cull_geometry(ctx, stream=sa)
+        c = renderer.read_counters(ctx, stream=sb)
+        late = frame.visible_meshlet_instances_indices_buffer[c.early_visible_meshlet_instances:c.early_visible_meshlet_instances + c.cull_triangles_cmd_x].cpu().numpy()
+        assert c.early_visible_meshlet_instances == want["early"] and np.array_equal(late, want["late_visible"]), f"rep {rep}"
+        assert np.array_equal(frame.meshlet_instance_visibility_mask_buffer.cpu().numpy(), want["mask"])
+
+
+def test_scratch_growth_is_refused_inside_a_stream_capture():
+    """A call that would have to grow the context's scratch returns OXC_INVALID_ARG while its stream is being captured (and
+    succeeds, captured, once oxc_reserve has run)."""
+    r = RendererInstance(0)  # a fresh context: nothing reserved
+    gpu = make_scene(SceneSpec(n_mesh_instances=64, meshlets_per_mesh=128, seed=43, with_geometry=False), "cuda")
+    frame = PreparedFrame.create(gpu, with_triangles=False)
+    r.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(L.OxcError) as ei:
+        with torch.cuda.graph(g, stream=s):
+            r.cull_geometry(ctx, stream=s)
+    assert ei.value.status == L.OXC_INVALID_ARG and "captured" in str(ei.value)
+    r.reserve(gpu.n_mesh_instances, gpu.n_meshlet_instances)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        r.cull_geometry(ctx, stream=s)
+    g2.replay()
+    torch.cuda.synchronize()
+    cpu = gpu.to("cpu")
+    want = oracle_frame(cpu, run_cull_meshes=True, with_triangles=False)
+    c = r.read_counters(ctx)
+    assert c.cull_triangles_cmd_x == len(want["visible"])
+    assert np.array_equal(frame.visible_meshlet_instances_indices_buffer[:c.cull_triangles_cmd_x].cpu().numpy(), want["visible"])
+    r.close()
+
+
+def test_device_side_list_length_is_clamped_to_the_callers_buffers(renderer, oracle_lib):
+    """visibility.total (device memory, e.g. produced by an earlier cull_meshes) larger than frame.max_meshlet_instance_count:
+    the kernels stop at the buffers' capacity instead of running past them."""
+    spec = SceneSpec(n_mesh_instances=50, meshlets_per_mesh=100, seed=47, with_geometry=False)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    N = gpu.n_meshlet_instances
+    want = oracle.cull_meshlets(cpu, cpu.cull_camera(), cpu.meshlet_instances)
+    frame = PreparedFrame.create(gpu, with_triangles=False)
+    guard = torch.full((4096,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")  # (allocated right after the frame's buffers)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), stages=L.STAGE_MESHLETS)
+    renderer.seed_meshlet_instances(ctx, N + 100_000)  # lies about the list length
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    assert c.cull_triangles_cmd_x == want.numel()
+    assert torch.equal(frame.visible_meshlet_instances_indices_buffer[:c.cull_triangles_cmd_x].cpu(), want)
+    assert bool((guard == 0x5A5A5A5A).all())
+
+
+def test_visibility_mask_buffer_size_is_validated(renderer):
+    gpu = make_scene(SceneSpec(n_mesh_instances=8, meshlets_per_mesh=100, seed=49, with_geometry=False), "cuda")
+    frame = PreparedFrame.create(gpu, with_triangles=False)
+    frame.meshlet_instance_visibility_mask_buffer = torch.zeros(4, dtype=torch.int32, device="cuda")  # 128 bits for 800 meshlets
+    renderer.prepared_frame = frame
+    hiz = ImageAttachment.hiz(64, 64, "cuda")
+    ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_MESHLETS)
+    renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
+    with pytest.raises(L.OxcError) as ei:
+        renderer.cull_geometry(ctx)
+    assert ei.value.status == L.OXC_INVALID_ARG
+
+
+def test_pack_counters_equals_read_counters(renderer, oracle_lib):
+    gpu = make_scene(SceneSpec(n_mesh_instances=30, meshlets_per_mesh=90, seed=51), "cuda")
+    frame = PreparedFrame.create(gpu)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera())
+    renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
+    renderer.cull_geometry(ctx)
+    packed = torch.zeros(4, dtype=torch.int32, device="cuda")
+    renderer.pack_counters(ctx, packed)
+    c = renderer.read_counters(ctx)
+    assert packed.cpu().tolist() == [c.cull_triangles_cmd_x, c.early_visible_meshlet_instances, c.late_visible_meshlet_instances, c.draw_index_count]
+    assert c.cull_triangles_cmd_x > 0 and c.draw_index_count > 0
