@@ -483,7 +483,7 @@ def bench_config3(args, e):
              "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures, HiZ taps excluded"}
 
     # ---- CPU checker on a bounded prefix of the SAME arrays: bit_match + cpu_baseline (rank 0, N = 1) ----
-    bit_match, cpu_baseline, hiz_match = None, None, None
+    bit_match, cpu_baseline, hiz_match, unpinned = None, None, None, None
     if rank == 0:
         import oracle  # checker only
 
@@ -520,6 +520,21 @@ def bench_config3(args, e):
         t_seq = time.perf_counter() - t_c0
         bit_match = bool(all(torch.equal(want[t][0], snap[t]["visible_prefix"]) and torch.equal(want[t][1], snap[t]["indices_prefix"]) for t in ("early", "late"))
                          and torch.equal(mask_want, mask_after))
+        if not args.no_cpu_baseline:
+            # What no oracle can pin (the reference is compiled fast-math and ships no vectors): on the same sample, how many decisions
+            # change under fused multiply-adds / reciprocal divisions, and how many triangles are ill-conditioned at all.
+            with oracle.variant("fast"):
+                fast, mask_fast = cpu_sequence()
+            tri1 = lambda t: (t.view(-1, 3)[:, 0].numpy().astype("int64") & 0xFFFFFFFF) if t.numel() else torch.zeros(0).numpy()  # noqa: E731
+            import numpy as _np
+
+            flags = oracle.triangle_boundary_flags(sub, cam, sub.meshlet_instances, want["late"][0], 0, want["late"][0].numel())
+            unpinned = {"sample": f"first {m0 * K} meshlet instances, both passes", "visible_meshlets_differ": sum(int(_np.setxor1d(want[t][0].numpy(), fast[t][0].numpy()).size) for t in ("early", "late")),
+                        "mask_bits_differ": int(_np.unpackbits((mask_want.numpy() ^ mask_fast.numpy()).view(_np.uint8)).sum()),
+                        "triangles_differ": sum(int(_np.setxor1d(tri1(want[t][1]), tri1(fast[t][1])).size) for t in ("early", "late")),
+                        "triangles_emitted": sum(int(want[t][1].numel() // 3) for t in ("early", "late")),
+                        "late_triangles_tested": int(want["late"][0].numel()) * min(args.tris, 64), "late_triangles_ill_conditioned": int(flags.sum()),
+                        "note": "canonical checker vs its fast-math-envelope build (oracle/Makefile); tools/unpinned_gap.py, profiles/r02_unpinned_gap.json"}
         if world == 1 and not args.no_cpu_baseline:
             reps = int(max(1, min(args.cpu_seconds / max(t_seq, 1e-3), 200)))
             t_c0 = time.perf_counter()
@@ -549,7 +564,7 @@ def bench_config3(args, e):
                                                          "counters_all_gather_bytes_per_rank": 16},
         },
         "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
-        "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "unpinned_gap": unpinned, "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
     # free the 25 GB of this workload before the nested one
     del scene, frame, depth, hiz, mask0

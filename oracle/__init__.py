@@ -135,6 +135,8 @@ def lib() -> C.CDLL:
         l.orc_test_triangle_small.argtypes = [vp, vp]
         l.orc_cull_triangles_flags.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, C.c_int, C.c_int]
         l.orc_cull_triangles_flags.restype = u32
+        l.orc_triangle_boundary_flags.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp]
+        l.orc_triangle_boundary_flags.restype = None
         l.orc_is_fast_envelope.restype = C.c_int
         assert bool(l.orc_is_fast_envelope()) == (path == FAST_LIB_PATH)
         _libs[path] = _lib = l
@@ -291,6 +293,14 @@ def entities_update_and_cull(trs10: np.ndarray, parent: np.ndarray, aabb6: np.nd
     vis = np.zeros(n, dtype=np.uint8)
     cnt = lib().orc_entities_update_and_cull_passes(n, _p(trs10), _p(parent), _p(aabb6), _p(planes24), _p(world), _p(vis), max(1, passes))
     return world, vis, int(cnt)
+
+
+def triangle_boundary_flags(scene, cam, meshlet_instances: torch.Tensor, visible: torch.Tensor, first: int, count: int) -> torch.Tensor:
+    """uint8 [count, 64]: 1 where a different legal evaluation order of cull_triangles' tests can flip triangle t of slot s."""
+    out = torch.zeros((max(count, 1), 64), dtype=torch.uint8)
+    lib().orc_triangle_boundary_flags(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
+                                      _p(cam), _p(out))
+    return out[:count]
 
 
 def make_hpb(data: torch.Tensor, width: int, height: int, layers: int, levels: int, level_offset_bytes) -> Hpb:

@@ -765,6 +765,53 @@ uint32_t orc_cull_triangles_flags(const orc_mesh* meshes, const float* transform
                              wide ? 9u : 8u, small_triangle_cull);
 }
 
+/* Which triangles of the visible slots sit in the BOUNDARY SET of cull_triangles' two tests: the ones whose decision a
+ * different (legal, fast-math) evaluation order can flip.  The backface determinant is a sum of six triple products that
+ * mostly cancel (tiny or distant triangles: |det| << the products), so "within a few ulp of the threshold" says nothing;
+ * the forward error of ANY evaluation order is bounded by a small multiple of eps * (sum of the |products|), and that is
+ * the criterion here: |det - 0.0001| <= 4 * 2^-24 * sum|products| (measured: a factor 2 already covers every flip of the fast-math envelope build; the factor covers the roundings of the clip coordinates
+ * themselves, which enter each product).  Same for the three clip.z >= 0 tests against sum|terms| of the row-2 dot product.
+ * flags64[s * 64 + t] = 1 for a boundary triangle, 0 otherwise (t < min(triangle_count, 64)). */
+void orc_triangle_boundary_flags(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                 const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                 uint32_t count, const orc_cull_camera* cam, uint8_t* flags64) {
+  const float eps = 4.0f * 5.9604644775390625e-08f;
+  for (uint32_t s = 0; s < count; s++) {
+    uint32_t mli_index = visible[first + s];
+    const orc_meshlet_instance* mli = &meshlet_instances[mli_index];
+    const orc_mesh_instance* inst = &mesh_instances[mli->mesh_instance_index];
+    const orc_mesh* mesh = &meshes[inst->mesh_index];
+    const orc_mesh_lod* lod = &((const orc_mesh_lod*)(uintptr_t)mesh->lods)[inst->lod_index];
+    const orc_meshlet* ml = &((const orc_meshlet*)(uintptr_t)lod->meshlets)[mli->meshlet_index];
+    float mvp[16];
+    orc_mul_mat4(cam->projection_view, xform(transforms, inst->transform_index), mvp);
+    const uint32_t* micro = (const uint32_t*)(uintptr_t)lod->local_triangle_indices;
+    const uint32_t* vidx = (const uint32_t*)(uintptr_t)lod->indirect_vertex_indices;
+    const uint16_t* pos = (const uint16_t*)(uintptr_t)mesh->vertex_positions;
+    uint32_t tcount = ml->triangle_count < 64u ? ml->triangle_count : 64u;
+    for (uint32_t t = 0; t < 64u; t++) {
+      uint8_t flag = 0;
+      if (t < tcount) {
+        float cp[12];
+        for (int k = 0; k < 3; k++) {
+          uint32_t li = micro_index(micro, ml->local_triangle_index_offset + t * 3u + (uint32_t)k);
+          uint32_t vi = vidx[ml->indirect_vertex_index_offset + li];
+          float p[3] = {orc_dequantize_half(pos[(size_t)vi * 4 + 0]), orc_dequantize_half(pos[(size_t)vi * 4 + 1]),
+                        orc_dequantize_half(pos[(size_t)vi * 4 + 2])};
+          mul_mp(mvp, p, &cp[k * 4]);
+          float zmag = (fabsf(M(mvp, 2, 0) * p[0]) + fabsf(M(mvp, 2, 1) * p[1])) + (fabsf(M(mvp, 2, 2) * p[2]) + fabsf(M(mvp, 2, 3)));
+          if (fabsf(cp[k * 4 + 2]) <= eps * zmag) flag = 1;
+        }
+        float a = cp[0], b = cp[1], c = cp[3], d = cp[4], e = cp[5], f = cp[7], g = cp[8], h = cp[9], i = cp[11];
+        float det = (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+        float mag = (fabsf(a) * (fabsf(e * i) + fabsf(f * h)) + fabsf(b) * (fabsf(d * i) + fabsf(f * g))) + fabsf(c) * (fabsf(d * h) + fabsf(e * g));
+        if (fabsf(det - 0.0001f) <= eps * mag) flag = 1;
+      }
+      flags64[(size_t)s * 64 + t] = flag;
+    }
+  }
+}
+
 uint32_t orc_cull_triangles_wide(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                  const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                  uint32_t count, const orc_cull_camera* cam, uint32_t* out) {

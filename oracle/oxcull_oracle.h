@@ -218,6 +218,11 @@ uint32_t orc_cull_triangles_flags(const orc_mesh* meshes, const float* transform
                                   const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                   uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out, int wide,
                                   int small_triangle_cull);
+/* Conditioning-aware boundary set of cull_triangles (see the .c): flags64[s * 64 + t] = 1 when the decision of triangle t of
+ * visible slot first + s can be flipped by a different legal evaluation order of the same formula. */
+void orc_triangle_boundary_flags(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
+                                 const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
+                                 uint32_t count, const orc_cull_camera* cam, uint8_t* flags64);
 /* 1 when this library is the -DORC_FAST_ENVELOPE build (liboxcull_oracle_fast.so), see oxcull_oracle.c */
 int orc_is_fast_envelope(void);
 

@@ -332,3 +332,41 @@ def test_entities_update_and_cull():
     nv = oracle.lib().orc_entities_update_and_cull(n, oracle._p(trs), oracle._p(parent), oracle._p(aabb), oracle._p(planes), oracle._p(world), oracle._p(vis))
     assert vis.tolist() == [1, 1, 0, 0] and nv == 2
     assert world[2, 12:15].tolist() == [1.0, 0.0, 10.0]
+
+
+# ---- opt-in small-triangle cull (include/oxcull.h, oxc_cull_geometry_context::small_triangle_cull) ---------------
+def test_triangle_small_known_answers():
+    """Rule: dropped iff all w > 0 and floor(lo + 0.5) == floor(hi + 0.5) on either axis of the screen-space bounding box
+    (pixel centres at k + 0.5).  clip rows are {x, y, z, w}; screen = (x / w * 0.5 + 0.5) * resolution."""
+    res = [100.0, 100.0]
+
+    def tri(pts, w=1.0):  # pts in pixels -> clip coordinates
+        return [[(px / 50.0 - 1.0) * w, (py / 50.0 - 1.0) * w, 0.5, w] for px, py in pts]
+
+    assert oracle.triangle_small(tri([(10.6, 10.6), (11.4, 10.7), (10.9, 11.3)]), res)          # between centres 10.5 and 11.5 on both axes
+    assert not oracle.triangle_small(tri([(10.4, 10.4), (11.6, 10.4), (10.4, 11.6)]), res)      # covers the centre (10.5, 10.5)... bbox spans 10.5 and 11.5
+    assert oracle.triangle_small(tri([(10.6, 3.0), (11.4, 40.0), (10.9, 80.0)]), res)           # a sliver: no centre in x although tall in y
+    assert not oracle.triangle_small(tri([(10.0, 10.0), (30.0, 10.0), (10.0, 30.0)]), res)      # a big triangle
+    assert oracle.triangle_small(tri([(10.6, 10.6), (11.4, 10.7), (10.9, 11.3)], w=7.0), res)   # the same footprint at another depth
+    # a corner at or behind the camera plane: never dropped by this rule
+    behind = tri([(10.6, 10.6), (11.4, 10.7), (10.9, 11.3)])
+    behind[1][3] = 0.0
+    assert not oracle.triangle_small(behind, res)
+    behind[1][3] = -2.0
+    assert not oracle.triangle_small(behind, res)
+    # exactly on a pixel centre: lo = 10.5 -> floor(11.0) = 11, hi = 10.9 -> floor(11.4) = 11: no centre strictly inside [10.5, 10.9]? the
+    # rule counts 10.5 as NOT covered from the left (round-half-up puts it in cell 11), stated behaviour
+    assert oracle.triangle_small(tri([(10.5, 10.6), (10.9, 10.7), (10.7, 11.3)]), res)
+    # resolution scales the footprint: the same clip-space triangle covers centres at 1000 px
+    t = tri([(10.6, 10.6), (11.4, 10.7), (10.9, 11.3)])
+    assert not oracle.triangle_small(t, [1000.0, 1000.0])
+
+
+def test_cull_triangles_small_flag_only_removes_triangles():
+    s = make_scene(SceneSpec(n_mesh_instances=20, meshlets_per_mesh=60, seed=61, resolution=128))
+    cam = s.cull_camera()
+    vis = oracle.cull_meshlets(s, cam, s.meshlet_instances)
+    off = oracle.cull_triangles(s, cam, s.meshlet_instances, vis, 0, vis.numel())
+    on = oracle.cull_triangles(s, cam, s.meshlet_instances, vis, 0, vis.numel(), small_triangle_cull=True)
+    assert 0 < on.numel() < off.numel()
+    assert set(on.view(-1, 3)[:, 0].tolist()) < set(off.view(-1, 3)[:, 0].tolist())
