@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: build + broadcast the pyramid on the cull stream instead of one frame ahead on a second stream")
+    ap.add_argument("--hiz-exchange", default="whole", choices=["whole", "top"],
+                    help="N > 1: 'whole' = rank 0 broadcasts every level of the pyramid (89.5 MB; no assumption about the other ranks); 'top' = only levels "
+                         ">= --hiz-top-level travel (5.6 MB at level 2) and every rank builds the lower levels from its own copy of the depth image")
+    ap.add_argument("--hiz-top-level", type=int, default=2)
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: run the two exchanges (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
                          "(oxc_exchange_counts / oxc_broadcast_hiz) instead of torch.distributed; the rendezvous stays torch.distributed")
@@ -305,13 +309,21 @@ def bench_config3(args, e):
         C.memmove(C.byref(c2), C.byref(cctx[0]), C.sizeof(L.CullGeometryContext))
         c2.hiz_attachment = hz.c()
         cctx.append(c2)
-    mgs = []
+    mgs, mgs_low = [], []
+    top = world > 1 and args.hiz_exchange == "top"
+    k_top = max(1, min(args.hiz_top_level, hiz[0].levels - 1))
     for hz in hiz:
         mg = L.MainGeometryContext()
         mg.struct_size = C.sizeof(L.MainGeometryContext)
         mg.depth_attachment, mg.hiz_attachment = depth.c(), hz.c()
         mgs.append(mg)
+        lo = L.MainGeometryContext()  # the same image with only the levels below k_top: what a non-root rank builds itself
+        lo.struct_size = C.sizeof(L.MainGeometryContext)
+        lo.depth_attachment, lo.hiz_attachment = depth.c(), hz.c()
+        lo.hiz_attachment.levels = k_top
+        mgs_low.append(lo)
     hiz_bytes = hiz[0].data.numel() * 4
+    hiz_wire_bytes = hiz_bytes - (hiz[0].level_offset[k_top] if top else 0)
 
     # ---- multi-GPU plumbing: second context + stream for the pyramid producer, events, counter all-gather ----
     overlap = world > 1 and not args.no_overlap
@@ -332,16 +344,16 @@ def bench_config3(args, e):
 
     def produce_hiz(b):
         """Rank 0 builds pyramid buffer b from the depth image; everybody receives it (RCCL broadcast over xGMI)."""
-        if rank == 0:
-            st = r_hiz._lib.oxc_generate_hiz(r_hiz._ctx, C.byref(mgs[b]), csp)
+        if rank == 0 or top:  # 'top': the other ranks build levels < k_top from their own copy of the depth image
+            st = r_hiz._lib.oxc_generate_hiz(r_hiz._ctx, C.byref(mgs[b] if rank == 0 else mgs_low[b]), csp)
             if st != L.OXC_OK:
                 raise RuntimeError(r_hiz._lib.oxc_last_error(r_hiz._ctx).decode())
         if dist is not None:
             if e.native_comm:
-                r_hiz.broadcast_hiz(hiz[b], 0, comm_stream)
+                r_hiz.broadcast_hiz(hiz[b], 0, comm_stream, first_level=k_top if top else 0)
             else:
                 with torch.cuda.stream(comm_stream):
-                    dist.broadcast(hiz[b].data, src=0)
+                    dist.broadcast(hiz[b].data[hiz[b].level_offset[k_top] // 4:] if top else hiz[b].data, src=0)
 
     def gather_counts(c):
         # {emitted, early, late, index_count} of this rank's last call -> every rank (north star's all-gather); packed on the
@@ -560,7 +572,8 @@ def bench_config3(args, e):
             "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
             "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
             "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": world, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else "torch.distributed nccl (RCCL)",
-                                                         "hiz_broadcast_bytes_per_frame": hiz_bytes, "hiz_one_frame_ahead_on_second_stream": overlap,
+                                                         "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if top else "whole pyramid broadcast from rank 0"),
+                                                         "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": overlap,
                                                          "counters_all_gather_bytes_per_rank": 16},
         },
         "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",

@@ -440,6 +440,12 @@ oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* cont
 oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all_counts_dptr, void* hip_stream);
 /* broadcast of every level of `hiz` from rank `root` (in place) */
 oxc_status oxc_broadcast_hiz(oxc_ctx* ctx, const oxc_image* hiz, uint64_t total_bytes, uint32_t root, void* hip_stream);
+/* The "top mips" form of the same exchange: only levels >= first_level travel (bytes [level_offset[first_level], total_bytes) of the
+ * linear chain: 5.6 MB instead of 89.5 MB for a 4096^2 pyramid with first_level = 2).  A rank must hold EVERY level it may sample
+ * (clamping the mip would change results), so this form is for ranks that own a copy of the depth image and build levels
+ * < first_level themselves: oxc_generate_hiz with hiz_attachment.levels = first_level.  The pyramid is a pure function of the depth
+ * image, so both forms give every rank the same bytes. */
+oxc_status oxc_broadcast_hiz_levels(oxc_ctx* ctx, const oxc_image* hiz, uint32_t first_level, uint64_t total_bytes, uint32_t root, void* hip_stream);
 
 /* Test hook: project_aabb (cull.slang:12-47) of n boxes {center.xyz, extent.xyz} with one matrix: out7 = {min.u, min.v,
  * min.z, max.u, max.v, max.z, returned ? 1 : 0} per box -- lets the tests compare the device's division fast path with IEEE

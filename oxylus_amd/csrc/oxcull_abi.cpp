@@ -1170,6 +1170,7 @@ oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all
   if (!ctx->comm) return fail(ctx, OXC_INVALID_ARG, "exchange_counts: oxc_comm_init has not been called");
   if (!counts4_dptr || !all_counts_dptr) return fail(ctx, OXC_INVALID_ARG, "exchange_counts: null buffer");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   int rc = rccl()->AllGather(counts4_dptr, all_counts_dptr, 4, kNcclUint32, ctx->comm, static_cast<hipStream_t>(hip_stream));
   return rc == 0 ? OXC_OK : rccl_fail(ctx, "ncclAllGather", rc);
 }
@@ -1179,7 +1180,21 @@ oxc_status oxc_broadcast_hiz(oxc_ctx* ctx, const oxc_image* hiz, uint64_t total_
   if (!ctx->comm) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz: oxc_comm_init has not been called");
   if (!hiz || !hiz->dptr || total_bytes == 0 || root >= ctx->comm_world) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz: null image, zero size or bad root");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
   int rc = rccl()->Broadcast(hiz->dptr, hiz->dptr, (size_t)total_bytes, kNcclUint8, (int)root, ctx->comm, static_cast<hipStream_t>(hip_stream));
+  return rc == 0 ? OXC_OK : rccl_fail(ctx, "ncclBroadcast", rc);
+}
+
+oxc_status oxc_broadcast_hiz_levels(oxc_ctx* ctx, const oxc_image* hiz, uint32_t first_level, uint64_t total_bytes, uint32_t root, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!ctx->comm) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz_levels: oxc_comm_init has not been called");
+  if (!hiz || !hiz->dptr || first_level >= hiz->levels || hiz->levels > 13 || root >= ctx->comm_world) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz_levels: null image, bad level or bad root");
+  const uint64_t begin = hiz->level_offset[first_level];
+  if (total_bytes <= begin) return fail(ctx, OXC_INVALID_ARG, "broadcast_hiz_levels: total_bytes does not reach first_level");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
+  char* p = static_cast<char*>(hiz->dptr) + begin;
+  int rc = rccl()->Broadcast(p, p, (size_t)(total_bytes - begin), kNcclUint8, (int)root, ctx->comm, static_cast<hipStream_t>(hip_stream));
   return rc == 0 ? OXC_OK : rccl_fail(ctx, "ncclBroadcast", rc);
 }
 

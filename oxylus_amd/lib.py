@@ -257,6 +257,7 @@ EXPORTS = [
     "oxc_pack_counters",
     "oxc_exchange_counts",
     "oxc_broadcast_hiz",
+    "oxc_broadcast_hiz_levels",
     "oxc_debug_read_u32",
     "oxc_debug_project_aabb",
 ]
@@ -318,6 +319,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_pack_counters.argtypes = [vp, C.POINTER(CullGeometryContext), vp, vp]
     lib.oxc_exchange_counts.argtypes = [vp, vp, vp, vp]
     lib.oxc_broadcast_hiz.argtypes = [vp, C.POINTER(Image), C.c_uint64, C.c_uint32, vp]
+    lib.oxc_broadcast_hiz_levels.argtypes = [vp, C.POINTER(Image), C.c_uint32, C.c_uint64, C.c_uint32, vp]
     lib.oxc_debug_project_aabb.argtypes = [vp, C.POINTER(C.c_float), C.c_float, vp, C.c_uint32, vp, vp]
     lib.oxc_draw_visbuffer.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(DrawContext), vp]
     for name in EXPORTS:

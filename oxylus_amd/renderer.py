@@ -395,9 +395,13 @@ class RendererInstance:
         self._check(self._lib.oxc_exchange_counts(self._ctx, C.c_void_p(counts4.data_ptr()), C.c_void_p(out.data_ptr()), self._stream(stream)))
         return out
 
-    def broadcast_hiz(self, hiz: "ImageAttachment", root: int, stream=None):
+    def broadcast_hiz(self, hiz: "ImageAttachment", root: int, stream=None, first_level: int = 0):
+        """Every level (first_level = 0) or only the top of the pyramid, levels >= first_level (the rest is built locally)."""
         im = hiz.c()
-        self._check(self._lib.oxc_broadcast_hiz(self._ctx, C.byref(im), hiz.data.numel() * 4, root, self._stream(stream)))
+        if first_level:
+            self._check(self._lib.oxc_broadcast_hiz_levels(self._ctx, C.byref(im), first_level, hiz.data.numel() * 4, root, self._stream(stream)))
+        else:
+            self._check(self._lib.oxc_broadcast_hiz(self._ctx, C.byref(im), hiz.data.numel() * 4, root, self._stream(stream)))
 
     def profile_begin(self):
         self._check(self._lib.oxc_profile_begin(self._ctx))

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [1, 2], ids=["world1-dry-run", "world2"])
-def test_ranks_native_comm_union_equals_single_device(tmp_path, oracle_lib, world):
+@pytest.mark.parametrize("world,top", [(1, 0), (1, 3), (2, 0), (2, 3)], ids=["world1-dry-run", "world1-top-mips", "world2", "world2-top-mips"])
+def test_ranks_native_comm_union_equals_single_device(tmp_path, oracle_lib, world, top):
     """world = 1 runs the very same worker on one GPU (RCCL communicator of one rank): keeps the script honest on a one-GPU box."""
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs")
@@ -27,7 +27,7 @@ def test_ranks_native_comm_union_equals_single_device(tmp_path, oracle_lib, worl
     import two_rank_worker as W
     from util import oracle_hiz
 
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OXC_TEST_HIZ_TOP=str(top))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(r), str(world), str(tmp_path)], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0

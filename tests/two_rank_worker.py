@@ -44,10 +44,15 @@ def main():
         uid = open(uid_path, "rb").read()
     r.comm_init(uid, rank, world)
     hiz = ImageAttachment.hiz(HIZ, HIZ, dev)
-    if rank == 0:  # depth is produced where rasterisation happens: rank 0 builds the pyramid ...
+    top = int(os.environ.get("OXC_TEST_HIZ_TOP", "0"))  # > 0: the "top mips" exchange (levels >= top travel, the rest is built locally)
+    if rank == 0 or top:  # depth is produced where rasterisation happens: rank 0 builds the pyramid ...
         depth = make_depth(2 * HIZ, 2 * HIZ, 40, seed=DEPTH_SEED, device=dev)
-        r.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
-    r.broadcast_hiz(hiz, 0)  # ... and every rank receives it
+        if rank == 0:
+            r.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
+        else:  # ... or, in the top-mips form, a rank builds the levels below `top` from its own copy of the depth image
+            low = ImageAttachment(hiz.data, hiz.width, hiz.height, top, hiz.level_offset[:top])
+            r.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), low))
+    r.broadcast_hiz(hiz, 0, first_level=top)  # ... and every rank receives it
     frame = PreparedFrame.create(shard)
     r.prepared_frame = frame
     ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=shard.cull_camera(), hiz_attachment=hiz)
