@@ -64,6 +64,14 @@ def broadcast_hiz(hiz_data: torch.Tensor, src: int = 0, group=None) -> None:
     dist.broadcast(hiz_data, src=src, group=group)
 
 
+def broadcast_hiz_top(hiz_data: torch.Tensor, level_offset_bytes, first_level: int, src: int = 0, group=None) -> None:
+    """The "top mips" form (north star wording): only levels >= first_level travel; a rank that uses it must have built the
+    levels below from its own copy of the depth image (same bytes: the pyramid is a pure function of the depth)."""
+    import torch.distributed as dist
+
+    dist.broadcast(hiz_data[level_offset_bytes[first_level] // 4:], src=src, group=group)
+
+
 def merge_visible(local_visible: torch.Tensor, first_meshlet: int) -> torch.Tensor:
     """Shard-local visible ids -> global meshlet-instance ids."""
     return local_visible.to(torch.int64) + first_meshlet

@@ -22,14 +22,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, top=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
-    from oxylus_amd.shard import broadcast_hiz, exchange_counts, exclusive_offsets, merge_visible, shard_scene
+    from oxylus_amd.shard import broadcast_hiz, broadcast_hiz_top, exchange_counts, exclusive_offsets, merge_visible, shard_scene
     from oxylus_amd.synth import SceneSpec, make_depth, make_scene
     from util import oracle_frame, oracle_hiz
 
@@ -41,7 +41,12 @@ def _worker(rank, world, port, out_dir):
     hz = torch.zeros(total // 4)
     if rank == 0:
         hz, _, _ = oracle_hiz(make_depth(256, 256, 32, seed=5), 128, 128)
-    broadcast_hiz(hz, src=0)
+    elif top:  # "top mips" exchange: this rank builds the levels below `top` from its own copy of the depth image
+        oracle.generate_hiz(make_depth(256, 256, 32, seed=5), hz, 128, 128, top, offs[:top])
+    if top:
+        broadcast_hiz_top(hz, offs, top, src=0)
+    else:
+        broadcast_hiz(hz, src=0)
     hizd = {"data": hz, "w": 128, "h": 128, "levels": levels, "offs": offs}
     mask = torch.zeros((shard.n_meshlet_instances + 31) // 32, dtype=torch.int32)
     res = oracle_frame(shard, use_hiz=True, hiz=hizd, mask=mask, two_pass=True)
@@ -58,10 +63,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_union_equals_single(tmp_path, oracle_lib):
+@pytest.mark.parametrize("top", [0, 2], ids=["whole-pyramid", "top-mips"])
+def test_two_rank_shards_union_equals_single(tmp_path, oracle_lib, top):
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), top), nprocs=world, join=True)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oxylus_amd.synth import SceneSpec, make_depth, make_scene
     from util import oracle_frame, oracle_hiz
