@@ -352,6 +352,41 @@ oxc_status oxc_mesh_blob_layout_of(const oxc_mesh_blob_desc* desc, oxc_mesh_blob
 oxc_status oxc_mesh_blob_finalize(const oxc_mesh_blob_desc* desc, const oxc_mesh_blob_layout* layout, uint64_t device_address,
                                   void* blob, uint64_t blob_bytes, const float mesh_bounds[6], void* out_gpu_mesh);
 
+/* ---- SURVEY 8(f)-1, clusteriser side: triangle soup -> LOD chain -> meshlets (host code, as in the reference) ----------
+ * Replaces the per-LOD loop of AssetManager_GLTF.cpp:599-682: LOD 0 = the input indices, LOD i = LOD i-1 simplified to half its
+ * index count with the border locked (meshopt_simplifyWithAttributes, normal weights 1), error accumulated down the chain, chain
+ * cut by the reference's three stop rules (:639-645) or at GPU::Mesh::MAX_LODS; every LOD clustered into meshlets of at most
+ * max_vertices / max_triangles (64 / 64: Model::MAX_MESHLET_INDICES / _PRIMITIVES, meshopt_buildMeshlets with cone_weight 0), u8
+ * micro-index runs 4-byte aligned (:687).  meshoptimizer is a third-party dependency that is not part of the reference tree: its two
+ * algorithms are restated in shape, not heuristic for heuristic (oxylus_amd/csrc/oxcull_meshbuild.cpp) -- a valid, different clustering.
+ * Host pointers in, host views out (owned by the handle); feed them to oxc_build_meshlet_bounds / oxc_quantize_vertex_streams /
+ * oxc_mesh_blob_* to obtain what oxc_cull_geometry consumes. */
+typedef struct oxc_mesh_build oxc_mesh_build;
+typedef struct oxc_mesh_build_desc {
+  uint32_t struct_size;
+  uint32_t vertex_count;
+  uint32_t index_count;   /* multiple of 3 */
+  uint32_t max_lods;      /* 0 = OXC_MESH_MAX_LODS */
+  uint32_t max_vertices;  /* per meshlet, 0 = 64 */
+  uint32_t max_triangles; /* per meshlet, 0 = 64 */
+  const float* positions; /* glm::vec3[vertex_count] */
+  const float* normals;   /* glm::vec3[vertex_count], optional (NULL: positions only) */
+  const uint32_t* indices;
+} oxc_mesh_build_desc;
+typedef struct oxc_mesh_lod_view { /* the arrays of one GPU::MeshLOD (SceneGPU.hpp:125-139), host memory */
+  const uint32_t* indices;
+  const void* meshlets; /* GPU::Meshlet[meshlet_count], 16 B each */
+  const uint32_t* indirect_vertex_indices;
+  const uint8_t* local_triangle_indices;
+  uint32_t indices_count, meshlet_count, indirect_vertex_indices_count, local_triangle_indices_count;
+  float error;
+  uint32_t _pad;
+} oxc_mesh_lod_view;
+oxc_status oxc_mesh_build_create(const oxc_mesh_build_desc* desc, oxc_mesh_build** out);
+uint32_t oxc_mesh_build_lod_count(const oxc_mesh_build* build);
+oxc_status oxc_mesh_build_lod(const oxc_mesh_build* build, uint32_t lod, oxc_mesh_lod_view* out);
+void oxc_mesh_build_destroy(oxc_mesh_build* build);
+
 /* ---- hierarchical page buffer producer ------------------------------------------
  * Replaces the "vsm downsample hpb" pass (Oxylus/src/Render/Passes/Shadowmaps.cpp:331-366, pipeline
  * rmvsm_downsample_hpb, Shaders/passes/rmvsm_downsample_hpb.slang:10-33): level 0 of the pyramid is 1 where

@@ -248,6 +248,10 @@ EXPORTS = [
     "oxc_quantize_vertex_streams",
     "oxc_mesh_blob_layout_of",
     "oxc_mesh_blob_finalize",
+    "oxc_mesh_build_create",
+    "oxc_mesh_build_lod_count",
+    "oxc_mesh_build_lod",
+    "oxc_mesh_build_destroy",
     "oxc_generate_hpb",
     "oxc_cull_terrain",
     "oxc_draw_visbuffer",
@@ -310,6 +314,12 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_quantize_vertex_streams.argtypes = [vp, C.POINTER(VertexStreamsDesc), vp]
     lib.oxc_mesh_blob_layout_of.argtypes = [C.POINTER(MeshBlobDesc), C.POINTER(MeshBlobLayout)]
     lib.oxc_mesh_blob_finalize.argtypes = [C.POINTER(MeshBlobDesc), C.POINTER(MeshBlobLayout), C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_float * 6), vp]
+    lib.oxc_mesh_build_create.argtypes = [C.POINTER(MeshBuildDesc), C.POINTER(vp)]
+    lib.oxc_mesh_build_lod_count.argtypes = [vp]
+    lib.oxc_mesh_build_lod_count.restype = C.c_uint32
+    lib.oxc_mesh_build_lod.argtypes = [vp, C.c_uint32, C.POINTER(MeshLodView)]
+    lib.oxc_mesh_build_destroy.argtypes = [vp]
+    lib.oxc_mesh_build_destroy.restype = None
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
@@ -323,10 +333,21 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_debug_project_aabb.argtypes = [vp, C.POINTER(C.c_float), C.c_float, vp, C.c_uint32, vp, vp]
     lib.oxc_draw_visbuffer.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(DrawContext), vp]
     for name in EXPORTS:
-        if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error"):
+        if name not in ("oxc_abi_version", "oxc_destroy", "oxc_last_error", "oxc_mesh_build_lod_count", "oxc_mesh_build_destroy"):
             getattr(lib, name).restype = C.c_int
     _libs[path] = lib
     return lib
+
+
+class MeshBuildDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("vertex_count", C.c_uint32), ("index_count", C.c_uint32), ("max_lods", C.c_uint32), ("max_vertices", C.c_uint32),
+                ("max_triangles", C.c_uint32), ("positions", C.c_void_p), ("normals", C.c_void_p), ("indices", C.c_void_p)]
+
+
+class MeshLodView(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("meshlets", C.c_void_p), ("indirect_vertex_indices", C.c_void_p), ("local_triangle_indices", C.c_void_p),
+                ("indices_count", C.c_uint32), ("meshlet_count", C.c_uint32), ("indirect_vertex_indices_count", C.c_uint32),
+                ("local_triangle_indices_count", C.c_uint32), ("error", C.c_float), ("_pad", C.c_uint32)]
 
 
 class KernelTimes(C.Structure):

@@ -1,0 +1,85 @@
+"""Host-side binding of the asset-side clusteriser (include/oxcull.h: oxc_mesh_build_*): triangle soup -> LOD chain -> meshlets,
+the loop of Oxylus/src/Asset/AssetManager_GLTF.cpp:599-682.  Pure host code in the reference too; the GPU takes over at the bounds
+producer (RendererInstance.build_meshlet_bounds / quantize_vertex_streams) and the mesh blob (oxylus_amd/mesh_blob.py)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def build_mesh_lods(positions: torch.Tensor, indices: torch.Tensor, normals: Optional[torch.Tensor] = None, max_lods: int = 0,
+                    max_vertices: int = 64, max_triangles: int = 64) -> List[dict]:
+    """positions f32 [V,3] (CPU), indices integer [T,3] or flat, normals f32 [V,3] or None.
+    Returns one dict per LOD: indices i32 [n], meshlets i32 [M,4] (GPU::Meshlet), vidx i32 [..], micro u8 [..], error float."""
+    lib = L.load()
+    pos = np.ascontiguousarray(positions.detach().cpu().numpy(), dtype=np.float32)
+    idx = np.ascontiguousarray(indices.detach().cpu().numpy().reshape(-1), dtype=np.uint32)
+    nrm = np.ascontiguousarray(normals.detach().cpu().numpy(), dtype=np.float32) if normals is not None else None
+    d = L.MeshBuildDesc()
+    d.struct_size = C.sizeof(L.MeshBuildDesc)
+    d.vertex_count, d.index_count, d.max_lods = pos.shape[0], idx.shape[0], max_lods
+    d.max_vertices, d.max_triangles = max_vertices, max_triangles
+    d.positions, d.indices = pos.ctypes.data, idx.ctypes.data
+    d.normals = nrm.ctypes.data if nrm is not None else None
+    h = C.c_void_p()
+    st = lib.oxc_mesh_build_create(C.byref(d), C.byref(h))
+    if st != L.OXC_OK:
+        raise L.OxcError(st, "oxc_mesh_build_create: bad description (index out of range, index_count not a multiple of 3, limits outside 3..255)")
+    try:
+        out = []
+        for i in range(lib.oxc_mesh_build_lod_count(h)):
+            v = L.MeshLodView()
+            st = lib.oxc_mesh_build_lod(h, i, C.byref(v))
+            if st != L.OXC_OK:
+                raise L.OxcError(st, "oxc_mesh_build_lod")
+
+            def arr(ptr, n, ctype, dtype):
+                return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype, copy=True)) if n else torch.zeros(0, dtype=getattr(torch, np.dtype(dtype).name))
+
+            out.append({"indices": arr(v.indices, v.indices_count, C.c_uint32, np.int32),
+                        "meshlets": arr(v.meshlets, v.meshlet_count * 4, C.c_uint32, np.int32).view(-1, 4),
+                        "vidx": arr(v.indirect_vertex_indices, v.indirect_vertex_indices_count, C.c_uint32, np.int32),
+                        "micro": arr(v.local_triangle_indices, v.local_triangle_indices_count, C.c_uint8, np.uint8), "error": float(v.error)})
+        return out
+    finally:
+        lib.oxc_mesh_build_destroy(h)
+
+
+def make_scene_from_lods(n_mesh_instances: int, lods: List[dict], bounds_per_lod: List[torch.Tensor], positions_u16x4: torch.Tensor, mesh_bounds6: torch.Tensor,
+                         seed: int = 0x0A1DE5, device="cpu", **spec_kw):
+    """A scene of randomly placed instances of ONE mesh with its whole LOD chain (arrays LOD-major, as the mesh blob holds them):
+    what cull_meshes' LOD select + expansion, cull_meshlets and cull_triangles consume."""
+    from .synth import Scene, SceneSpec, make_scene
+
+    Lc = len(lods)
+    K0 = int(lods[0]["meshlets"].shape[0])
+    spec = SceneSpec(n_mesh_instances=n_mesh_instances, meshlets_per_mesh=K0, share_meshes=1, lod_count=Lc, with_geometry=False, seed=seed, **spec_kw)
+    s = make_scene(spec, device)
+    dev = s.device
+    cat = lambda key: torch.cat([l[key] for l in lods]).to(dev).contiguous()  # noqa: E731
+    s.meshlets, s.vidx, s.micro = cat("meshlets"), cat("vidx"), cat("micro")
+    s.bounds = torch.cat(list(bounds_per_lod)).to(dev).contiguous()
+    s.positions = positions_u16x4.to(dev).contiguous().clone()
+    counts = torch.tensor([int(l["meshlets"].shape[0]) for l in lods], dtype=torch.int64)
+    start = lambda sizes: torch.cumsum(sizes, 0) - sizes  # noqa: E731
+    s._lod_tables = {"meshlet_start": start(counts), "vidx_start": start(torch.tensor([int(l["vidx"].shape[0]) for l in lods], dtype=torch.int64)),
+                     "micro_start": start(torch.tensor([int(l["micro"].shape[0]) for l in lods], dtype=torch.int64)), "mesh_vertex_start": torch.zeros(1, dtype=torch.int64)}
+    l32 = s.lods.view(torch.int32)
+    l32[:, 10] = torch.tensor([int(l["indices"].shape[0]) for l in lods], dtype=torch.int32)
+    l32[:, 11] = counts.to(torch.int32)
+    l32[:, 12] = counts.to(torch.int32)
+    l32[:, 13] = torch.tensor([int(l["micro"].shape[0]) for l in lods], dtype=torch.int32)
+    l32[:, 14] = torch.tensor([int(l["vidx"].shape[0]) for l in lods], dtype=torch.int32)
+    l32[:, 15] = torch.tensor([l["error"] for l in lods], dtype=torch.float32).view(torch.int32)
+    m32 = s.meshes.view(torch.int32)
+    m32[0, 6] = int(positions_u16x4.shape[0])
+    m32[0, 7] = Lc
+    m32[0, 10:16] = mesh_bounds6.to(dev).to(torch.float32).view(torch.int32)
+    s.lod_meshlet_counts = counts.tolist()
+    s.spec = SceneSpec(**{**spec.__dict__, "with_geometry": True, "tris_per_meshlet": int(s.meshlets[:, 3].max().item()), "verts_per_meshlet": int(s.meshlets[:, 2].max().item())})
+    return s.bind()
