@@ -287,7 +287,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist):
             cam.near_clip = zn
             ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD, cull_camera=cam,
                                       stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
-            C.memmove(C.byref(cc, e * C.sizeof(L.CullGeometryContext)), C.byref(ctx.c()), C.sizeof(L.CullGeometryContext))
+            C.memmove(C.byref(cc[e]), C.byref(ctx.c()), C.sizeof(L.CullGeometryContext))
         groups.append((n, cf, cc))
 
     def check(st):
@@ -306,7 +306,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist):
     for n, cf, cc in groups:  # the last step's counters are still in the slots of each element
         for e in range(n):
             out = L.Counters()
-            check(lib.oxc_read_counters(ctxp, C.byref(cc, e * C.sizeof(L.CullGeometryContext)), C.byref(out), sp))
+            check(lib.oxc_read_counters(ctxp, C.byref(cc[e]), C.byref(out), sp))
             per_view.append((out.total_visible_meshlet_instances, out.cull_triangles_cmd_x))
     if dist is not None:
         dist.barrier()
