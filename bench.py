@@ -15,7 +15,8 @@ A frame takes well under a millisecond, so a STEP is `inner_reps` frames (stated
 work and `value` is not launch latency.  All inputs are generated in HBM; the ABI takes device pointers (no PCIe in the loop).
 
 N > 1 = configs[3]: the meshlet-instance array shards by contiguous range, 12.5M per rank ("100M sharded 8 ways"; weak
-scaling), shard-local ids and outputs.  Rank 0 builds the pyramid and broadcasts it over RCCL/xGMI; the per-rank counters
+scaling), shard-local ids and outputs.  Rank 0 builds the pyramid and broadcasts its top (levels >= 2, 5.6 MB; `--hiz-exchange whole`:
+all 89.5 MB) over RCCL/xGMI, the other ranks build levels 0-1 from their copy of the depth image; the per-rank counters
 {emitted, early, late, index_count} are all-gathered every frame.  The HiZ a frame culls against is the PRIOR frame's, so its
 build + broadcast run one frame ahead on a second stream (double-buffered pyramid) and overlap the cull.
 
@@ -66,9 +67,10 @@ def parse():
     ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: build + broadcast the pyramid on the cull stream instead of one frame ahead on a second stream")
-    ap.add_argument("--hiz-exchange", default="whole", choices=["whole", "top"],
-                    help="N > 1: 'whole' = rank 0 broadcasts every level of the pyramid (89.5 MB; no assumption about the other ranks); 'top' = only levels "
-                         ">= --hiz-top-level travel (5.6 MB at level 2) and every rank builds the lower levels from its own copy of the depth image")
+    ap.add_argument("--hiz-exchange", default="top", choices=["whole", "top"],
+                    help="N > 1: 'top' (default, the north star's wording: \"a broadcast of the top HiZ mips\") = only levels >= --hiz-top-level travel "
+                         "(5.6 MB at level 2) and every rank builds the lower levels from its own copy of the prior-frame depth image; 'whole' = rank 0 "
+                         "broadcasts every level (89.5 MB; assumes nothing about the other ranks).  Same pyramid bytes on every rank either way.")
     ap.add_argument("--hiz-top-level", type=int, default=2)
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: run the two exchanges (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
@@ -88,7 +90,7 @@ def respawn_under_torchrun(args):
     import subprocess
 
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not os.environ.get("OXC_BENCH_DEBUG_BACKEND"):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to report a {n_dev}-GPU number as {args.gpus}")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -114,13 +116,21 @@ def setup(args) -> Env:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={e.world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible (the cull path has no CPU fallback; --workload config1 is the CPU-only case)")
+    # OXC_BENCH_DEBUG_BACKEND=gloo: exercise the N > 1 control flow (sharding, double-buffered pyramid, events, exchanges) with all ranks on
+    # whatever GPUs exist -- a development aid for one-GPU boxes; the line it prints says so and is not a measurement
+    e.debug_backend = os.environ.get("OXC_BENCH_DEBUG_BACKEND", "")
+    if e.debug_backend:
+        e.local_rank = e.local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(e.local_rank)
     e.dev = torch.device("cuda", e.local_rank)
     e.dist = None
     if e.world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=e.dev)  # RCCL over xGMI
+        if e.debug_backend:
+            dist.init_process_group(e.debug_backend)
+        else:
+            dist.init_process_group("nccl", device_id=e.dev)  # RCCL over xGMI
         e.dist = dist
     e.r = RendererInstance(e.local_rank)
     e.stream = torch.cuda.Stream(device=e.dev)
@@ -361,6 +371,11 @@ def bench_config3(args, e):
         check(lib.oxc_pack_counters(ctxp, C.byref(c), C.c_void_p(my_counts.data_ptr()), sp))
         if e.native_comm:
             check(lib.oxc_exchange_counts(ctxp, C.c_void_p(my_counts.data_ptr()), C.c_void_p(gathered.data_ptr()), sp))
+        elif e.debug_backend:  # gloo has no device all-gather: stage through the host (debug aid only)
+            host = torch.zeros(world * 4, dtype=torch.int32)
+            stream.synchronize()
+            dist.all_gather_into_tensor(host, my_counts.cpu())
+            gathered.copy_(host)
         else:
             dist.all_gather_into_tensor(gathered, my_counts)
 
@@ -571,7 +586,7 @@ def bench_config3(args, e):
             "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris, "verts_per_meshlet": 64,
             "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
             "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
-            "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": world, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else "torch.distributed nccl (RCCL)",
+            "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
                                                          "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if top else "whole pyramid broadcast from rank 0"),
                                                          "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": overlap,
                                                          "counters_all_gather_bytes_per_rank": 16},
