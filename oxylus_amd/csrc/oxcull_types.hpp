@@ -103,7 +103,10 @@ constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block 
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
 constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel
-constexpr uint32_t kHizLdsTexels = 5632;      // LDS budget (floats) for the staged top HiZ mips: a 64x64 level and everything above it
+#ifndef OXC_HIZ_LDS_TEXELS
+#define OXC_HIZ_LDS_TEXELS 384
+#endif
+constexpr uint32_t kHizLdsTexels = OXC_HIZ_LDS_TEXELS;      // LDS budget (floats) for the staged top HiZ mips: the 16x16 level and everything above it (round 2: staging the 64x64 level too -- 22 KB per block -- measured 4 % slower: 93 / 121 us against 89 / 116)
 constexpr uint32_t kSuperStride = 64;         // words between super-chunk accumulators: one per 256 B so their atomics do not serialise on a cache line
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
 
