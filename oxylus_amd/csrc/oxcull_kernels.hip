@@ -688,13 +688,18 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
         for (int j = 0; j < G; j++) {
           if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
-          const uint4 b = bnd[j];
+          uint4 b = bnd[j];
+          // decode again instead of keeping phase 1's 24 floats alive across the phase boundary (see meshlets_plain_body): 103 / 116 -> 89
+          // VGPRs, 5 waves per SIMD (measured -2 us per launch; also recomputing the mask index, 81 VGPRs, costs more than it gives)
+          asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+          const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
+          const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
           const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
           const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
-          const int tier1 = cone_visible_fast(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+          const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
           bool cone_ok = tier1 == 1;
           if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-            const bool exact = cone_visible(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+            const bool exact = cone_visible(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
             cone_ok = tier1 == 2 ? exact : cone_ok;
           }
           st[j] = (need[j] != 0u && !cone_ok) ? (st[j] & ~2u) : st[j];
