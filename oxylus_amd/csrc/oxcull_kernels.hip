@@ -780,298 +780,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   }
 }
 
-template <bool OCCL, bool LATE, int G>
-OXC_DEV void meshlets_hiz_carry_body(const MeshletTestArgs& a) {
-  set_half_denorm_flush();
-  constexpr int kWaves = 16 / G;
-  constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
-  __shared__ uint32_t s_level_off[13];
-  __shared__ uint32_t s_lds_off[13];
-  __shared__ float s_hiz_top[kHizLdsTexels];
-  // occlusion candidates per wave: up to 63 carried over from the previous step + this step's
-  __shared__ uint4 s_strip[kWaves][G * 64 + 64];
-#ifdef OXC_HIZ_LDS_PAD
-  __shared__ uint32_t s_pad[OXC_HIZ_LDS_PAD / 4];  // occupancy experiment
-  if (threadIdx.x == 0 && a.n_cap == 0xFFFFFFFFu) s_pad[0] = 1;
-#endif
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
-  const uint32_t nwords = (N + 63u) / 64u;
-  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
-  if (threadIdx.x < 13) {
-    s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
-    s_lds_off[threadIdx.x] = a.hiz_lds_off[threadIdx.x];
-  }
-  // stage the top of the pyramid (levels >= hiz_lds_first) once per block
-  for (uint32_t k = a.hiz_lds_first; k < a.hiz_levels; k++) {
-    const uint32_t n = mip_dim(a.hiz_w, k) * mip_dim(a.hiz_h, k);
-    const float* src = a.hiz_data + a.hiz_level_off[k];
-    float* dst = s_hiz_top + a.hiz_lds_off[k];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-  }
-  __syncthreads();
-  HizView hiz;
-  hiz.data = a.hiz_data;
-  hiz.width = a.hiz_w;
-  hiz.height = a.hiz_h;
-  hiz.levels = a.hiz_levels;
-  hiz.lds = s_hiz_top;
-  hiz.lds_off = s_lds_off;
-  hiz.lds_first = a.hiz_lds_first;
-  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
-  const uint32_t last_index = N ? N - 1u : 0u;
-  const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
-
-  // The occlusion phase is ~500 instructions per 64-candidate batch and the kernel is instruction-bound, so lanes idling in it are
-  // the most expensive idle lanes of the path.  A step (G x 64 meshlets) yields ~66 candidates in the late pass and ~20 in the early
-  // one: run batch by batch per step that is 1.55 and 1 batches at 66 % and 31 % lane utilisation.  Here only FULL batches run; what
-  // is left (< 64 candidates) is carried in the strip into the next step and resolved there with that step's candidates (a step is
-  // never left pending for more than one step; the block's last step flushes).  The finish of a step with pending lanes -- mask
-  // update, emit ballots, chunk count -- is deferred until they are resolved.  Per-candidate arithmetic is unchanged.
-  constexpr uint32_t kNone = 0xFFFFFFFFu;
-  uint32_t carry_n = 0;      // wave-uniform: records strip[0 .. carry_n) belong to the previous step
-  bool prev_live = false;    // wave-uniform: the previous step awaits its finish
-  uint32_t p_group0 = 0;
-  uint32_t p_st[G], p_idx[G], p_midx[G];
-#pragma unroll
-  for (int j = 0; j < G; j++) p_st[j] = 0u, p_idx[j] = kNone, p_midx[j] = kMaskNone;
-  uint4* const strip = s_strip[wave];
-  // mask update, emit ballots and the survivor count of one finished step
-  auto finish_step = [&](uint32_t g0, const uint32_t (&stv)[G], const uint32_t (&midx)[G]) {
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      if (g0 + j >= nwords) continue;  // wave-uniform
-      const bool visible = (stv[j] & 2u) != 0u;
-      if (OCCL) update_visibility_mask(a.mask, midx[j], visible, (g0 + j) * 64 + lane < N && midx[j] != kMaskNone, lane);
-      const bool emit = visible && (!LATE || (stv[j] & 4u) == 0u);
-      const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
-      if (lane == 0) gptr(a.bits)[g0 + j] = bits;
-      cnt += (uint32_t)__popcll((unsigned long long)bits);
-    }
-    if (lane == 0 && g0 < nwords) {
-      const uint32_t wchunk = g0 / (uint32_t)G;
-      gptr(a.chunk_counts)[wchunk] = cnt;
-      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t group0 = chunk * 16 + wave * G;
-    uint2 rec[G];
-    uint32_t st[G];        // bit 0: still to be decided, bit 1: visible, bit 2: was_visible
-    uint32_t mask_idx[G];  // bit index into the persistent visibility mask
-    uint32_t cidx[G];      // strip index of this lane's occlusion candidate (kNone: none)
-    uint32_t n_step = 0;   // wave-uniform: candidates this step has appended so far
-#pragma unroll
-    for (int j = 0; j < G; j++) cidx[j] = kNone;
-#pragma unroll
-    for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
-      mask_idx[j] = 0;
-    }
-    for (;;) {
-      uint32_t mi_u = 0;
-      bool found = false;
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        const uint64_t p = __builtin_amdgcn_ballot_w64((st[j] & 1u) != 0u);
-        if (!found && p) {
-          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)p) - 1);
-          found = true;
-        }
-      }
-      if (!found) break;
-      const kconst32p row = const_row(a.cache, mi_u);
-      const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
-      const uint32_t vis_offset = row[kRowVisOffset];
-      uint4 bnd[G];
-      bool mine[G];
-      uint32_t mword[G];
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
-        bnd[j] = OXC_LOAD_BND(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
-        mword[j] = 0xFFFFFFFFu;
-        if (OCCL) {  // cull_meshlets_hiz.slang:45-51 (unconditional load: lanes of other instances re-read this instance's first word)
-          // (a mask index beyond the caller's buffer -- inconsistent visibility offsets -- reads as "not visible" and is
-          // never written: kMaskNone)
-          uint32_t mi_bit = vis_offset + (mine[j] ? rec[j].y : 0u);
-          const bool in_mask = mi_bit < a.mask_bits;
-          mi_bit = in_mask ? mi_bit : 0u;
-          mask_idx[j] = mine[j] ? (in_mask ? mi_bit : kMaskNone) : mask_idx[j];
-          mword[j] = load_global_u32(reinterpret_cast<uint64_t>(a.mask), mi_bit >> 5) >> (mi_bit & 31u);
-          mword[j] = in_mask ? mword[j] : 0u;
-        }
-      }
-      // ---- phase 1: bounds decode + frustum
-      float cx[G], cy[G], cz[G], ex[G], ey[G], ez[G];
-      uint32_t need[G];
-      uint64_t any_need = 0;
-      {
-        float pl[24], sg[18];
-#pragma unroll
-        for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
-#pragma unroll
-        for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint4 b = bnd[j];
-          const bool was_visible = (mword[j] & 1u) != 0u;
-          if (!LATE && __builtin_amdgcn_ballot_w64(mine[j] && was_visible) == 0) {
-            // early pass, and no meshlet of this group was visible last frame (cull_meshlets_hiz.slang:45-51: they all return
-            // before any test): skip the decode + frustum code for the whole group.  Visibility is coherent per instance, so
-            // this is most groups of a typical frame.
-            cx[j] = cy[j] = cz[j] = ex[j] = ey[j] = ez[j] = 0.0f;
-            need[j] = 0u;
-            st[j] = mine[j] ? 0u : st[j];
-            continue;
-          }
-          cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
-          ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
-          bool vis = mine[j] & (LATE ? true : was_visible);
-          vis = vis & test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j]);
-          const bool nc = vis & (((int32_t)b.w >> 24) != 127);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
-          need[j] = nc ? 1u : 0u;
-          any_need |= __builtin_amdgcn_ballot_w64(nc);
-          st[j] = mine[j] ? ((vis ? 2u : 0u) | (was_visible ? 4u : 0u)) : st[j];
-        }
-      }
-      // ---- phase 2: normal cone
-#ifdef OXC_ABL_NOCONE
-      any_need = 0;
-#endif
-      if (any_need) {
-        ConeU cu;
-#pragma unroll
-        for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
-#pragma unroll
-        for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
-#pragma unroll
-        for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
-        cu.scale_max = asf(row[kRowScale]);
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
-          uint4 b = bnd[j];
-          // decode again instead of keeping phase 1's 24 floats alive across the phase boundary (see meshlets_plain_body): 103 / 116 -> 89
-          // VGPRs, 5 waves per SIMD (measured -2 us per launch; also recomputing the mask index, 81 VGPRs, costs more than it gives)
-          asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-          const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
-          const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-          const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
-          const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
-          const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
-          bool cone_ok = tier1 == 1;
-          if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-            const bool exact = cone_visible(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
-            cone_ok = tier1 == 2 ? exact : cone_ok;
-          }
-          st[j] = (need[j] != 0u && !cone_ok) ? (st[j] & ~2u) : st[j];
-        }
-      }
-      // ---- phase 3a: this round's occlusion candidates join the strip behind the carried ones and the earlier rounds'.  The record
-      // carries the mesh instance in the 32 bits the cone operands occupied (a batch may mix instances now)
-      {
-        uint32_t base = carry_n + n_step;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint64_t vb = __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
-          if ((vb >> lane) & 1ull) {
-            const uint32_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb, 0u));
-            cidx[j] = k;
-            strip[k] = make_uint4(bnd[j].x, (bnd[j].y & 0xFFFFu) | (mi_u << 16), bnd[j].z, (bnd[j].w & 0xFFFFu) | (mi_u & 0xFFFF0000u));
-          }
-          base += (uint32_t)__popcll((unsigned long long)vb);
-        }
-        n_step = base - carry_n;
-      }
-    }
-    // ---- phase 3b: full batches of the strip through project_aabb + test_occlusion (cull_meshlets_hiz.slang:56-66)
-    {
-      const uint32_t total = carry_n + n_step;
-      const bool last_step = chunk + gridDim.x >= nchunks;
-      uint32_t n_proc = last_step ? total : (total & ~63u);
-      if (n_proc == 0u && carry_n > 0u) n_proc = total;  // the previous step's leftovers are resolved now, full batch or not
-#ifdef OXC_ABL_NOOCCL
-      n_proc = total;
-#endif
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
-#ifndef OXC_ABL_NOOCCL
-      for (uint32_t t0 = 0; t0 < n_proc; t0 += 64) {
-        const uint32_t t = t0 + (uint32_t)lane;
-        const bool act = t < n_proc;
-        const uint4 b = strip[act ? t : n_proc - 1u];
-        const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
-        const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-        const uint32_t mi = (b.y >> 16) | (b.w & 0xFFFF0000u);
-        bool occluded = false;
-        uint64_t pending = __builtin_amdgcn_ballot_w64(act);
-        while (pending) {  // one round per mesh instance in the batch (usually one, two at an instance or step boundary)
-          const uint32_t mi_b = readlane_u(mi, __ffsll((unsigned long long)pending) - 1);
-          const bool mine_b = act && mi == mi_b;
-          const kconst32p row_b = const_row(a.cache, mi_b);
-          float mvp[16];
-#pragma unroll
-          for (int k = 0; k < 16; k++) mvp[k] = asf(row_b[kRowMvp + k]);
-          const bool o = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, mine_b);
-          occluded = mine_b ? o : occluded;
-          pending &= ~__builtin_amdgcn_ballot_w64(mine_b);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (act) strip[t].x = occluded ? 1u : 0u;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-      for (uint32_t t = (uint32_t)lane; t < n_proc; t += 64) strip[t].x = 0u;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      // this step's candidates: resolved (index < n_proc) or pending with their index in the moved-down strip
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        if (cidx[j] != kNone) {
-          if (cidx[j] < n_proc) {
-            st[j] = strip[cidx[j]].x ? (st[j] & ~2u) : st[j];
-            cidx[j] = kNone;
-          } else {
-            cidx[j] -= n_proc;
-          }
-        }
-      }
-      // the previous step's pending candidates sat at [0, carry_n): all resolved now; finish that step
-      if (prev_live) {
-#pragma unroll
-        for (int j = 0; j < G; j++)
-          if (p_idx[j] != kNone) p_st[j] = strip[p_idx[j]].x ? (p_st[j] & ~2u) : p_st[j];
-        finish_step(p_group0, p_st, p_midx);
-        prev_live = false;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint32_t rem = total - n_proc;  // < 64
-      if (rem) {
-        uint4 tmp = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < rem) tmp = strip[n_proc + (uint32_t)lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if ((uint32_t)lane < rem) strip[lane] = tmp;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      carry_n = rem;
-      if (rem == 0u) {
-        finish_step(group0, st, mask_idx);
-      } else {
-        prev_live = true;
-        p_group0 = group0;
-#pragma unroll
-        for (int j = 0; j < G; j++) p_st[j] = st[j], p_idx[j] = cidx[j], p_midx[j] = mask_idx[j];
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // VSM multi-view meshlet test (passes/cull_meshlets_hpb.slang:25-99): directional cone +
 // camera frustum, then "visible if ANY dirty clipmap view passes frustum + page-pyramid test".
@@ -1697,17 +1405,10 @@ __global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) 
 #ifndef OXC_HIZ_WAVES
 #define OXC_HIZ_WAVES 1
 #endif
-#ifdef OXC_HIZ_NOCARRY
-constexpr bool kHizCarry = false;
-#else
-constexpr bool kHizCarry = true;
-#endif
 template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
 __global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? OXC_HIZ_WAVES : 1) void k_cull_meshlets_test(MeshletTestArgs a) {
   if constexpr (!HIZ)
     meshlets_plain_body<G>(a);
-  else if constexpr (kHizCarry && (OCCL || LATE))
-    meshlets_hiz_carry_body<OCCL, LATE, G>(a);
   else
     meshlets_hiz_body<OCCL, LATE, G>(a);
 }
