@@ -788,9 +788,14 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 // by k_cull_meshlets_emit<false,false> like the plain meshlet stage.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
+  // Round 2: the view loop is the OUTER loop of a wave step.  Round 1 walked one 64-meshlet group at a time and, inside it, one
+  // clipmap view at a time, so every (group, view) paid the scalar-load round trips of the view's plane / matrix row on its own --
+  // 0.89 ms per 10 M meshlets, latency-bound.  Here a wave holds G groups (all loads batched, as in the plain kernel) and a view's
+  // row is fetched once per instance round for all of them.
   set_half_denorm_flush();
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_level_off[13];
+  constexpr int G = (int)kGroupsPerWave;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = min(a.vis[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
@@ -803,85 +808,133 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   hpb.height = a.hpb_h;
   hpb.layers = a.hpb_layers;
   hpb.levels = a.hpb_levels;
-  const uint2* __restrict__ mlis = reinterpret_cast<const uint2*>(a.meshlet_instances);
-  constexpr int G = (int)kGroupsPerWave;
+  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
+  const uint32_t last_index = N ? N - 1u : 0u;
 
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    uint32_t cnt = 0;
-#pragma unroll 1
-    for (int j = 0; j < G; j++) {
-      const uint32_t group = chunk * (4 * G) + wave * G + j;
-      if (group >= nwords) break;  // wave-uniform
-      const uint32_t idx = group * 64 + lane;
-      const bool in = idx < N;
-      // (unconditional load at a clamped index: an exec-masked load block waits vmcnt(0) inside)
-      uint2 rec = load_stream_u2(reinterpret_cast<uint64_t>(mlis), min(idx, N - 1u));
-      if (!in) rec = make_uint2(0xFFFFFFFFu, 0u);
-      bool visible = false;
-      uint64_t pending = __builtin_amdgcn_ballot_w64(in);
-      while (pending) {
-        const uint32_t mi_u = readlane_u(rec.x, __ffsll((unsigned long long)pending) - 1);
-        const bool mine = in && rec.x == mi_u;
-        // camera row through scalar loads: planes + signs, then the normal matrix (never live together with the
-        // per-view operands below)
-        const kconst32p row = const_row(a.cache, mi_u);
-        const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
-        const uint4 b = load_stream_u4(bounds, mine ? rec.y : 0u);  // other lanes read element 0 (always valid)
-        const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16), cz = dequantize_half(b.y & 0xFFFFu);
-        const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16), ez = dequantize_half(b.w & 0xFFFFu);
-        bool cand = mine;
-        {
-          float pl[24], sg[18];
+    const uint32_t group0 = chunk * (4 * G) + wave * G;
+    uint2 rec[G];
+    uint32_t st[G];  // bit 0: still to be decided, bit 1: visible
 #pragma unroll
-          for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+    for (int j = 0; j < G; j++) rec[j] = load_stream_u2(mlis, min((group0 + j) * 64 + lane, last_index));
 #pragma unroll
-          for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
-          cand = cand & test_frustum_planes(pl, sg, cx, cy, cz, ex, ey, ez);
+    for (int j = 0; j < G; j++) st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
+    for (;;) {
+      uint32_t mi_u = 0;
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t p = __builtin_amdgcn_ballot_w64((st[j] & 1u) != 0u);
+        if (!found && p) {
+          mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)p) - 1);
+          found = true;
         }
-        if (__builtin_amdgcn_ballot_w64(cand)) {  // cull_meshlets_hpb.slang:53-54: directional cone
-          float nm[9];
+      }
+      if (!found) break;
+      const kconst32p row = const_row(a.cache, mi_u);
+      const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
+      uint4 bnd[G];
+      bool mine[G], cand[G], vis[G];
 #pragma unroll
-          for (int k = 0; k < 9; k++) nm[k] = asf(row[kRowNm + k]);
+      for (int j = 0; j < G; j++) {
+        mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
+        bnd[j] = load_stream_u4(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
+      }
+      // (centre / extent are decoded from the 16-byte record at every use: 6 conversions against 24 VGPRs held across the view loop)
+#define OXC_HPB_DECODE(b)                                                                                                             \
+  const float cxj = dequantize_half((b).x & 0xFFFFu), cyj = dequantize_half((b).x >> 16), czj = dequantize_half((b).y & 0xFFFFu); \
+  const float exj = dequantize_half((b).z & 0xFFFFu), eyj = dequantize_half((b).z >> 16), ezj = dequantize_half((b).w & 0xFFFFu)
+      uint64_t any_cand = 0;
+      {  // camera frustum (cull_meshlets_hpb.slang:49-52)
+        float pl[24], sg[18];
+#pragma unroll
+        for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+#pragma unroll
+        for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          OXC_HPB_DECODE(bnd[j]);
+          cand[j] = mine[j] & test_frustum_planes(pl, sg, cxj, cyj, czj, exj, eyj, ezj);
+          vis[j] = false;
+          any_cand |= __builtin_amdgcn_ballot_w64(cand[j]);
+        }
+      }
+      if (any_cand) {  // cull_meshlets_hpb.slang:53-54: directional cone
+        float nm[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) nm[k] = asf(row[kRowNm + k]);
+        any_cand = 0;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          if (__builtin_amdgcn_ballot_w64(cand[j]) == 0) continue;  // wave-uniform
+          const uint4 b = bnd[j];
           const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
           const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
-          cand = cand && cone_visible_directional(nm, a.light_dir[0], a.light_dir[1], a.light_dir[2], axy.x, axy.y, azc.x, azc.y);
+          cand[j] = cand[j] && cone_visible_directional(nm, a.light_dir[0], a.light_dir[1], a.light_dir[2], axy.x, axy.y, azc.x, azc.y);
+          any_cand |= __builtin_amdgcn_ballot_w64(cand[j]);
         }
-        bool vis = false;
-        for (uint32_t v = 0; v < a.clipmap_count; v++) {
-          if (a.dirty[v] == 0u) continue;                                // uniform
-          if (__builtin_amdgcn_ballot_w64(cand && !vis) == 0) break;    // nobody in the wave still needs a view
-          const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
-          const bool need = cand && !vis;
-          bool inside;
-          {
-            float vpl[24], vsg[18];
-#pragma unroll
-            for (int k = 0; k < 24; k++) vpl[k] = asf(vrow[kRowPlanes + k]);
-#pragma unroll
-            for (int k = 0; k < 18; k++) vsg[k] = asf(vrow[kRowSigns + k]);
-            inside = need & test_frustum_planes(vpl, vsg, cx, cy, cz, ex, ey, ez);
-          }
-          if (__builtin_amdgcn_ballot_w64(inside)) {  // wave-uniform
-            float vmvp[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) vmvp[k] = asf(vrow[kRowMvp + k]);
-            const oxc_virtual_clipmap* cm = a.clipmaps + v;
-            const float z_near = cm->z_near;
-            const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
-            if (inside) {
-              float sa[6];
-              if (project_aabb(vmvp, z_near, cx, cy, cz, ex, ey, ez, sa))
-                vis = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
-              else
-                vis = true;
-            }
-          }
-        }
-        if (mine) visible = vis;
-        pending &= ~__builtin_amdgcn_ballot_w64(mine);
       }
-      const uint64_t bits = __ballot(visible);
-      if (lane == 0) a.bits[group] = bits;
+      // "visible if ANY dirty clipmap view passes frustum + page test" (:59-79); the reference's break on the first hit has no side effect
+      for (uint32_t v = 0; v < a.clipmap_count && any_cand; v++) {
+        if (a.dirty[v] == 0u) continue;  // uniform
+        uint64_t need_any = 0;
+#pragma unroll
+        for (int j = 0; j < G; j++) need_any |= __builtin_amdgcn_ballot_w64(cand[j] && !vis[j]);
+        if (need_any == 0) break;  // nobody in the wave still needs a view
+        const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
+        bool inside[G];
+        uint64_t any_inside = 0;
+        {
+          float vpl[24], vsg[18];
+#pragma unroll
+          for (int k = 0; k < 24; k++) vpl[k] = asf(vrow[kRowPlanes + k]);
+#pragma unroll
+          for (int k = 0; k < 18; k++) vsg[k] = asf(vrow[kRowSigns + k]);
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            inside[j] = false;
+            if (__builtin_amdgcn_ballot_w64(cand[j] && !vis[j]) == 0) continue;  // wave-uniform
+            uint4 b = bnd[j];
+            asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+            OXC_HPB_DECODE(b);
+            inside[j] = (cand[j] && !vis[j]) & test_frustum_planes(vpl, vsg, cxj, cyj, czj, exj, eyj, ezj);
+            any_inside |= __builtin_amdgcn_ballot_w64(inside[j]);
+          }
+        }
+        if (any_inside) {
+          float vmvp[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) vmvp[k] = asf(vrow[kRowMvp + k]);
+          const oxc_virtual_clipmap* cm = a.clipmaps + v;
+          const float z_near = cm->z_near;
+          const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            if (__builtin_amdgcn_ballot_w64(inside[j]) == 0) continue;  // wave-uniform
+            uint4 b = bnd[j];
+            asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+            OXC_HPB_DECODE(b);
+            if (inside[j]) {
+              float sa[6];
+              if (project_aabb(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa))
+                vis[j] = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
+              else
+                vis[j] = true;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one group's projection at a time (four interleaved ones need 147 VGPRs)
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G; j++) st[j] = mine[j] ? ((cand[j] && vis[j]) ? 2u : 0u) : st[j];
+#undef OXC_HPB_DECODE
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      if (group0 + j >= nwords) continue;  // wave-uniform
+      const uint64_t bits = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u);
+      if (lane == 0) gptr(a.bits)[group0 + j] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
     __syncthreads();
