@@ -111,8 +111,11 @@ oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hi
 oxc_status order_stream(oxc_ctx* ctx, hipStream_t s) {
   if (ctx->has_last_stream && ctx->last_stream != s) {
     if (!ctx->order_event) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
-    OXC_HIP(ctx, hipEventRecord(ctx->order_event, ctx->last_stream));
-    OXC_HIP(ctx, hipStreamWaitEvent(s, ctx->order_event, 0));
+    // (the previous stream may have been destroyed by its owner since: its work is complete then, nothing to wait for)
+    if (hipEventRecord(ctx->order_event, ctx->last_stream) == hipSuccess)
+      OXC_HIP(ctx, hipStreamWaitEvent(s, ctx->order_event, 0));
+    else
+      (void)hipGetLastError();
   }
   ctx->last_stream = s;
   ctx->has_last_stream = true;

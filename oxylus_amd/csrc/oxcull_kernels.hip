@@ -559,10 +559,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   __shared__ uint32_t s_lds_off[13];
   __shared__ float s_hiz_top[kHizLdsTexels];
   __shared__ uint4 s_strip[OCCL_OR_LATE ? kWaves : 1][G * 64];  // occlusion candidates of one round, per wave
-#ifdef OXC_HIZ_LDS_PAD
-  __shared__ uint32_t s_pad[OXC_HIZ_LDS_PAD / 4];  // occupancy experiment
-  if (threadIdx.x == 0 && a.n_cap == 0xFFFFFFFFu) s_pad[0] = 1;
-#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
@@ -1455,11 +1451,8 @@ __global__ __launch_bounds__(1024) void k_scan_mesh_counts(ScanArgs a) { scan_bo
 __global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) { expand_body(a); }
 // (Capping SGPRs at 80 for 8 waves/SIMD -- the compiler otherwise keeps ~106 live -- was measured:
 // plain kernel 36.7 -> 38.8 us per 4M meshlets, HiZ variant 183 -> 175 us; not kept.)
-#ifndef OXC_HIZ_WAVES
-#define OXC_HIZ_WAVES 1
-#endif
 template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
-__global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? OXC_HIZ_WAVES : 1) void k_cull_meshlets_test(MeshletTestArgs a) {
+__global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
   if constexpr (!HIZ)
     meshlets_plain_body<G>(a);
   else
@@ -1581,9 +1574,6 @@ constexpr int kHizGroups = (int)kHizGroupsPerWave;  // groups per wave of the Hi
 // are worse than both).
 template <class K>
 static uint32_t resident_grid(K kernel, uint32_t block, uint32_t num_cus) {
-#ifdef OXC_HIZ_GRID_MULT
-  return num_cus * (uint32_t)(OXC_HIZ_GRID_MULT);
-#endif
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, 0) != hipSuccess || per_cu <= 0) return num_cus * 8u;
   return (uint32_t)per_cu * num_cus;
