@@ -8,7 +8,7 @@ mkdir -p "$ROOT/gpurun_out/profiles_out"
 cd /tmp && export TMPDIR=/tmp
 for w in bounds loop vsm config5; do
   rm -rf /tmp/aux_$w
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/aux_$w -o t -- python $ROOT/bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 3 > /tmp/aux_$w.json 2>/tmp/aux_$w.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/aux_$w -o t -- python $ROOT/bench.py --workload $w --no-cpu-baseline > /tmp/aux_$w.json 2>/tmp/aux_$w.log
   f=$(find /tmp/aux_$w -name t_kernel_stats.csv | head -1)
   (cd $ROOT && python tools/summarize_profiles.py ${TAG}_aux_$w --stats $f --note "bench.py --workload $w --steps 20 --warmup 3 under rocprofv3 --kernel-trace --stats" > /dev/null && \
      python - <<PY
