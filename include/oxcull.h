@@ -429,8 +429,14 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* context, void* hi
  * the rules used instead are stated here and in the checker:
  *   vertex  VisBufferData(index) -> (meshlet instance, corner); Meshlet::index, Mesh::decode_position;
  *           world = mul(world, (p,1)).xyz, clip = mul(projection_view, (world,1))              (as vs_main);
- *   setup   a triangle with any clip.w <= 0 or a screen coordinate beyond +-2^20 pixels is dropped (no clipper);
- *           screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel; back faces (fixed-point
+ *   clip    Sutherland-Hodgman against five planes in this order: w >= 2^-10, 64 w - x >= 0, 64 w + x >= 0, 64 w - y >= 0,
+ *           64 w + y >= 0 (a 64x guard band: every screen coordinate stays inside the +-2^20 px fixed-point range for extents up
+ *           to 16384; the reference's fixed-function clipper stands here).  A vertex with distance d >= 0 is inside.  On a crossing
+ *           edge with inside end I and outside end O the new vertex is I + t (O - I), t = d(I) / (d(I) - d(O)), binary32, no
+ *           contraction, all four clip coordinates -- the same value for both triangles that share the edge.  The polygon
+ *           (<= 8 corners) is drawn as the fan (p0, pk, pk+1), each with the vis value of the source triangle; a triangle inside
+ *           every plane is untouched (round 1 had no clipper and dropped triangles with a corner at w <= 0);
+ *   setup   screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel; back faces (fixed-point
  *           area >= 0, the orientation cull_triangles' determinant test calls back-facing) are dropped;
  *   cover   pixel centres, integer edge functions, top-left rule;
  *   depth   z/w interpolated in binary64, ((e0 z0 + e1 z1) + e2 z2) * (1 / area) with the exact integer edge values e_i, rounded to

@@ -410,6 +410,13 @@ def draw_visbuffer(scene, meshlet_instances: torch.Tensor, indices: torch.Tensor
                              width, height, 9 if wide else 8, _p(visdepth))
 
 
+def draw_clipped_count() -> int:
+    """Triangles of the last draw_visbuffer call that crossed a clip plane and survived it."""
+    f = lib().orc_draw_clipped_count
+    f.restype = C.c_uint32
+    return int(f())
+
+
 def resolve_visbuffer(visdepth: torch.Tensor):
     h, w = visdepth.shape
     depth = torch.zeros((h, w), dtype=torch.float32)

@@ -1203,15 +1203,83 @@ static int edge_inclusive(int64_t ax, int64_t ay, int64_t bx, int64_t by) {
   return dy > 0 || (dy == 0 && dx < 0);
 }
 
+/* clip planes of the stated rules: w >= 2^-10 and the guard band |x|, |y| <= 64 w */
+#define ORC_CLIP_WMIN 0.0009765625f
+#define ORC_CLIP_GUARD 64.0f
+static float clip_distance(const float* v, int plane) {
+  switch (plane) {
+    case 0: return v[3] - ORC_CLIP_WMIN;
+    case 1: return ORC_CLIP_GUARD * v[3] - v[0];
+    case 2: return ORC_CLIP_GUARD * v[3] + v[0];
+    case 3: return ORC_CLIP_GUARD * v[3] - v[1];
+    default: return ORC_CLIP_GUARD * v[3] + v[1];
+  }
+}
+
+/* setup + coverage + depth for one (possibly clipped) triangle given in clip coordinates */
+static void raster_clip_triangle(const float* c0, const float* c1, const float* c2, uint32_t vis_out, uint32_t W, uint32_t H, uint64_t* visdepth) {
+  const float* cl[3] = {c0, c1, c2};
+  int64_t X[3], Y[3];
+  float z[3];
+  for (int k = 0; k < 3; k++) {
+    const float* clip = cl[k];
+    if (!(clip[3] > 0.0f)) return;
+    float sx = ((clip[0] / clip[3]) * 0.5f + 0.5f) * (float)W;
+    float sy = ((clip[1] / clip[3]) * 0.5f + 0.5f) * (float)H;
+    z[k] = clip[2] / clip[3];
+    if (!(fabsf(sx) <= 1048576.0f) || !(fabsf(sy) <= 1048576.0f)) return;
+    X[k] = (int64_t)floorf(sx * 256.0f + 0.5f);
+    Y[k] = (int64_t)floorf(sy * 256.0f + 0.5f);
+  }
+  int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+  if (area >= 0) return; /* cullMode eBack: det(xyw) > 0 <=> positive area (cull.slang:169-171); 0 = no coverage */
+  /* orient positively: swap corners 1 and 2 */
+  int64_t t = X[1]; X[1] = X[2]; X[2] = t;
+  t = Y[1]; Y[1] = Y[2]; Y[2] = t;
+  float tz = z[1]; z[1] = z[2]; z[2] = tz;
+  area = -area;
+  int64_t minx = X[0] < X[1] ? X[0] : X[1], maxx = X[0] > X[1] ? X[0] : X[1];
+  int64_t miny = Y[0] < Y[1] ? Y[0] : Y[1], maxy = Y[0] > Y[1] ? Y[0] : Y[1];
+  minx = minx < X[2] ? minx : X[2]; maxx = maxx > X[2] ? maxx : X[2];
+  miny = miny < Y[2] ? miny : Y[2]; maxy = maxy > Y[2] ? maxy : Y[2];
+  /* pixel (px,py) has its centre at (256 px + 128, 256 py + 128) */
+  int64_t px0 = (minx - 128 + 255) >> 8, px1 = (maxx - 128) >> 8;
+  int64_t py0 = (miny - 128 + 255) >> 8, py1 = (maxy - 128) >> 8;
+  if (px0 < 0) px0 = 0;
+  if (py0 < 0) py0 = 0;
+  if (px1 > (int64_t)W - 1) px1 = (int64_t)W - 1;
+  if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
+  const int64_t b0 = edge_inclusive(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
+  const int64_t b1 = edge_inclusive(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
+  const int64_t b2 = edge_inclusive(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
+  const double inv_area = 1.0 / (double)area; /* one reciprocal per triangle */
+  for (int64_t py = py0; py <= py1; py++)
+    for (int64_t px = px0; px <= px1; px++) {
+      int64_t cxp = px * 256 + 128, cyp = py * 256 + 128;
+      int64_t e0 = edge_fn(X[1], Y[1], X[2], Y[2], cxp, cyp); /* weight of corner 0 */
+      int64_t e1 = edge_fn(X[2], Y[2], X[0], Y[0], cxp, cyp);
+      int64_t e2 = edge_fn(X[0], Y[0], X[1], Y[1], cxp, cyp);
+      if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) continue;
+      double zd = (((double)e0 * (double)z[0] + (double)e1 * (double)z[1]) + (double)e2 * (double)z[2]) * inv_area;
+      float zf = (float)zd;
+      if (!(zf > 0.0f) || zf > 1.0f) continue;
+      uint64_t packed = ((uint64_t)f2u(zf) << 32) | vis_out;
+      uint64_t* dst = &visdepth[(size_t)py * W + (size_t)px];
+      if (packed > *dst) *dst = packed;
+    }
+}
+
+static uint32_t g_draw_clipped; /* triangles of the last orc_draw_visbuffer that crossed a clip plane (tests: "the clipper ran") */
+uint32_t orc_draw_clipped_count(void) { return g_draw_clipped; }
+
 void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                         const orc_meshlet_instance* meshlet_instances, const uint32_t* indices, uint32_t index_count, const float* pv, uint32_t W,
                         uint32_t H, uint32_t corner_bits, uint64_t* visdepth) {
   const uint32_t corner_mask = (1u << corner_bits) - 1u;
+  g_draw_clipped = 0;
   for (uint32_t i = 0; i + 2 < index_count; i += 3) {
-    int64_t X[3], Y[3];
-    float z[3];
+    float poly[2][9][4];
     uint32_t vis_out = 0;
-    int drop = 0;
     for (int k = 0; k < 3; k++) {
       /* vs_main, visbuffer_encode.slang:24-49 */
       uint32_t data = indices[i + k];
@@ -1225,61 +1293,42 @@ void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const o
       uint32_t vi = ((const uint32_t*)(uintptr_t)lod->indirect_vertex_indices)[ml->indirect_vertex_index_offset + li];
       const uint16_t* pos = (const uint16_t*)(uintptr_t)mesh->vertex_positions;
       float p[3] = {orc_dequantize_half(pos[(size_t)vi * 4 + 0]), orc_dequantize_half(pos[(size_t)vi * 4 + 1]), orc_dequantize_half(pos[(size_t)vi * 4 + 2])};
-      float world[4], clip[4];
+      float world[4];
       mul_mp(xform(transforms, inst->transform_index), p, world);
-      mul_mp(pv, world, clip);
+      mul_mp(pv, world, poly[0][k]);
       if (k == 0) vis_out = (mli_index << 8) | ((corner / 3u) & 0xFFu); /* VisBufferData(mli, triangle_index / 3).encode() */
-      if (!(clip[3] > 0.0f)) {
-        drop = 1;
-        continue;
-      }
-      float sx = ((clip[0] / clip[3]) * 0.5f + 0.5f) * (float)W;
-      float sy = ((clip[1] / clip[3]) * 0.5f + 0.5f) * (float)H;
-      z[k] = clip[2] / clip[3];
-      if (!(fabsf(sx) <= 1048576.0f) || !(fabsf(sy) <= 1048576.0f)) {
-        drop = 1;
-        continue;
-      }
-      X[k] = (int64_t)floorf(sx * 256.0f + 0.5f);
-      Y[k] = (int64_t)floorf(sy * 256.0f + 0.5f);
     }
-    if (drop) continue;
-    int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
-    if (area >= 0) continue; /* cullMode eBack: det(xyw) > 0 <=> positive area (cull.slang:169-171); 0 = no coverage */
-    /* orient positively: swap corners 1 and 2 */
-    int64_t t = X[1]; X[1] = X[2]; X[2] = t;
-    t = Y[1]; Y[1] = Y[2]; Y[2] = t;
-    float tz = z[1]; z[1] = z[2]; z[2] = tz;
-    area = -area;
-    int64_t minx = X[0] < X[1] ? X[0] : X[1], maxx = X[0] > X[1] ? X[0] : X[1];
-    int64_t miny = Y[0] < Y[1] ? Y[0] : Y[1], maxy = Y[0] > Y[1] ? Y[0] : Y[1];
-    minx = minx < X[2] ? minx : X[2]; maxx = maxx > X[2] ? maxx : X[2];
-    miny = miny < Y[2] ? miny : Y[2]; maxy = maxy > Y[2] ? maxy : Y[2];
-    /* pixel (px,py) has its centre at (256 px + 128, 256 py + 128) */
-    int64_t px0 = (minx - 128 + 255) >> 8, px1 = (maxx - 128) >> 8;
-    int64_t py0 = (miny - 128 + 255) >> 8, py1 = (maxy - 128) >> 8;
-    if (px0 < 0) px0 = 0;
-    if (py0 < 0) py0 = 0;
-    if (px1 > (int64_t)W - 1) px1 = (int64_t)W - 1;
-    if (py1 > (int64_t)H - 1) py1 = (int64_t)H - 1;
-    const int64_t b0 = edge_inclusive(X[1], Y[1], X[2], Y[2]) ? 0 : -1;
-    const int64_t b1 = edge_inclusive(X[2], Y[2], X[0], Y[0]) ? 0 : -1;
-    const int64_t b2 = edge_inclusive(X[0], Y[0], X[1], Y[1]) ? 0 : -1;
-    const double inv_area = 1.0 / (double)area; /* one reciprocal per triangle */
-    for (int64_t py = py0; py <= py1; py++)
-      for (int64_t px = px0; px <= px1; px++) {
-        int64_t cxp = px * 256 + 128, cyp = py * 256 + 128;
-        int64_t e0 = edge_fn(X[1], Y[1], X[2], Y[2], cxp, cyp); /* weight of corner 0 */
-        int64_t e1 = edge_fn(X[2], Y[2], X[0], Y[0], cxp, cyp);
-        int64_t e2 = edge_fn(X[0], Y[0], X[1], Y[1], cxp, cyp);
-        if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) continue;
-        double zd = (((double)e0 * (double)z[0] + (double)e1 * (double)z[1]) + (double)e2 * (double)z[2]) * inv_area;
-        float zf = (float)zd;
-        if (!(zf > 0.0f) || zf > 1.0f) continue;
-        uint64_t packed = ((uint64_t)f2u(zf) << 32) | vis_out;
-        uint64_t* dst = &visdepth[(size_t)py * W + (size_t)px];
-        if (packed > *dst) *dst = packed;
+    /* Sutherland-Hodgman against the five planes (the fixed-function clipper the graphics pipeline runs between vs_main and the
+     * rasteriser; round 1 dropped every triangle with a corner at w <= 0).  A new vertex is always interpolated from the inside end
+     * I of the crossing edge to its outside end O: t = d(I) / (d(I) - d(O)), v = I + t (O - I), so both triangles sharing the edge
+     * compute the same vertex.  A triangle inside every plane passes through untouched. */
+    int n = 3, cur = 0, crossed = 0;
+    for (int pl = 0; pl < 5 && n >= 3; pl++) {
+      int m = 0;
+      for (int k = 0; k < n; k++) {
+        const float* p = poly[cur][k];
+        const float* q = poly[cur][(k + 1) % n];
+        float dp = clip_distance(p, pl), dq = clip_distance(q, pl);
+        int ip = dp >= 0.0f, iq = dq >= 0.0f;
+        if (ip) {
+          for (int c = 0; c < 4; c++) poly[cur ^ 1][m][c] = p[c];
+          m++;
+        }
+        if (ip != iq) {
+          crossed = 1;
+          const float* I = ip ? p : q;
+          const float* O = ip ? q : p;
+          float dI = ip ? dp : dq, dO = ip ? dq : dp;
+          float t = dI / (dI - dO);
+          for (int c = 0; c < 4; c++) poly[cur ^ 1][m][c] = I[c] + t * (O[c] - I[c]);
+          m++;
+        }
       }
+      n = m;
+      cur ^= 1;
+    }
+    g_draw_clipped += (uint32_t)(crossed && n >= 3);
+    for (int k = 1; k + 1 < n; k++) raster_clip_triangle(poly[cur][0], poly[cur][k], poly[cur][k + 1], vis_out, W, H, visdepth);
   }
 }
 

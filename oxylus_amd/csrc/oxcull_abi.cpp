@@ -1050,7 +1050,7 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   if (!ctx->raster_scratch) {
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
       return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: the first call allocates its scratch; make one un-captured call first");
-    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + 256);
+    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + 256 + (size_t)kRasterBigCapacity * 4);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster scratch)", e);
   }
   DrawArgs a;
@@ -1069,6 +1069,9 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   a.big_capacity = kRasterBigCapacity;
   a.big_count = static_cast<uint32_t*>(ctx->raster_scratch);
   a.big_list = reinterpret_cast<TriSetup*>(static_cast<char*>(ctx->raster_scratch) + 256);
+  a.clip_capacity = kRasterBigCapacity;  // more than 2^20 clipped triangles in one draw: the excess is dropped
+  a.clip_count = static_cast<uint32_t*>(ctx->raster_scratch) + 32;
+  a.clip_list = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->raster_scratch) + 256 + (size_t)kRasterBigCapacity * kTriSetupBytes);
   launch_draw_visbuffer(a, d->clear != 0, dep.dptr ? reinterpret_cast<float*>(static_cast<char*>(dep.dptr) + dep.level_offset[0]) : nullptr,
                         static_cast<uint32_t*>(d->visbuffer_attachment.dptr), ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());

@@ -321,6 +321,9 @@ struct DrawArgs {
   uint32_t big_capacity;
   TriSetup* big_list;
   uint32_t* big_count;
+  uint32_t clip_capacity;  // triangles that cross a clip plane: ids queued for k_draw_clipped
+  uint32_t* clip_list;
+  uint32_t* clip_count;
 };
 void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint32_t* vis_out, uint32_t max_grid, hipStream_t s);
 constexpr uint32_t kTriSetupBytes = 40;

@@ -5,7 +5,7 @@
 // reversed Z) as a compute rasteriser, so that early cull -> draw -> depth -> generate_hiz -> late cull -> draw can run
 // frame after frame without a graphics queue.  The fixed-function rasteriser's exact rules cannot be matched, so
 // the rules are stated (include/oxcull.h, oxc_draw_visbuffer) and implemented twice (here and in the CPU checker):
-// 1/256-pixel snapping, integer edge functions with a top-left rule, z/w interpolated in binary64 from the exact
+// clipping against w >= 2^-10 and a 64x guard band (round 2: triangles crossing the camera plane used to be dropped), 1/256-pixel snapping, integer edge functions with a top-left rule, z/w interpolated in binary64 from the exact
 // edge values, and per pixel the maximum of (depth bits << 32 | vis) through a 64-bit atomic max -- the "R64
 // visbuffer" the reference's own note wishes for (visbuffer.slang:43-45), order-independent by construction.
 //
@@ -93,14 +93,24 @@ OXC_DEV void tri_fragment(const TriRaster& r, int64_t e0, int64_t e1, int64_t e2
   atomicMax(&visdepth[(size_t)py * W + (size_t)px], packed);
 }
 
-// vs_main (visbuffer_encode.slang:24-49) for the three corners of triangle `tri` + the stated setup rules.
-// Returns false when the triangle is dropped (w <= 0, guard band, back face / zero area).
-OXC_DEV bool tri_setup(const DrawArgs& a, uint32_t tri, TriSetup& out) {
+// Clip planes of the stated rules (include/oxcull.h): w >= kClipWMin and the guard band |x|, |y| <= kClipGuard * w, which keeps every
+// screen coordinate inside the +-2^20 px fixed-point range for extents up to 16384.
+constexpr float kClipWMin = 0.0009765625f;  // 2^-10
+constexpr float kClipGuard = 64.0f;
+OXC_DEV float clip_distance(const float* v, int plane) {
+  switch (plane) {
+    case 0: return v[3] - kClipWMin;
+    case 1: return kClipGuard * v[3] - v[0];
+    case 2: return kClipGuard * v[3] + v[0];
+    case 3: return kClipGuard * v[3] - v[1];
+    default: return kClipGuard * v[3] + v[1];
+  }
+}
+
+// vs_main (visbuffer_encode.slang:24-49) for the three corners of triangle `tri`: clip coordinates + the encoded vis value.
+OXC_DEV void tri_clip_coords(const DrawArgs& a, uint32_t tri, float (&clip)[3][4], uint32_t& vis_out) {
   const uint32_t corner_bits = a.wide ? 9u : 8u;
   const uint32_t corner_mask = (1u << corner_bits) - 1u;
-  int64_t X[3], Y[3];
-  float z[3];
-  bool drop = false;
   // The three indices of a triangle written by cull_triangles name the same meshlet instance, so everything up to
   // the Meshlet record and the world matrix is fetched once and reused while the instance id repeats (vs_main
   // decodes every index on its own; an index list that mixes instances inside a triangle still works, slower).
@@ -133,30 +143,45 @@ OXC_DEV bool tri_setup(const DrawArgs& a, uint32_t tri, TriSetup& out) {
     const uint32_t vi = load_global_u32(vidx, ml.x + li);
     const uint2 q = load_global_u2(positions, vi);  // u16x4
     const float p[3] = {dequantize_half(q.x & 0xFFFFu), dequantize_half(q.x >> 16), dequantize_half(q.y & 0xFFFFu)};
-    float world[3], clip[4];
+    float world[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) world[r] = ((w[r * 4 + 0] * p[0] + w[r * 4 + 1] * p[1]) + w[r * 4 + 2] * p[2]) + w[r * 4 + 3];
 #pragma unroll
-    for (int r = 0; r < 4; r++) clip[r] = ((OXC_M(a.pv, r, 0) * world[0] + OXC_M(a.pv, r, 1) * world[1]) + OXC_M(a.pv, r, 2) * world[2]) + OXC_M(a.pv, r, 3);
-    if (k == 0) out.vis = (mli_index << 8) | ((corner / 3u) & 0xFFu);  // VisBufferData(mli, triangle_index / 3).encode()
-    if (!(clip[3] > 0.0f)) {
-      drop = true;
-      X[k] = Y[k] = 0;
-      z[k] = 0.0f;
-      continue;
-    }
+    for (int r = 0; r < 4; r++) clip[k][r] = ((OXC_M(a.pv, r, 0) * world[0] + OXC_M(a.pv, r, 1) * world[1]) + OXC_M(a.pv, r, 2) * world[2]) + OXC_M(a.pv, r, 3);
+    if (k == 0) vis_out = (mli_index << 8) | ((corner / 3u) & 0xFFu);  // VisBufferData(mli, triangle_index / 3).encode()
+  }
+}
+
+// 0: every corner inside every clip plane (the usual case); 1: crosses a plane (goes to the clipper); 2: all corners outside one plane
+OXC_DEV int tri_clip_class(const float (&clip)[3][4]) {
+  bool crosses = false;
+#pragma unroll
+  for (int pl = 0; pl < 5; pl++) {
+    const bool i0 = clip_distance(clip[0], pl) >= 0.0f, i1 = clip_distance(clip[1], pl) >= 0.0f, i2 = clip_distance(clip[2], pl) >= 0.0f;
+    if (!i0 && !i1 && !i2) return 2;
+    crosses |= !(i0 && i1 && i2);
+  }
+  return crosses ? 1 : 0;
+}
+
+// The stated setup rules for one (possibly clipped) triangle given in clip coordinates.  Returns false when it is dropped
+// (back face / zero area; w <= 0 or a coordinate beyond the fixed-point range cannot happen behind the clipper but are kept as guards).
+OXC_DEV bool tri_finish(const DrawArgs& a, const float* c0, const float* c1, const float* c2, uint32_t vis, TriSetup& out) {
+  const float* cl[3] = {c0, c1, c2};
+  int64_t X[3], Y[3];
+  float z[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float* clip = cl[k];
+    if (!(clip[3] > 0.0f)) return false;
     const float sx = ((clip[0] / clip[3]) * 0.5f + 0.5f) * (float)a.width;
     const float sy = ((clip[1] / clip[3]) * 0.5f + 0.5f) * (float)a.height;
     z[k] = clip[2] / clip[3];
-    if (!(__builtin_fabsf(sx) <= 1048576.0f) || !(__builtin_fabsf(sy) <= 1048576.0f)) {
-      drop = true;
-      X[k] = Y[k] = 0;
-      continue;
-    }
+    if (!(__builtin_fabsf(sx) <= 1048576.0f) || !(__builtin_fabsf(sy) <= 1048576.0f)) return false;
     X[k] = (int64_t)__builtin_floorf(sx * 256.0f + 0.5f);
     Y[k] = (int64_t)__builtin_floorf(sy * 256.0f + 0.5f);
   }
-  if (drop) return false;
+  out.vis = vis;
   const int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
   if (area >= 0) return false;  // cullMode eBack: det(xyw) > 0 <=> positive area; 0 = no coverage
   // orient positively: swap corners 1 and 2
@@ -172,37 +197,95 @@ OXC_DEV bool tri_setup(const DrawArgs& a, uint32_t tri, TriSetup& out) {
   return true;
 }
 
+// rasterise one set-up triangle from this lane (small ones) or queue it for k_draw_big
+OXC_DEV void tri_emit(const DrawArgs& a, const TriSetup& t) {
+  TriRaster r;
+  tri_prepare(t, a.width, a.height, r);
+  if (r.px1 < r.px0 || r.py1 < r.py0) return;
+  bool small = (r.px1 - r.px0) < kSmallSpan && (r.py1 - r.py0) < kSmallSpan;
+  if (!small) {
+    const uint32_t slot = atomicAdd(a.big_count, 1u);
+    if (slot < a.big_capacity) {
+      a.big_list[slot] = t;
+      return;
+    }
+    // the list is full: this lane walks the box itself (slow, correct)
+  }
+  int64_t r0, r1, r2;  // edge values at the start of the row: stepped exactly (integers) instead of re-multiplied
+  tri_edges(r, r.px0, r.py0, r0, r1, r2);
+  for (int64_t py = r.py0; py <= r.py1; py++) {
+    int64_t e0 = r0, e1 = r1, e2 = r2;
+    for (int64_t px = r.px0; px <= r.px1; px++) {
+      tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
+      e0 += r.dx0;
+      e1 += r.dx1;
+      e2 += r.dx2;
+    }
+    r0 += r.dy0;
+    r1 += r.dy1;
+    r2 += r.dy2;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_draw_setup(DrawArgs a) {
   set_half_denorm_flush();
   const uint32_t tris = a.draw_cmd[0] / 3u;  // VkDrawIndexedIndirectCommand.indexCount
   for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < tris; tri += gridDim.x * blockDim.x) {
-    TriSetup t;
-    if (!tri_setup(a, tri, t)) continue;
-    TriRaster r;
-    tri_prepare(t, a.width, a.height, r);
-    if (r.px1 < r.px0 || r.py1 < r.py0) continue;
-    bool small = (r.px1 - r.px0) < kSmallSpan && (r.py1 - r.py0) < kSmallSpan;
-    if (!small) {
-      const uint32_t slot = atomicAdd(a.big_count, 1u);
-      if (slot < a.big_capacity) {
-        a.big_list[slot] = t;
-        continue;
-      }
-      small = true;  // the list is full: this lane walks the box itself (slow, correct)
+    float clip[3][4];
+    uint32_t vis;
+    tri_clip_coords(a, tri, clip, vis);
+    const int cls = tri_clip_class(clip);
+    if (cls == 2) continue;
+    if (cls == 1) {  // rare: crosses the camera plane or the guard band -- clipped by k_draw_clipped, one thread per triangle
+      const uint32_t slot = atomicAdd(a.clip_count, 1u);
+      if (slot < a.clip_capacity) a.clip_list[slot] = tri;
+      continue;
     }
-    int64_t r0, r1, r2;  // edge values at the start of the row: stepped exactly (integers) instead of re-multiplied
-    tri_edges(r, r.px0, r.py0, r0, r1, r2);
-    for (int64_t py = r.py0; py <= r.py1; py++) {
-      int64_t e0 = r0, e1 = r1, e2 = r2;
-      for (int64_t px = r.px0; px <= r.px1; px++) {
-        tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
-        e0 += r.dx0;
-        e1 += r.dx1;
-        e2 += r.dx2;
+    TriSetup t;
+    if (tri_finish(a, clip[0], clip[1], clip[2], vis, t)) tri_emit(a, t);
+  }
+}
+
+// Sutherland-Hodgman against the five planes, fan triangulation, then the same setup as an unclipped triangle.  A new vertex on a
+// crossing edge is always interpolated from its inside end I to its outside end O -- t = d(I) / (d(I) - d(O)), v = I + t (O - I), IEEE
+// operations in that order -- so the two triangles that share the edge get the same vertex whatever their winding.
+__global__ __launch_bounds__(64) void k_draw_clipped(DrawArgs a) {
+  set_half_denorm_flush();
+  const uint32_t count = min(*a.clip_count, a.clip_capacity);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    float clip[3][4];
+    uint32_t vis;
+    tri_clip_coords(a, a.clip_list[i], clip, vis);
+    float poly[2][9][4];
+    int n = 3, cur = 0;
+    for (int k = 0; k < 3; k++)
+      for (int c = 0; c < 4; c++) poly[0][k][c] = clip[k][c];
+    for (int pl = 0; pl < 5 && n >= 3; pl++) {
+      int m = 0;
+      for (int k = 0; k < n; k++) {
+        const float* p = poly[cur][k];
+        const float* q = poly[cur][(k + 1) % n];
+        const float dp = clip_distance(p, pl), dq = clip_distance(q, pl);
+        const bool ip = dp >= 0.0f, iq = dq >= 0.0f;
+        if (ip) {
+          for (int c = 0; c < 4; c++) poly[cur ^ 1][m][c] = p[c];
+          m++;
+        }
+        if (ip != iq) {
+          const float* I = ip ? p : q;
+          const float* O = ip ? q : p;
+          const float dI = ip ? dp : dq, dO = ip ? dq : dp;
+          const float t = dI / (dI - dO);
+          for (int c = 0; c < 4; c++) poly[cur ^ 1][m][c] = I[c] + t * (O[c] - I[c]);
+          m++;
+        }
       }
-      r0 += r.dy0;
-      r1 += r.dy1;
-      r2 += r.dy2;
+      n = m;
+      cur ^= 1;
+    }
+    for (int k = 1; k + 1 < n; k++) {
+      TriSetup t;
+      if (tri_finish(a, poly[cur][0], poly[cur][k], poly[cur][k + 1], vis, t)) tri_emit(a, t);
     }
   }
 }
@@ -234,8 +317,9 @@ __global__ __launch_bounds__(256) void k_resolve_visbuffer(const unsigned long l
 void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint32_t* vis_out, uint32_t max_grid, hipStream_t s) {
   const uint64_t n = (uint64_t)a.width * a.height;
   if (clear) (void)hipMemsetAsync(a.visdepth, 0, n * 8u, s);
-  (void)hipMemsetAsync(a.big_count, 0, 4, s);
+  (void)hipMemsetAsync(a.big_count, 0, 256, s);  // big_count and clip_count live in the same 256-byte header
   hipLaunchKernelGGL(k_draw_setup, dim3(max_grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_draw_clipped, dim3(256), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_draw_big, dim3(max_grid), dim3(256), 0, s, a);
   if (depth_out || vis_out)
     hipLaunchKernelGGL(k_resolve_visbuffer, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, max_grid)), dim3(256), 0, s, a.visdepth, n, depth_out, vis_out);

@@ -340,10 +340,11 @@ class RendererInstance:
         return visible[: cmd_host[1]].clone(), cmd_host
 
     def draw_visbuffer(self, context: CullGeometryContext, projection_view, width: int, height: int, visdepth: torch.Tensor, clear: bool,
-                       depth: "ImageAttachment" = None, visbuffer: torch.Tensor = None, stream=None):
+                       depth: "ImageAttachment" = None, visbuffer: torch.Tensor = None, stream=None, draw_cmd: torch.Tensor = None):
         """SURVEY 8(f)-2, DrawGeometry.cpp:104-190: rasterise the triangles the last cull_geometry(context) emitted into
         `visdepth` (int64 [h, w]: depth bits << 32 | vis); optional resolves into `depth` (ImageAttachment, levels = 1) and
-        `visbuffer` (int32 [h, w])."""
+        `visbuffer` (int32 [h, w]).  `draw_cmd` (int32 [5], VkDrawIndexedIndirectCommand) replaces the context's own command:
+        draw a caller-written `reordered_indices_buffer`."""
         assert self.prepared_frame is not None
         f = self.prepared_frame.c()
         d = L.DrawContext()
@@ -353,13 +354,13 @@ class RendererInstance:
         d.width, d.height = width, height
         for i in range(16):
             d.projection_view[i] = float(projection_view[i])
-        d.draw_geometry_cmd_buffer = context._c.draw_geometry_cmd_buffer
+        d.draw_geometry_cmd_buffer = context._c.draw_geometry_cmd_buffer if draw_cmd is None else L.Buffer(C.c_void_p(draw_cmd.data_ptr()), draw_cmd.numel() * 4)
         d.visdepth_buffer = L.Buffer(C.c_void_p(visdepth.data_ptr()), visdepth.numel() * 8)
         if depth is not None:
             d.depth_attachment = depth.c()
         if visbuffer is not None:
             d.visbuffer_attachment = L.Buffer(C.c_void_p(visbuffer.data_ptr()), visbuffer.numel() * 4)
-        self._keep = (visdepth, depth, visbuffer)
+        self._keep = (visdepth, depth, visbuffer, draw_cmd)
         self._check(self._lib.oxc_draw_visbuffer(self._ctx, C.byref(f), C.byref(d), self._stream(stream)))
 
     def debug_project_aabb(self, mvp16, near_clip: float, boxes6: torch.Tensor) -> torch.Tensor:
