@@ -49,6 +49,7 @@ struct oxc_ctx {
     uint64_t* bits = nullptr;
     uint32_t* m_chunk_counts = nullptr;
     uint32_t* m_supers = nullptr;
+    uint32_t* m_tickets = nullptr;
     uint64_t* tri_masks = nullptr;
     uint32_t* t_chunk_counts = nullptr;
     uint32_t* t_supers = nullptr;
@@ -155,6 +156,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_bits = carve((uint64_t)cdiv(N, 64) * 8);
   const uint64_t o_mcc = carve((uint64_t)m_chunks * 4);
   const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4 * kSuperStride);
+  const uint64_t o_mtick = carve((uint64_t)kTicketCounters * 4 * kSuperStride);
   const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
@@ -176,6 +178,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->bits = reinterpret_cast<uint64_t*>(b + o_bits);
   L->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
   L->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
+  L->m_tickets = reinterpret_cast<uint32_t*>(b + o_mtick);
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
   L->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
@@ -438,6 +441,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.meshlets_cmd = meshlets_cmd;
   pa.supers_meshlets = ctx->lane[0].m_supers;
   pa.supers_tris = ctx->lane[0].t_supers;
+  pa.tickets = ctx->lane[0].m_tickets;
   pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
   pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
   pa.mesh_instance_count = M;
@@ -473,6 +477,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ha.bits = ctx->lane[0].bits;
     ha.chunk_counts = ctx->lane[0].m_chunk_counts;
     ha.supers = ctx->lane[0].m_supers;
+    ha.tickets = ctx->lane[0].m_tickets;
     ha.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
     ha.dirty = static_cast<const uint32_t*>(c->vsm_clipmap_dirty_flags_buffer.dptr);
     ha.clipmap_count = views;
@@ -493,7 +498,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     MeshletEmitArgs ea;
     ea.n_host = 0;
     ea.n_cap = N;
-    ea.count_meshlets = kMeshletChunk;  // the HPB test kernel publishes one count per 1024-meshlet block
+    ea.count_meshlets = 64u * kGroupsPerWave;  // one count per wave step
     ea.bits = ctx->lane[0].bits;
     ea.chunk_counts = ctx->lane[0].m_chunk_counts;
     ea.supers = ctx->lane[0].m_supers;
@@ -516,6 +521,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ta.chunk_counts = ctx->lane[0].m_chunk_counts;
     ta.supers = ctx->lane[0].m_supers;
     if (c->use_hiz) {
+      ta.tickets = ctx->lane[0].m_tickets;  // the HiZ variants take their work dynamically (step cost varies 10x)
       const oxc_image& h = c->hiz_attachment;
       ta.hiz_data = static_cast<const float*>(h.dptr);
       ta.hiz_w = h.width;

@@ -98,6 +98,7 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
   if (main_view) {
     for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i * kSuperStride] = 0;
     for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i * kSuperStride] = 0;
+    if (a.tickets && tid < kTicketCounters) a.tickets[tid * kSuperStride] = 0;
   }
   const bool do_cull_meshes = main_view && a.do_cull_meshes;
 
@@ -587,13 +588,32 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   const uint32_t last_index = N ? N - 1u : 0u;
   const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
 
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t group0 = chunk * 16 + wave * G;
+  // Work distribution.  A wave step (64 * G meshlets) costs anything between a few hundred cycles (early pass, nothing of it was visible
+  // last frame) and several thousand (a visible instance: cone + occlusion), so a fixed stride leaves the CUs half empty while
+  // the unlucky waves finish (average occupancy 69 % of the resident waves, SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES).  With
+  // a.tickets the waves draw their steps from kTicketCounters counters instead -- counter x = blockIdx % K hands out
+  // the steps congruent to x mod K (K = min(kTicketCounters, grid)); the next ticket is requested while the current step is worked on.  Results are
+  // stored by step index, so the output is the same whatever wave does the step.  Same-address atomics retire at ~13 ns each on
+  // this part (one counter: 520 us per launch), hence many counters: 8 -> 116 us, 32 -> 82, 256 -> 79 (fixed stride: 87), 512 -> 83;
+  // two steps per ticket or drawing the ticket later in the step are worse (config 3, early pass; the late pass 113 -> 101 us).
+  const uint32_t nsteps = nchunks * kWaves;
+  const uint32_t K = min(kTicketCounters, gridDim.x), kx = blockIdx.x % K;  // every counter in use has at least one block drawing from it
+  uint32_t* const ticket = a.tickets ? a.tickets + kx * kSuperStride : nullptr;
+  auto draw_ticket = [&]() -> uint32_t {
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  uint32_t step = blockIdx.x * kWaves + wave;
+  if (ticket) step = readlane_u(draw_ticket(), 0) * K + kx;
+  while (step < nsteps) {
+    const uint32_t group0 = step * G;
     uint2 rec[G];
     uint32_t st[G];        // bit 0: still to be decided, bit 1: visible, bit 2: was_visible
     uint32_t mask_idx[G];  // bit index into the persistent visibility mask
 #pragma unroll
     for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
+    const uint32_t next_ticket = ticket ? draw_ticket() : 0u;  // in flight behind the record loads; read at the end of the step
 #pragma unroll
     for (int j = 0; j < G; j++) {
       st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
@@ -769,10 +789,10 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
     if (lane == 0 && group0 < nwords) {
-      const uint32_t wchunk = chunk * kWaves + wave;
-      gptr(a.chunk_counts)[wchunk] = cnt;
-      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gptr(a.chunk_counts)[step] = cnt;
+      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (step / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    step = ticket ? readlane_u(next_ticket, 0) * K + kx : step + gridDim.x * kWaves;
   }
 }
 
@@ -788,10 +808,15 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   // clipmap view at a time, so every (group, view) paid the scalar-load round trips of the view's plane / matrix row on its own --
   // 0.89 ms per 10 M meshlets, latency-bound.  Here a wave holds G groups (all loads batched, as in the plain kernel) and a view's
   // row is fetched once per instance round for all of them.
+  // The page test of a view (project_aabb: 8 corners, 24 divisions, then the pyramid fetch) runs on the lanes that passed the view's
+  // frustum -- a minority of most groups -- so those lanes are first compacted across the wave's G groups through an LDS strip, as
+  // the HiZ kernel does for its occlusion phase, and waves draw their steps from the ticket counters (a step costs between one frustum
+  // test and ten projections).
   set_half_denorm_flush();
-  __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_level_off[13];
   constexpr int G = (int)kGroupsPerWave;
+  constexpr uint32_t kWaves = 4;
+  __shared__ uint4 s_strip[kWaves][G * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = min(a.vis[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
@@ -807,12 +832,23 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
   const uint32_t last_index = N ? N - 1u : 0u;
 
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t group0 = chunk * (4 * G) + wave * G;
+  const uint32_t nsteps = nchunks * kWaves;
+  const uint32_t K = min(kTicketCounters, gridDim.x), kx = blockIdx.x % K;
+  uint32_t* const ticket = a.tickets + kx * kSuperStride;
+  auto draw_ticket = [&]() -> uint32_t {
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  uint4* const strip = s_strip[wave];
+  uint32_t step = readlane_u(draw_ticket(), 0) * K + kx;
+  while (step < nsteps) {
+    const uint32_t group0 = step * G;
     uint2 rec[G];
     uint32_t st[G];  // bit 0: still to be decided, bit 1: visible
 #pragma unroll
     for (int j = 0; j < G; j++) rec[j] = load_stream_u2(mlis, min((group0 + j) * 64 + lane, last_index));
+    const uint32_t next_ticket = draw_ticket();
 #pragma unroll
     for (int j = 0; j < G; j++) st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
     for (;;) {
@@ -904,21 +940,38 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
           const oxc_virtual_clipmap* cm = a.clipmaps + v;
           const float z_near = cm->z_near;
           const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
+          uint64_t ib[G];
+          uint32_t base[G + 1], slot[G];
+          base[0] = 0;
 #pragma unroll
           for (int j = 0; j < G; j++) {
-            if (__builtin_amdgcn_ballot_w64(inside[j]) == 0) continue;  // wave-uniform
-            uint4 b = bnd[j];
-            asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-            OXC_HPB_DECODE(b);
-            if (inside[j]) {
-              float sa[6];
-              if (project_aabb(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa))
-                vis[j] = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
-              else
-                vis[j] = true;
-            }
-            __builtin_amdgcn_sched_barrier(0);  // one group's projection at a time (four interleaved ones need 147 VGPRs)
+            ib[j] = __builtin_amdgcn_ballot_w64(inside[j]);
+            base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)ib[j]);
           }
+          const uint32_t total = base[G];
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(ib[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ib[j], 0u));
+            if (inside[j]) strip[slot[j]] = bnd[j];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
+          for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const bool act = t < total;
+            const uint4 b = strip[act ? t : total - 1u];
+            OXC_HPB_DECODE(b);
+            float sa[6];
+            bool pass = true;  // projection crosses the near plane: visible (cull_meshlets_hpb.slang:70-76)
+            if (project_aabb(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa)) pass = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (act) strip[t].x = pass ? 1u : 0u;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            if (inside[j]) vis[j] = strip[slot[j]].x != 0u;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next view
         }
       }
 #pragma unroll
@@ -933,14 +986,11 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
       if (lane == 0) gptr(a.bits)[group0 + j] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
-    __syncthreads();
-    if (lane == 0) s_red[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      a.chunk_counts[chunk] = c;
-      if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && group0 < nwords) {  // one count per wave step (64 * G meshlets), as the other meshlet test kernels publish them
+      gptr(a.chunk_counts)[step] = cnt;
+      if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (step / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    step = readlane_u(next_ticket, 0) * K + kx;
   }
 }
 

@@ -22,6 +22,7 @@ struct PrepareArgs {
   uint32_t* supers_meshlets;
   uint32_t* supers_tris;
   uint32_t n_supers_meshlets, n_supers_tris;
+  uint32_t* tickets;  // kTicketCounters work counters (stride kSuperStride) zeroed here for the test kernels that take work dynamically; may be null
   uint32_t mesh_instance_count;
   uint32_t cull_flags;
   uint32_t do_cull_meshes;
@@ -42,6 +43,7 @@ struct HpbTestArgs {
   uint64_t* bits;
   uint32_t* chunk_counts;
   uint32_t* supers;
+  uint32_t* tickets;  // work counters (zeroed by prepare)
   const oxc_virtual_clipmap* clipmaps;
   const uint32_t* dirty;
   uint32_t clipmap_count;
@@ -64,6 +66,7 @@ struct MeshletTestArgs {
   uint64_t* bits;
   uint32_t* chunk_counts;
   uint32_t* supers;
+  uint32_t* tickets;  // != null: waves take their 64*G-meshlet steps from these counters instead of a fixed stride (zeroed by prepare)
   const float* hiz_data;
   uint32_t hiz_level_off[13];  // float offsets of each mip
   uint32_t hiz_w, hiz_h, hiz_levels;
@@ -199,6 +202,7 @@ inline void prepare_args_of(const BatchCore& c, PrepareArgs& pa) {
   pa.meshlets_cmd = c.meshlets_cmd;
   pa.supers_meshlets = c.m_supers;
   pa.supers_tris = c.t_supers;
+  pa.tickets = nullptr;  // batched elements run the plain meshlet test (fixed stride)
   pa.n_supers_meshlets = c.n_supers_meshlets;
   pa.n_supers_tris = c.n_supers_tris;
   pa.mesh_instance_count = c.mesh_instance_count;

@@ -108,6 +108,7 @@ constexpr uint32_t kTriSpan = 256;           // visible meshlets per block itera
 #endif
 constexpr uint32_t kHizLdsTexels = OXC_HIZ_LDS_TEXELS;      // LDS budget (floats) for the staged top HiZ mips: the 16x16 level and everything above it (round 2: staging the 64x64 level too -- 22 KB per block -- measured 4 % slower: 93 / 121 us against 89 / 116)
 constexpr uint32_t kSuperStride = 64;         // words between super-chunk accumulators: one per 256 B so their atomics do not serialise on a cache line
+constexpr uint32_t kTicketCounters = 256;    // dynamic work counters of the HiZ meshlet test: counter x hands out the wave steps congruent to x mod 256
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
 
 }  // namespace oxc
