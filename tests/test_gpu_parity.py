@@ -61,8 +61,8 @@ def test_cull_meshes_frustum_only_flags(renderer, oracle_lib):
     assert (want["lod_index"] == 0).all()
 
 
-@pytest.mark.parametrize("size,depth_scale", [(64, 2), (256, 2), (1024, 2), (256, 1), (128, 3), (32, 2), (8, 2), (4096, 2)],
-                         ids=["64", "256", "1024", "256-same-size", "128-x3", "32", "8", "4096-max-13-mips"])
+@pytest.mark.parametrize("size,depth_scale", [(64, 2), (256, 2), (1024, 2), (256, 1), (128, 3), (32, 2), (8, 2), (4096, 2), (2048, 1)],
+                         ids=["64", "256", "1024", "256-same-size", "128-x3", "32", "8", "4096-max-13-mips", "2048"])
 def test_generate_hiz(renderer, oracle_lib, size, depth_scale):
     depth = make_depth(size * depth_scale, size * depth_scale, 24, seed=size)
     depth += torch.rand(depth.shape, generator=torch.Generator().manual_seed(size)) * 1e-4  # no flat areas
@@ -79,9 +79,11 @@ def test_generate_hiz(renderer, oracle_lib, size, depth_scale):
         assert np.array_equal(a, b), f"mip {k}: {(a != b).sum()} texels differ"
 
 
-def test_generate_hiz_non_square(renderer, oracle_lib):
-    w, h = 512, 256
-    depth = torch.rand((2 * h, 2 * w), generator=torch.Generator().manual_seed(5))
+@pytest.mark.parametrize("w,h,scale", [(512, 256, 2), (192, 320, 2), (64, 1024, 1), (4160, 2112, 1), (100, 36, 2)],
+                         ids=["512x256", "192x320-odd-upper-mips", "64x1024", "4160x2112-odd-upper-mips", "100x36-generic"])
+def test_generate_hiz_non_square(renderer, oracle_lib, w, h, scale):
+    """The tile path (w, h multiples of 64) hands mip 6 to the single-block tail; upper mips of non-power-of-two sizes clamp at the edge."""
+    depth = torch.rand((scale * h, scale * w), generator=torch.Generator().manual_seed(5))
     from oxylus_amd.synth import hiz_layout
     import oracle
 
