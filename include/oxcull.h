@@ -248,8 +248,8 @@ enum {
   OXC_K_MESHLETS_EMIT_LATE = 9,
   OXC_K_TRIANGLES_TEST_LATE = 10,
   OXC_K_TRIANGLES_EMIT_LATE = 11,
-  OXC_K_MESHLETS_OCCLUSION = 12,      /* occlusion pass over the compacted frustum/cone survivors (use_hiz) */
-  OXC_K_MESHLETS_OCCLUSION_LATE = 13,
+  OXC_K_DRAW_VISBUFFER = 12, /* every launch of one oxc_draw_visbuffer call (clear, setup, clipped, big, resolve) */
+  OXC_K_MESHLET_BOUNDS = 13, /* oxc_build_meshlet_bounds */
   OXC_K_COUNT = 16
 };
 typedef struct oxc_kernel_times {

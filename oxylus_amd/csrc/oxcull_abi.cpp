@@ -61,6 +61,8 @@ struct oxc_ctx {
   float* bounds_scratch = nullptr;
   uint32_t bounds_scratch_cap = 0;
   void* raster_scratch = nullptr;  // oxc_draw_visbuffer: list of large triangles + its counter
+  void* raster_rows = nullptr;     // oxc_draw_visbuffer: one DrawRow per mesh instance
+  uint32_t raster_rows_cap = 0;
   void* comm = nullptr;            // ncclComm_t (oxc_comm_init)
   uint32_t comm_rank = 0, comm_world = 0;
   // counter slots
@@ -326,6 +328,7 @@ void oxc_destroy(oxc_ctx* ctx) {
   if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
   if (ctx->bounds_scratch) (void)hipFree(ctx->bounds_scratch);
   if (ctx->raster_scratch) (void)hipFree(ctx->raster_scratch);
+  if (ctx->raster_rows) (void)hipFree(ctx->raster_rows);
   if (ctx->comm) (void)oxc_comm_destroy(ctx);
   if (ctx->slots) (void)hipFree(ctx->slots);
   if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
@@ -877,11 +880,14 @@ oxc_status oxc_build_meshlet_bounds(oxc_ctx* ctx, const oxc_meshlet_bounds_desc*
   const uint32_t chunk = std::min(kBoundsChunk, ctx->bounds_scratch_cap);
   float* fold = ctx->bounds_scratch + align_up((size_t)ctx->bounds_scratch_cap * 24u, 256) / 4;
   float* normals = fold + 256 * 12;
-  launch_build_meshlet_bounds(static_cast<const float*>(d->positions.dptr), d->vertex_count, d->meshlets.dptr, d->meshlet_count,
-                              static_cast<const uint32_t*>(d->indirect_vertex_indices.dptr), static_cast<const uint8_t*>(d->local_triangle_indices.dptr),
-                              d->meshlet_bounds.dptr, static_cast<float*>(d->mesh_bounds.dptr), d->quantized_positions.dptr, ctx->bounds_scratch, normals,
-                              reinterpret_cast<uint32_t*>(normals + (size_t)chunk * 192), fold, chunk, ctx->num_cus * 8,
-                              static_cast<hipStream_t>(hip_stream));
+  {
+    KernelTimer t(ctx, OXC_K_MESHLET_BOUNDS, static_cast<hipStream_t>(hip_stream));
+    launch_build_meshlet_bounds(static_cast<const float*>(d->positions.dptr), d->vertex_count, d->meshlets.dptr, d->meshlet_count,
+                                static_cast<const uint32_t*>(d->indirect_vertex_indices.dptr), static_cast<const uint8_t*>(d->local_triangle_indices.dptr),
+                                d->meshlet_bounds.dptr, static_cast<float*>(d->mesh_bounds.dptr), d->quantized_positions.dptr, ctx->bounds_scratch, normals,
+                                reinterpret_cast<uint32_t*>(normals + (size_t)chunk * 192), fold, chunk, ctx->num_cus * 8,
+                                static_cast<hipStream_t>(hip_stream));
+  }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }
@@ -1056,12 +1062,25 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   if (!ctx->raster_scratch) {
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
       return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: the first call allocates its scratch; make one un-captured call first");
-    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + 256 + (size_t)kRasterBigCapacity * 4);
+    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + kRasterHeaderBytes + (size_t)kRasterBigCapacity * 4 + (size_t)kRasterBigCapacity * 2 * 8);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster scratch)", e);
+  }
+  if (f->mesh_instance_count > ctx->raster_rows_cap) {
+    if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
+      return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: more mesh instances than any earlier call (scratch would grow); make one un-captured call first");
+    OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight draws may still read the old rows
+    if (ctx->raster_rows) OXC_HIP(ctx, hipFree(ctx->raster_rows));
+    ctx->raster_rows = nullptr;
+    ctx->raster_rows_cap = 0;
+    hipError_t e = hipMalloc(&ctx->raster_rows, (size_t)f->mesh_instance_count * sizeof(DrawRow));
+    if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster rows)", e);
+    ctx->raster_rows_cap = f->mesh_instance_count;
   }
   DrawArgs a;
   std::memset(&a, 0, sizeof a);
   std::memcpy(a.pv, d->projection_view, 64);
+  a.rows = static_cast<DrawRow*>(ctx->raster_rows);
+  a.mesh_instance_count = f->mesh_instance_count;
   a.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
   a.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
   a.mesh_instances = static_cast<const GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
@@ -1072,14 +1091,21 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   a.width = d->width;
   a.height = d->height;
   a.wide = d->wide_triangle_index;
-  a.big_capacity = kRasterBigCapacity;
-  a.big_count = static_cast<uint32_t*>(ctx->raster_scratch);
-  a.big_list = reinterpret_cast<TriSetup*>(static_cast<char*>(ctx->raster_scratch) + 256);
+  char* const rs = static_cast<char*>(ctx->raster_scratch);
+  a.clip_count = reinterpret_cast<uint32_t*>(rs);
+  a.tile_count = reinterpret_cast<uint32_t*>(rs) + 32;
+  a.big_seg_counts = reinterpret_cast<uint32_t*>(rs + 256);
+  a.big_seg_capacity = kRasterBigCapacity / kBigSegs;
+  a.big_list = reinterpret_cast<TriSetup*>(rs + kRasterHeaderBytes);
   a.clip_capacity = kRasterBigCapacity;  // more than 2^20 clipped triangles in one draw: the excess is dropped
-  a.clip_count = static_cast<uint32_t*>(ctx->raster_scratch) + 32;
-  a.clip_list = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->raster_scratch) + 256 + (size_t)kRasterBigCapacity * kTriSetupBytes);
-  launch_draw_visbuffer(a, d->clear != 0, dep.dptr ? reinterpret_cast<float*>(static_cast<char*>(dep.dptr) + dep.level_offset[0]) : nullptr,
-                        static_cast<uint32_t*>(d->visbuffer_attachment.dptr), ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
+  a.clip_list = reinterpret_cast<uint32_t*>(rs + kRasterHeaderBytes + (size_t)kRasterBigCapacity * kTriSetupBytes);
+  a.tile_capacity = kRasterBigCapacity * 2;
+  a.tile_list = reinterpret_cast<uint2*>(rs + kRasterHeaderBytes + (size_t)kRasterBigCapacity * (kTriSetupBytes + 4));
+  {
+    KernelTimer t(ctx, OXC_K_DRAW_VISBUFFER, static_cast<hipStream_t>(hip_stream));
+    launch_draw_visbuffer(a, d->clear != 0, dep.dptr ? reinterpret_cast<float*>(static_cast<char*>(dep.dptr) + dep.level_offset[0]) : nullptr,
+                          static_cast<uint32_t*>(d->visbuffer_attachment.dptr), ctx->num_cus * 8, static_cast<hipStream_t>(hip_stream));
+  }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }

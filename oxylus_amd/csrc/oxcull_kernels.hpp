@@ -311,8 +311,16 @@ struct DebugProjectArgs {
 void launch_debug_project_aabb(const DebugProjectArgs& a, hipStream_t s);
 // oxcull_raster.hip: consumer of the indirect draw
 struct TriSetup;
+// What vs_main needs of a mesh instance, resolved once per draw by k_draw_rows (mesh_instance -> mesh -> lods[lod] is three dependent
+// loads per vertex otherwise): the LOD's arrays and rows 0..2 of the world matrix.
+struct DrawRow {
+  uint64_t meshlets, micro, vidx, positions;
+  float w[12];
+};
 struct DrawArgs {
   float pv[16];
+  DrawRow* rows;
+  uint32_t mesh_instance_count;
   const GpuMesh* meshes;
   const float* transforms;
   const GpuMeshInstance* mesh_instances;
@@ -322,15 +330,22 @@ struct DrawArgs {
   unsigned long long* visdepth;
   uint32_t width, height;
   uint32_t wide;
-  uint32_t big_capacity;
+  // Big triangles (pixel box beyond the small path) are queued in kBigSegs segments of the big list, each with its own counter
+  // (stride kBigSegStride words): a single counter retires ~13 ns per wave-level atomic on this part, which serialised the setup kernel.
+  uint32_t big_seg_capacity;  // triangles per segment
   TriSetup* big_list;
-  uint32_t* big_count;
+  uint32_t* big_seg_counts;
   uint32_t clip_capacity;  // triangles that cross a clip plane: ids queued for k_draw_clipped
   uint32_t* clip_list;
   uint32_t* clip_count;
+  uint32_t tile_capacity;  // 64 x 64 pixel tiles of the big triangles' boxes: {big list index, tile} pairs, one wave each in k_draw_big
+  uint2* tile_list;
+  uint32_t* tile_count;
 };
 void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint32_t* vis_out, uint32_t max_grid, hipStream_t s);
 constexpr uint32_t kTriSetupBytes = 40;
+constexpr uint32_t kBigSegs = 256, kBigSegStride = 16;
+constexpr uint32_t kRasterHeaderBytes = 256 + kBigSegs * kBigSegStride * 4;  // clip / tile counters, then the segment counters
 // oxcull_terrain.hip: terrain patch cull
 struct TerrainArgs {
   float pv[16];

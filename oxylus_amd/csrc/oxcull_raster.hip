@@ -9,8 +9,11 @@
 // edge values, and per pixel the maximum of (depth bits << 32 | vis) through a 64-bit atomic max -- the "R64
 // visbuffer" the reference's own note wishes for (visbuffer.slang:43-45), order-independent by construction.
 //
-// One lane per triangle fetches and sets up; triangles covering at most kSmallSpan x kSmallSpan pixels (almost all
-// meshlet triangles) are rasterised by that lane, larger ones go to a list that one block per triangle walks.
+// One lane per triangle fetches and sets up.  Triangles whose pixel box is at most kSmallSpan x kSmallSpan (almost all meshlet
+// triangles) are rasterised by their wave: the 64 boxes of a wave step are laid end to end (prefix sum of the box sizes) and every
+// lane takes one box pixel per iteration, finding its triangle by a binary search over the 64 offsets in LDS -- a lane walking its
+// own box made the whole wave wait for the largest box of the 64 (round 1: 0.90 ms for 14.6 M triangles).  Larger
+// triangles go to a list that one block per triangle walks.
 #include <hip/hip_runtime.h>
 
 #include "oxcull_device.hpp"
@@ -22,16 +25,32 @@ namespace oxc {
 
 constexpr int64_t kSmallSpan = 8;
 
+// inclusive prefix sum across the 64 lanes
+OXC_DEV uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
 struct TriSetup {
   int32_t x[3], y[3];  // 24.8 fixed point, oriented with positive area
   float z[3];
   uint32_t vis;
 };
+constexpr int64_t kBigTile = 64;
 
 OXC_DEV int64_t edge_fn(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t px, int64_t py) { return (bx - ax) * (py - ay) - (by - ay) * (px - ax); }
 // top-left rule for positively oriented triangles: an edge owns its pixels when it goes down, or is horizontal going left
 OXC_DEV bool edge_inclusive(int64_t ax, int64_t ay, int64_t bx, int64_t by) {
   const int64_t dx = bx - ax, dy = by - ay;
+  return dy > 0 || (dy == 0 && dx < 0);
+}
+
+OXC_DEV bool edge_inclusive32(int32_t ax, int32_t ay, int32_t bx, int32_t by) {  // coordinates are below 2^29 in magnitude: no wrap
+  const int32_t dx = bx - ax, dy = by - ay;
   return dy > 0 || (dy == 0 && dx < 0);
 }
 
@@ -83,15 +102,49 @@ OXC_DEV void tri_edges(const TriRaster& r, int64_t px, int64_t py, int64_t& e0, 
   e1 = edge_fn(r.X[2], r.Y[2], r.X[0], r.Y[0], cx, cy);
   e2 = edge_fn(r.X[0], r.Y[0], r.X[1], r.Y[1], cx, cy);
 }
-OXC_DEV void tri_fragment(const TriRaster& r, int64_t e0, int64_t e1, int64_t e2, int64_t px, int64_t py, uint32_t W, unsigned long long* visdepth) {
-  if (e0 + r.b0 < 0 || e1 + r.b1 < 0 || e2 + r.b2 < 0) return;
-  const double zd = (((double)e0 * (double)r.z[0] + (double)e1 * (double)r.z[1]) + (double)e2 * (double)r.z[2]) * r.inv_area;
+OXC_DEV void fragment(int64_t e0, int64_t e1, int64_t e2, int64_t b0, int64_t b1, int64_t b2, float z0, float z1, float z2, double inv_area, uint32_t vis,
+                      int64_t px, int64_t py, uint32_t W, unsigned long long* visdepth) {
+  if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) return;
+  const double zd = (((double)e0 * (double)z0 + (double)e1 * (double)z1) + (double)e2 * (double)z2) * inv_area;
   const float zf = (float)zd;
   if (!(zf > 0.0f) || zf > 1.0f) return;
-  const unsigned long long packed = ((unsigned long long)asu(zf) << 32) | r.vis;
+  const unsigned long long packed = ((unsigned long long)asu(zf) << 32) | vis;
   // (reading the stored value first to skip occluded fragments was measured slower: 1.61 -> 2.15 ms per frame)
   atomicMax(&visdepth[(size_t)py * W + (size_t)px], packed);
 }
+// The same edge function in 32-bit arithmetic: exact (no wrap) when every coordinate difference that enters it is below 2^15 in
+// magnitude.  The 64-bit form is five emulated multi-word operations per edge on this hardware; pixels of the small path (corner
+// spread < 2^12) and of most big-list tiles (< 2^15) qualify, and an exact integer is the same integer in either width.
+OXC_DEV int32_t edge_fn32(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t px, int32_t py) { return (bx - ax) * (py - ay) - (by - ay) * (px - ax); }
+OXC_DEV void fragment32(int32_t e0, int32_t e1, int32_t e2, int32_t b0, int32_t b1, int32_t b2, float z0, float z1, float z2, double inv_area, uint32_t vis,
+                        uint32_t px, uint32_t py, uint32_t W, unsigned long long* visdepth) {
+  if (e0 + b0 < 0 || e1 + b1 < 0 || e2 + b2 < 0) return;
+  const double zd = (((double)e0 * (double)z0 + (double)e1 * (double)z1) + (double)e2 * (double)z2) * inv_area;
+  const float zf = (float)zd;
+  if (!(zf > 0.0f) || zf > 1.0f) return;
+  const unsigned long long packed = ((unsigned long long)asu(zf) << 32) | vis;
+  atomicMax(&visdepth[(size_t)py * W + (size_t)px], packed);
+}
+OXC_DEV void tri_fragment(const TriRaster& r, int64_t e0, int64_t e1, int64_t e2, int64_t px, int64_t py, uint32_t W, unsigned long long* visdepth) {
+  fragment(e0, e1, e2, r.b0, r.b1, r.b2, r.z[0], r.z[1], r.z[2], r.inv_area, r.vis, px, py, W, visdepth);
+}
+
+// What a box pixel needs of its triangle, parked in LDS by the lane that set the triangle up (56 bytes)
+struct TriLds {
+  int32_t x[3], y[3];
+  float z[3];
+  uint32_t vis;
+  uint32_t inv_area_lo, inv_area_hi;
+  uint32_t box;   // px0 | py0 << 16
+  uint32_t misc;  // (box width - 1) | edge bias bits << 4 | ceil(256 / box width) << 8
+};
+constexpr bool small_division_exact() {  // k / bw == (k * ceil(256 / bw)) >> 8 for every box pixel index and width the small path sees
+  for (int bw = 1; bw <= (int)kSmallSpan; bw++)
+    for (int k = 0; k < (int)(kSmallSpan * kSmallSpan); k++)
+      if (k / bw != (k * ((256 + bw - 1) / bw)) >> 8) return false;
+  return true;
+}
+static_assert(small_division_exact(), "box pixel index -> (x, y)");
 
 // Clip planes of the stated rules (include/oxcull.h): w >= kClipWMin and the guard band |x|, |y| <= kClipGuard * w, which keeps every
 // screen coordinate inside the +-2^20 px fixed-point range for extents up to 16384.
@@ -107,8 +160,28 @@ OXC_DEV float clip_distance(const float* v, int plane) {
   }
 }
 
-// vs_main (visbuffer_encode.slang:24-49) for the three corners of triangle `tri`: clip coordinates + the encoded vis value.
-OXC_DEV void tri_clip_coords(const DrawArgs& a, uint32_t tri, float (&clip)[3][4], uint32_t& vis_out) {
+__global__ __launch_bounds__(256) void k_draw_rows(DrawArgs a) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.mesh_instance_count; i += gridDim.x * blockDim.x) {
+    const GpuMeshInstance inst = a.mesh_instances[i];
+    const GpuMesh* mesh = a.meshes + inst.mesh_index;
+    const GpuMeshLOD* lod = reinterpret_cast<const GpuMeshLOD*>(mesh->lods) + inst.lod_index;
+    DrawRow r;
+    r.meshlets = lod->meshlets;
+    r.micro = lod->local_triangle_indices;
+    r.vidx = lod->indirect_vertex_indices;
+    r.positions = mesh->vertex_positions;
+    const float* wm = a.transforms + (size_t)inst.transform_index * 16;
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) r.w[rr * 4 + c] = OXC_M(wm, rr, c);
+    a.rows[i] = r;
+  }
+}
+
+// vs_main (visbuffer_encode.slang:24-49) for the three corners of a triangle given its three index-buffer entries: clip coordinates +
+// the encoded vis value.
+OXC_DEV void tri_clip_coords(const DrawArgs& a, const uint32_t (&idx)[3], float (&clip)[3][4], uint32_t& vis_out) {
   const uint32_t corner_bits = a.wide ? 9u : 8u;
   const uint32_t corner_mask = (1u << corner_bits) - 1u;
   // The three indices of a triangle written by cull_triangles name the same meshlet instance, so everything up to
@@ -120,23 +193,21 @@ OXC_DEV void tri_clip_coords(const DrawArgs& a, uint32_t tri, float (&clip)[3][4
   float w[12] = {0};  // rows 0..2 of world
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const uint32_t data = a.indices[tri * 3u + (uint32_t)k];
+    const uint32_t data = idx[k];
     const uint32_t mli_index = data >> corner_bits, corner = data & corner_mask;
     if (mli_index != cur_mli) {
       cur_mli = mli_index;
       const uint2 mli = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli_index];
-      const GpuMeshInstance inst = a.mesh_instances[mli.x];
-      const GpuMesh* mesh = a.meshes + inst.mesh_index;
-      const GpuMeshLOD* lod = reinterpret_cast<const GpuMeshLOD*>(mesh->lods) + inst.lod_index;
-      ml = load_global_u4(lod->meshlets, mli.y);  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
-      micro = lod->local_triangle_indices;
-      vidx = lod->indirect_vertex_indices;
-      positions = mesh->vertex_positions;
-      const float* wm = a.transforms + (size_t)inst.transform_index * 16;
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) w[r * 4 + c] = OXC_M(wm, r, c);
+      const DrawRow* row = a.rows + mli.x;
+      const uint4 p0 = reinterpret_cast<const uint4*>(row)[0], p1 = reinterpret_cast<const uint4*>(row)[1];
+      const float4 w0 = reinterpret_cast<const float4*>(row)[2], w1 = reinterpret_cast<const float4*>(row)[3], w2 = reinterpret_cast<const float4*>(row)[4];
+      micro = (uint64_t)p0.z | ((uint64_t)p0.w << 32);
+      vidx = (uint64_t)p1.x | ((uint64_t)p1.y << 32);
+      positions = (uint64_t)p1.z | ((uint64_t)p1.w << 32);
+      ml = load_global_u4((uint64_t)p0.x | ((uint64_t)p0.y << 32), mli.y);  // {vertex_offset, tri_offset(bytes), vertex_count, tri_count}
+      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w;
+      w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+      w[8] = w2.x, w[9] = w2.y, w[10] = w2.z, w[11] = w2.w;
     }
     const uint32_t boff = ml.y + corner;
     const uint32_t li = (load_global_u32(micro, boff >> 2) >> ((boff & 3u) * 8u)) & 0xFFu;  // scene.slang:336-348
@@ -166,9 +237,11 @@ OXC_DEV int tri_clip_class(const float (&clip)[3][4]) {
 
 // The stated setup rules for one (possibly clipped) triangle given in clip coordinates.  Returns false when it is dropped
 // (back face / zero area; w <= 0 or a coordinate beyond the fixed-point range cannot happen behind the clipper but are kept as guards).
-OXC_DEV bool tri_finish(const DrawArgs& a, const float* c0, const float* c1, const float* c2, uint32_t vis, TriSetup& out) {
+// spread_out: the larger of the corners' x and y extents (24.8 units); below 4096 every edge-function value of the triangle's own
+// pixel box fits 32 bits with room to spare
+OXC_DEV bool tri_finish(const DrawArgs& a, const float* c0, const float* c1, const float* c2, uint32_t vis, TriSetup& out, int32_t* spread_out = nullptr) {
   const float* cl[3] = {c0, c1, c2};
-  int64_t X[3], Y[3];
+  int32_t X[3], Y[3];  // |s| <= 2^20 pixels: the snapped values fit 32 bits (the stated rules are in integers; 64 bits are only needed for products)
   float z[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -178,44 +251,38 @@ OXC_DEV bool tri_finish(const DrawArgs& a, const float* c0, const float* c1, con
     const float sy = ((clip[1] / clip[3]) * 0.5f + 0.5f) * (float)a.height;
     z[k] = clip[2] / clip[3];
     if (!(__builtin_fabsf(sx) <= 1048576.0f) || !(__builtin_fabsf(sy) <= 1048576.0f)) return false;
-    X[k] = (int64_t)__builtin_floorf(sx * 256.0f + 0.5f);
-    Y[k] = (int64_t)__builtin_floorf(sy * 256.0f + 0.5f);
+    X[k] = (int32_t)__builtin_floorf(sx * 256.0f + 0.5f);
+    Y[k] = (int32_t)__builtin_floorf(sy * 256.0f + 0.5f);
   }
   out.vis = vis;
-  const int64_t area = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
-  if (area >= 0) return false;  // cullMode eBack: det(xyw) > 0 <=> positive area; 0 = no coverage
+  const int32_t spread = max(max(max(X[0], X[1]), X[2]) - min(min(X[0], X[1]), X[2]), max(max(Y[0], Y[1]), Y[2]) - min(min(Y[0], Y[1]), Y[2]));
+  if (spread_out) *spread_out = spread;
+  bool back;  // cullMode eBack: det(xyw) > 0 <=> positive area; 0 = no coverage
+  if (spread < 32768)
+    back = edge_fn32(X[0], Y[0], X[1], Y[1], X[2], Y[2]) >= 0;
+  else
+    back = edge_fn(X[0], Y[0], X[1], Y[1], X[2], Y[2]) >= 0;
+  if (back) return false;
   // orient positively: swap corners 1 and 2
-  out.x[0] = (int32_t)X[0];
-  out.y[0] = (int32_t)Y[0];
-  out.x[1] = (int32_t)X[2];
-  out.y[1] = (int32_t)Y[2];
-  out.x[2] = (int32_t)X[1];
-  out.y[2] = (int32_t)Y[1];
+  out.x[0] = X[0];
+  out.y[0] = Y[0];
+  out.x[1] = X[2];
+  out.y[1] = Y[2];
+  out.x[2] = X[1];
+  out.y[2] = Y[1];
   out.z[0] = z[0];
   out.z[1] = z[2];
   out.z[2] = z[1];
   return true;
 }
 
-// rasterise one set-up triangle from this lane (small ones) or queue it for k_draw_big
-OXC_DEV void tri_emit(const DrawArgs& a, const TriSetup& t) {
-  TriRaster r;
-  tri_prepare(t, a.width, a.height, r);
-  if (r.px1 < r.px0 || r.py1 < r.py0) return;
-  bool small = (r.px1 - r.px0) < kSmallSpan && (r.py1 - r.py0) < kSmallSpan;
-  if (!small) {
-    const uint32_t slot = atomicAdd(a.big_count, 1u);
-    if (slot < a.big_capacity) {
-      a.big_list[slot] = t;
-      return;
-    }
-    // the list is full: this lane walks the box itself (slow, correct)
-  }
+// one lane walks a pixel rectangle of its triangle
+OXC_DEV void walk_box(const DrawArgs& a, const TriRaster& r, int64_t x0, int64_t y0, int64_t x1, int64_t y1) {
   int64_t r0, r1, r2;  // edge values at the start of the row: stepped exactly (integers) instead of re-multiplied
-  tri_edges(r, r.px0, r.py0, r0, r1, r2);
-  for (int64_t py = r.py0; py <= r.py1; py++) {
+  tri_edges(r, x0, y0, r0, r1, r2);
+  for (int64_t py = y0; py <= y1; py++) {
     int64_t e0 = r0, e1 = r1, e2 = r2;
-    for (int64_t px = r.px0; px <= r.px1; px++) {
+    for (int64_t px = x0; px <= x1; px++) {
       tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
       e0 += r.dx0;
       e1 += r.dx1;
@@ -227,22 +294,132 @@ OXC_DEV void tri_emit(const DrawArgs& a, const TriSetup& t) {
   }
 }
 
+// A triangle whose pixel box exceeds kSmallSpan goes to segment `seg` of the big list (k_draw_big: one wave per triangle).  A triangle
+// that does not fit its segment any more is walked by this lane (slow, correct).
+OXC_DEV void push_big(const DrawArgs& a, const TriSetup& t, uint32_t seg) {
+  const uint32_t slot = atomicAdd(a.big_seg_counts + seg * kBigSegStride, 1u);
+  if (slot < a.big_seg_capacity) {
+    a.big_list[(size_t)seg * a.big_seg_capacity + slot] = t;
+    return;
+  }
+  TriRaster r;
+  tri_prepare(t, a.width, a.height, r);
+  for (int64_t py = r.py0; py <= r.py1; py++)
+    for (int64_t px = r.px0; px <= r.px1; px++) {
+      int64_t e0, e1, e2;
+      tri_edges(r, px, py, e0, e1, e2);
+      tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
+    }
+}
+
+// rasterise one set-up triangle from this lane (small ones) or queue it for k_draw_big
+OXC_DEV void tri_emit(const DrawArgs& a, const TriSetup& t, uint32_t seg) {
+  TriRaster r;
+  tri_prepare(t, a.width, a.height, r);
+  if (r.px1 < r.px0 || r.py1 < r.py0) return;
+  const bool small = (r.px1 - r.px0) < kSmallSpan && (r.py1 - r.py0) < kSmallSpan;
+  if (!small) {
+    push_big(a, t, seg);
+    return;
+  }
+  walk_box(a, r, r.px0, r.py0, r.px1, r.py1);
+}
+
 __global__ __launch_bounds__(256) void k_draw_setup(DrawArgs a) {
   set_half_denorm_flush();
+  __shared__ TriLds s_tri[4][64];
+  __shared__ uint32_t s_off[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TriLds* const tl = s_tri[wave];
+  uint32_t* const off = s_off[wave];
   const uint32_t tris = a.draw_cmd[0] / 3u;  // VkDrawIndexedIndirectCommand.indexCount
-  for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < tris; tri += gridDim.x * blockDim.x) {
-    float clip[3][4];
-    uint32_t vis;
-    tri_clip_coords(a, tri, clip, vis);
-    const int cls = tri_clip_class(clip);
-    if (cls == 2) continue;
-    if (cls == 1) {  // rare: crosses the camera plane or the guard band -- clipped by k_draw_clipped, one thread per triangle
-      const uint32_t slot = atomicAdd(a.clip_count, 1u);
-      if (slot < a.clip_capacity) a.clip_list[slot] = tri;
-      continue;
+  const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)wave, nwaves = gridDim.x * 4u;
+  uint32_t nidx[3] = {0, 0, 0};  // the next step's index-buffer entries, fetched a step ahead
+  if (wave_id * 64u + (uint32_t)lane < tris) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) nidx[k] = a.indices[(wave_id * 64u + (uint32_t)lane) * 3u + (uint32_t)k];
+  }
+  for (uint32_t base = wave_id * 64u; base < tris; base += nwaves * 64u) {  // wave-uniform
+    const uint32_t tri = base + (uint32_t)lane;
+    const uint32_t idx[3] = {nidx[0], nidx[1], nidx[2]};
+    {
+      const uint32_t nt = tri + nwaves * 64u;
+      if (nt < tris) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) nidx[k] = a.indices[nt * 3u + (uint32_t)k];
+      }
     }
-    TriSetup t;
-    if (tri_finish(a, clip[0], clip[1], clip[2], vis, t)) tri_emit(a, t);
+    uint32_t count = 0;  // box pixels this lane's triangle contributes to the wave's small-triangle pass
+    if (tri < tris) {
+      float clip[3][4];
+      uint32_t vis;
+      tri_clip_coords(a, idx, clip, vis);
+      const int cls = tri_clip_class(clip);
+      TriSetup t;
+      if (cls == 1) {  // rare: crosses the camera plane or the guard band -- clipped by k_draw_clipped, one thread per triangle
+        const uint32_t slot = atomicAdd(a.clip_count, 1u);
+        if (slot < a.clip_capacity) a.clip_list[slot] = tri;
+      } else if (int32_t spread = 0; cls == 0 && tri_finish(a, clip[0], clip[1], clip[2], vis, t, &spread)) {
+        // pixel box (tri_prepare's, in 32 bits): pixel (px, py) has its centre at (256 px + 128, 256 py + 128)
+        const int32_t minx = min(min(t.x[0], t.x[1]), t.x[2]), maxx = max(max(t.x[0], t.x[1]), t.x[2]);
+        const int32_t miny = min(min(t.y[0], t.y[1]), t.y[2]), maxy = max(max(t.y[0], t.y[1]), t.y[2]);
+        const int32_t px0 = max((minx - 128 + 255) >> 8, 0), py0 = max((miny - 128 + 255) >> 8, 0);
+        const int32_t px1 = min((maxx - 128) >> 8, (int32_t)a.width - 1), py1 = min((maxy - 128) >> 8, (int32_t)a.height - 1);
+        if (px1 >= px0 && py1 >= py0) {
+          const int32_t bw = px1 - px0 + 1, bh = py1 - py0 + 1;
+          // (the spread test only fails for triangles reaching far outside the image whose clamped box is small: they take the big path)
+          if (bw <= (int32_t)kSmallSpan && bh <= (int32_t)kSmallSpan && spread < 4096) {
+            count = (uint32_t)(bw * bh);
+            TriLds o;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              o.x[k] = t.x[k];
+              o.y[k] = t.y[k];
+              o.z[k] = t.z[k];
+            }
+            o.vis = t.vis;
+            const int32_t area = edge_fn32(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);  // > 0 (oriented), < 2^25
+            const unsigned long long ia = __builtin_bit_cast(unsigned long long, 1.0 / (double)area);  // one reciprocal per triangle (tri_prepare)
+            o.inv_area_lo = (uint32_t)ia;
+            o.inv_area_hi = (uint32_t)(ia >> 32);
+            o.box = (uint32_t)px0 | ((uint32_t)py0 << 16);
+            const uint32_t bias = (edge_inclusive32(t.x[1], t.y[1], t.x[2], t.y[2]) ? 0u : 1u) | (edge_inclusive32(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0u : 2u) |
+                                  (edge_inclusive32(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0u : 4u);
+            o.misc = (uint32_t)(bw - 1) | (bias << 4) | (((256u + (uint32_t)bw - 1u) / (uint32_t)bw) << 8);
+            tl[lane] = o;
+          } else {
+            push_big(a, t, wave_id % kBigSegs);
+          }
+        }
+      }
+    }
+    // ---- the wave's small triangles, one box pixel per lane and iteration
+    const uint32_t incl = wave_incl_scan(count, lane);
+    const uint32_t total = readlane_u(incl, 63);
+    off[lane] = incl - count;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
+    for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
+      const uint32_t g = g0 + (uint32_t)lane;
+      if (g < total) {
+        uint32_t j = 0;  // the last triangle whose first box pixel is at or before g (empty boxes share their successor's offset)
+#pragma unroll
+        for (uint32_t stp = 32u; stp >= 1u; stp >>= 1)
+          if (off[j + stp] <= g) j += stp;
+        const uint32_t k = g - off[j];
+        const TriLds q = tl[j];
+        const uint32_t bw = (q.misc & 7u) + 1u, m = q.misc >> 8;
+        const uint32_t qy = (k * m) >> 8, qx = k - qy * bw;
+        const uint32_t px = (q.box & 0xFFFFu) + qx, py = (q.box >> 16) + qy;
+        const int32_t cx = (int32_t)px * 256 + 128, cy = (int32_t)py * 256 + 128;
+        const int32_t e0 = edge_fn32(q.x[1], q.y[1], q.x[2], q.y[2], cx, cy);  // corner spread < 2^12, centre inside the box: |e| < 2^25
+        const int32_t e1 = edge_fn32(q.x[2], q.y[2], q.x[0], q.y[0], cx, cy);
+        const int32_t e2 = edge_fn32(q.x[0], q.y[0], q.x[1], q.y[1], cx, cy);
+        const double inv_area = __builtin_bit_cast(double, (unsigned long long)q.inv_area_lo | ((unsigned long long)q.inv_area_hi << 32));
+        fragment32(e0, e1, e2, (q.misc & 0x10u) ? -1 : 0, (q.misc & 0x20u) ? -1 : 0, (q.misc & 0x40u) ? -1 : 0, q.z[0], q.z[1], q.z[2], inv_area, q.vis, px, py,
+                   a.width, a.visdepth);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS rows are rewritten by the next step
   }
 }
 
@@ -255,7 +432,9 @@ __global__ __launch_bounds__(64) void k_draw_clipped(DrawArgs a) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     float clip[3][4];
     uint32_t vis;
-    tri_clip_coords(a, a.clip_list[i], clip, vis);
+    const uint32_t tri = a.clip_list[i];
+    const uint32_t idx[3] = {a.indices[tri * 3u], a.indices[tri * 3u + 1u], a.indices[tri * 3u + 2u]};
+    tri_clip_coords(a, idx, clip, vis);
     float poly[2][9][4];
     int n = 3, cur = 0;
     for (int k = 0; k < 3; k++)
@@ -285,23 +464,110 @@ __global__ __launch_bounds__(64) void k_draw_clipped(DrawArgs a) {
     }
     for (int k = 1; k + 1 < n; k++) {
       TriSetup t;
-      if (tri_finish(a, poly[cur][0], poly[cur][k], poly[cur][k + 1], vis, t)) tri_emit(a, t);
+      if (tri_finish(a, poly[cur][0], poly[cur][k], poly[cur][k + 1], vis, t)) tri_emit(a, t, blockIdx.x % kBigSegs);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_draw_big(DrawArgs a) {
-  const uint32_t count = min(*a.big_count, a.big_capacity);
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    TriRaster r;
-    tri_prepare(a.big_list[i], a.width, a.height, r);
-    const int64_t bw = r.px1 - r.px0 + 1, bh = r.py1 - r.py0 + 1;
-    for (int64_t k = threadIdx.x; k < bw * bh; k += blockDim.x) {
-      const int64_t px = r.px0 + k % bw, py = r.py0 + k / bw;
-      int64_t e0, e1, e2;
-      tri_edges(r, px, py, e0, e1, e2);
-      tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
+// A pixel rectangle of a big triangle's box, walked by a wave in 8 x 8 pixel blocks (lane = pixel of the block), 64-bit edge functions.
+OXC_DEV void raster_rect64(const DrawArgs& a, const TriRaster& r, int64_t ox, int64_t oy, int64_t x1, int64_t y1, int lane) {
+  for (int64_t by = oy; by <= y1; by += 8)
+    for (int64_t bx = ox; bx <= x1; bx += 8) {
+      const int64_t px = bx + (lane & 7), py = by + (lane >> 3);
+      if (px <= x1 && py <= y1) {
+        int64_t e0, e1, e2;
+        tri_edges(r, px, py, e0, e1, e2);
+        tri_fragment(r, e0, e1, e2, px, py, a.width, a.visdepth);
+      }
     }
+}
+// The same with 32-bit edge functions when they are exact for this rectangle (wave-uniform test).
+OXC_DEV void raster_rect(const DrawArgs& a, const TriRaster& r, int64_t ox, int64_t oy, int64_t x1, int64_t y1, int lane) {
+  // every difference the edge functions of this rectangle see: corner - corner, pixel centre - corner
+  const int64_t cx0 = ox * 256 + 128, cx1 = x1 * 256 + 128, cy0 = oy * 256 + 128, cy1 = y1 * 256 + 128;
+  const int64_t lox = min(min(min(r.X[0], r.X[1]), r.X[2]), cx0), hix = max(max(max(r.X[0], r.X[1]), r.X[2]), cx1);
+  const int64_t loy = min(min(min(r.Y[0], r.Y[1]), r.Y[2]), cy0), hiy = max(max(max(r.Y[0], r.Y[1]), r.Y[2]), cy1);
+  if (hix - lox < 32768 && hiy - loy < 32768) {
+    const int32_t X0 = (int32_t)r.X[0], X1 = (int32_t)r.X[1], X2 = (int32_t)r.X[2], Y0 = (int32_t)r.Y[0], Y1 = (int32_t)r.Y[1], Y2 = (int32_t)r.Y[2];
+    for (int32_t by = (int32_t)oy; by <= (int32_t)y1; by += 8)
+      for (int32_t bx = (int32_t)ox; bx <= (int32_t)x1; bx += 8) {
+        const int32_t px = bx + (lane & 7), py = by + (lane >> 3);
+        if (px <= (int32_t)x1 && py <= (int32_t)y1) {
+          const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+          fragment32(edge_fn32(X1, Y1, X2, Y2, cx, cy), edge_fn32(X2, Y2, X0, Y0, cx, cy), edge_fn32(X0, Y0, X1, Y1, cx, cy), (int32_t)r.b0, (int32_t)r.b1,
+                     (int32_t)r.b2, r.z[0], r.z[1], r.z[2], r.inv_area, r.vis, (uint32_t)px, (uint32_t)py, a.width, a.visdepth);
+        }
+      }
+  } else {
+    raster_rect64(a, r, ox, oy, x1, y1, lane);
+  }
+}
+
+// One wave per big triangle.  Round 1 gave every big triangle a 256-thread block: 0.43 ms for the 330 K triangles of the loop
+// benchmark whose boxes are barely larger than 8 x 8, and a full-screen triangle was a single block's 16 K iterations.  Here a box of
+// at most 64 x 64 pixels (nearly all) is walked at once; a larger one is cut into 64 x 64 tiles that go to the tile list
+// (k_draw_big_tiles: one wave per tile), so a screen-filling triangle becomes a thousand balanced items.
+__global__ __launch_bounds__(256) void k_draw_big(DrawArgs a) {
+  __shared__ uint32_t s_prefix[kBigSegs + 1];
+  __shared__ uint32_t s_wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {  // the segments' fill counts -> exclusive prefix (every block computes the same 256-entry scan)
+    static_assert(kBigSegs == 256, "one count per thread");
+    const uint32_t c = min(a.big_seg_counts[threadIdx.x * kBigSegStride], a.big_seg_capacity);
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wsum[w];
+    s_prefix[threadIdx.x + 1] = base + incl;
+    if (threadIdx.x == 0) s_prefix[0] = 0;
+    __syncthreads();
+  }
+  const uint32_t total = s_prefix[kBigSegs];
+  const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)wave, nwaves = gridDim.x * 4u;
+  for (uint32_t i = wave_id; i < total; i += nwaves) {  // wave-uniform
+    uint32_t seg = 0;  // the segment task i falls into: the last one whose prefix is <= i
+#pragma unroll
+    for (uint32_t stp = kBigSegs / 2; stp >= 1u; stp >>= 1)
+      if (s_prefix[seg + stp] <= i) seg += stp;
+    const uint32_t slot = seg * a.big_seg_capacity + (i - s_prefix[seg]);
+    TriRaster r;
+    tri_prepare(a.big_list[slot], a.width, a.height, r);
+    const uint32_t ntx = (uint32_t)((r.px1 - r.px0 + kBigTile) / kBigTile), nty = (uint32_t)((r.py1 - r.py0 + kBigTile) / kBigTile);
+    const uint32_t n = ntx * nty;
+    if (n == 1u) {
+      raster_rect(a, r, r.px0, r.py0, r.px1, r.py1, lane);
+      continue;
+    }
+    uint32_t first = 0;
+    if (lane == 0) first = atomicAdd(a.tile_count, n);
+    first = readlane_u(first, 0);
+    for (uint32_t k = (uint32_t)lane; k < n; k += 64u) {
+      if (first + k < a.tile_capacity && first + k >= first) a.tile_list[first + k] = make_uint2(slot, k);
+    }
+    if (first + n > a.tile_capacity || first + n < first) {  // the tile list is full: the tiles that did not fit are walked here (slow, correct)
+#pragma clang loop unroll(disable)
+      for (uint32_t k = 0; k < n; k++) {
+        if (first + k < a.tile_capacity && first + k >= first) continue;
+        const int64_t ox = r.px0 + (int64_t)(k % ntx) * kBigTile, oy = r.py0 + (int64_t)(k / ntx) * kBigTile;
+        raster_rect64(a, r, ox, oy, min(ox + kBigTile - 1, r.px1), min(oy + kBigTile - 1, r.py1), lane);
+      }
+    }
+  }
+}
+
+// One wave per tile-list item: a 64 x 64 pixel tile of a triangle whose box is larger than that.
+__global__ __launch_bounds__(256) void k_draw_big_tiles(DrawArgs a) {
+  const uint32_t count = min(*a.tile_count, a.tile_capacity);
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+  for (uint32_t i = wave_id; i < count; i += nwaves) {
+    const uint2 item = a.tile_list[i];
+    TriRaster r;
+    tri_prepare(a.big_list[item.x], a.width, a.height, r);
+    const uint32_t ntx = (uint32_t)((r.px1 - r.px0 + kBigTile) / kBigTile);
+    const int64_t ox = r.px0 + (int64_t)(item.y % ntx) * kBigTile, oy = r.py0 + (int64_t)(item.y / ntx) * kBigTile;
+    raster_rect(a, r, ox, oy, min(ox + kBigTile - 1, r.px1), min(oy + kBigTile - 1, r.py1), lane);
   }
 }
 
@@ -317,10 +583,12 @@ __global__ __launch_bounds__(256) void k_resolve_visbuffer(const unsigned long l
 void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint32_t* vis_out, uint32_t max_grid, hipStream_t s) {
   const uint64_t n = (uint64_t)a.width * a.height;
   if (clear) (void)hipMemsetAsync(a.visdepth, 0, n * 8u, s);
-  (void)hipMemsetAsync(a.big_count, 0, 256, s);  // big_count and clip_count live in the same 256-byte header
+  (void)hipMemsetAsync(a.clip_count, 0, kRasterHeaderBytes, s);  // clip / tile counters and the big list's segment counters
+  hipLaunchKernelGGL(k_draw_rows, dim3(std::max(1u, std::min((a.mesh_instance_count + 255u) / 256u, max_grid))), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_draw_setup, dim3(max_grid), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_draw_clipped, dim3(256), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_draw_big, dim3(max_grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_draw_big_tiles, dim3(max_grid), dim3(256), 0, s, a);
   if (depth_out || vis_out)
     hipLaunchKernelGGL(k_resolve_visbuffer, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, max_grid)), dim3(256), 0, s, a.visdepth, n, depth_out, vis_out);
 }

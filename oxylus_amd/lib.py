@@ -281,7 +281,7 @@ _libs = {}
 def load(path: str = None) -> C.CDLL:
     """liboxcull.so with prototypes.  `path`: another build of the same library (tools/kbench.py compares kernel
     variants built with different -D flags in one process)."""
-    path = os.path.abspath(path or LIB_PATH)
+    path = os.path.abspath(path or os.environ.get("OXC_LIB_PATH") or LIB_PATH)  # OXC_LIB_PATH: an experiment build (tools/build_variants.sh)
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -357,7 +357,7 @@ class KernelTimes(C.Structure):
 # OXC_K_* (include/oxcull.h); the *_late entries are the LatePass instantiations, timed apart
 KERNEL_NAMES = ["prepare_instances", "cull_meshes_scan", "cull_meshes_expand", "cull_meshlets_test", "cull_meshlets_emit",
                 "cull_triangles_test", "cull_triangles_emit", "hiz", "cull_meshlets_test_late", "cull_meshlets_emit_late",
-                "cull_triangles_test_late", "cull_triangles_emit_late", "cull_meshlets_occlusion", "cull_meshlets_occlusion_late",
+                "cull_triangles_test_late", "cull_triangles_emit_late", "draw_visbuffer", "build_meshlet_bounds",
                 "_14", "_15"]
 
 

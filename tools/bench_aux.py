@@ -162,6 +162,12 @@ def bench_loop(args, r, dev, stream, rank, world, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     covered = float((visdepth != 0).float().mean().item())
+    r.profile_begin()
+    with torch.cuda.stream(stream):
+        for _ in range(10):
+            one_frame()
+    prof = r.profile_end()
+    per_frame_us = {k: round(v["total_ms"] / 10 * 1e3, 1) for k, v in prof["kernels"].items() if not k.startswith("_")}
     if rank == 0:
         print(json.dumps({
             "metric": "meshlets/s through the closed two-pass frame (cull + draw + HiZ)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
@@ -169,7 +175,7 @@ def bench_loop(args, r, dev, stream, rank, world, dist):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SURVEY 8f-2 loop: early cull -> draw -> depth -> HiZ -> late cull -> draw, static scene, steady state",
                        "meshlets_per_gpu": n_meshlets, "target": [W, H], "hiz": [W // 2, H // 2], "tris_per_meshlet": 64,
-                       "steady_state_counts": counts, "covered_pixel_fraction": round(covered, 4)},
+                       "steady_state_counts": counts, "covered_pixel_fraction": round(covered, 4), "per_frame_us": per_frame_us},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()
