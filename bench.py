@@ -481,8 +481,6 @@ def bench_config3(args, e):
         per_frame = k["launches"] / n_prof
         ent = {"launches_per_frame": round(per_frame, 3), "launches_timed": k["launches"], "avg_us": round(k["avg_us"], 3)}
         b = alg.get(name)
-        if b is None and name == "cull_meshlets_occlusion":
-            b = 0.0
         if b is not None:
             ent["algorithmic_bytes_per_launch"] = round(b)
             ent["achieved_GBps"] = round(b / (k["avg_us"] * 1e-6) / 1e9, 1)
