@@ -497,6 +497,11 @@ oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float n
 /* Harness helper: copy n u32 from device memory (e.g. a callee-owned indirect command) to the host; synchronises the stream. */
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream);
 
+/* Test hook: what the last oxc_draw_visbuffer on this context did with its triangles; synchronises the stream.
+ * out4 = {triangles queued for the big path (pixel box beyond 8 x 8), triangles that crossed a clip plane, 64 x 64 tiles handed to
+ * the tile list, big-list segments that overflowed (their excess triangles were walked by the setup lane: slow, correct)}. */
+oxc_status oxc_debug_raster_stats(oxc_ctx* ctx, uint32_t* host_out4, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

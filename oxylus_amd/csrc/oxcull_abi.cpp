@@ -61,6 +61,7 @@ struct oxc_ctx {
   float* bounds_scratch = nullptr;
   uint32_t bounds_scratch_cap = 0;
   void* raster_scratch = nullptr;  // oxc_draw_visbuffer: list of large triangles + its counter
+  uint32_t raster_capacity = 0;    // entries of the big / clip lists (the tile list has twice as many)
   void* raster_rows = nullptr;     // oxc_draw_visbuffer: one DrawRow per mesh instance
   uint32_t raster_rows_cap = 0;
   void* comm = nullptr;            // ncclComm_t (oxc_comm_init)
@@ -1042,7 +1043,10 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   return OXC_OK;
 }
 
-constexpr uint32_t kRasterBigCapacity = 1u << 20;  // large triangles queued per draw; beyond that the setup lane rasterises itself
+// Big triangles (and clipped triangle ids) queued per draw; beyond that the producing lane rasterises the triangle itself (slow,
+// correct) and clipped triangles are dropped.  240 MB of scratch, allocated by the first draw.  OXC_RASTER_BIG_CAPACITY (read by
+// that first draw) shrinks it so that the tests can reach the overflow paths with a small scene.
+constexpr uint32_t kRasterBigCapacity = 1u << 22;
 
 oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const oxc_draw_context* d, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
@@ -1062,8 +1066,14 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   if (!ctx->raster_scratch) {
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
       return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: the first call allocates its scratch; make one un-captured call first");
-    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)kRasterBigCapacity * kTriSetupBytes + kRasterHeaderBytes + (size_t)kRasterBigCapacity * 4 + (size_t)kRasterBigCapacity * 2 * 8);
+    uint32_t cap = kRasterBigCapacity;
+    if (const char* env = std::getenv("OXC_RASTER_BIG_CAPACITY")) {
+      const long v = std::atol(env);
+      if (v > 0) cap = (uint32_t)std::min<long>(std::max<long>(v, kBigSegs * 16), 1L << 24) / kBigSegs * kBigSegs;
+    }
+    hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)cap * kTriSetupBytes + kRasterHeaderBytes + (size_t)cap * 4 + (size_t)cap * 2 * 8);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster scratch)", e);
+    ctx->raster_capacity = cap;
   }
   if (f->mesh_instance_count > ctx->raster_rows_cap) {
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
@@ -1095,12 +1105,13 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   a.clip_count = reinterpret_cast<uint32_t*>(rs);
   a.tile_count = reinterpret_cast<uint32_t*>(rs) + 32;
   a.big_seg_counts = reinterpret_cast<uint32_t*>(rs + 256);
-  a.big_seg_capacity = kRasterBigCapacity / kBigSegs;
+  const uint32_t cap = ctx->raster_capacity;
+  a.big_seg_capacity = cap / kBigSegs;
   a.big_list = reinterpret_cast<TriSetup*>(rs + kRasterHeaderBytes);
-  a.clip_capacity = kRasterBigCapacity;  // more than 2^20 clipped triangles in one draw: the excess is dropped
-  a.clip_list = reinterpret_cast<uint32_t*>(rs + kRasterHeaderBytes + (size_t)kRasterBigCapacity * kTriSetupBytes);
-  a.tile_capacity = kRasterBigCapacity * 2;
-  a.tile_list = reinterpret_cast<uint2*>(rs + kRasterHeaderBytes + (size_t)kRasterBigCapacity * (kTriSetupBytes + 4));
+  a.clip_capacity = cap;  // more clipped triangles than that in one draw: the excess is dropped
+  a.clip_list = reinterpret_cast<uint32_t*>(rs + kRasterHeaderBytes + (size_t)cap * kTriSetupBytes);
+  a.tile_capacity = cap * 2;
+  a.tile_list = reinterpret_cast<uint2*>(rs + kRasterHeaderBytes + (size_t)cap * (kTriSetupBytes + 4));
   {
     KernelTimer t(ctx, OXC_K_DRAW_VISBUFFER, static_cast<hipStream_t>(hip_stream));
     launch_draw_visbuffer(a, d->clear != 0, dep.dptr ? reinterpret_cast<float*>(static_cast<char*>(dep.dptr) + dep.level_offset[0]) : nullptr,
@@ -1258,6 +1269,31 @@ oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   OXC_HIP(ctx, hipMemcpyAsync(host_out, dptr, (size_t)n * 4u, hipMemcpyDeviceToHost, s));
   OXC_HIP(ctx, hipStreamSynchronize(s));
+  return OXC_OK;
+}
+
+oxc_status oxc_debug_raster_stats(oxc_ctx* ctx, uint32_t* host_out4, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!host_out4) return fail(ctx, OXC_INVALID_ARG, "debug_raster_stats: null pointer");
+  if (!ctx->raster_scratch) return fail(ctx, OXC_INVALID_ARG, "debug_raster_stats: no oxc_draw_visbuffer call on this context yet");
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  std::vector<uint32_t> h(kRasterHeaderBytes / 4);
+  OXC_HIP(ctx, hipMemcpyAsync(h.data(), ctx->raster_scratch, kRasterHeaderBytes, hipMemcpyDeviceToHost, s));
+  OXC_HIP(ctx, hipStreamSynchronize(s));
+  const uint32_t seg_cap = ctx->raster_capacity / kBigSegs;
+  uint64_t big = 0;
+  uint32_t overflowed = 0;
+  for (uint32_t k = 0; k < kBigSegs; k++) {
+    const uint32_t c = h[64 + k * kBigSegStride];
+    big += c;
+    overflowed += c > seg_cap ? 1u : 0u;
+  }
+  host_out4[0] = (uint32_t)std::min<uint64_t>(big, 0xFFFFFFFFull);
+  host_out4[1] = h[0];
+  host_out4[2] = h[32];
+  host_out4[3] = overflowed;
   return OXC_OK;
 }
 

@@ -242,6 +242,7 @@ EXPORTS = [
     "oxc_read_counters",
     "oxc_stream_read_probe",
     "oxc_debug_decode_bounds",
+    "oxc_debug_raster_stats",
     "oxc_profile_begin",
     "oxc_profile_end",
     "oxc_build_meshlet_bounds",
@@ -323,6 +324,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.oxc_debug_raster_stats.argtypes = [vp, vp, vp]
     lib.oxc_comm_unique_id.argtypes = [vp, vp]
     lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     lib.oxc_comm_destroy.argtypes = [vp]

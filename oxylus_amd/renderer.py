@@ -363,6 +363,12 @@ class RendererInstance:
         self._keep = (visdepth, depth, visbuffer, draw_cmd)
         self._check(self._lib.oxc_draw_visbuffer(self._ctx, C.byref(f), C.byref(d), self._stream(stream)))
 
+    def debug_raster_stats(self, stream=None) -> dict:
+        """What the last draw_visbuffer did with its triangles (test hook; synchronises)."""
+        out = (C.c_uint32 * 4)()
+        self._check(self._lib.oxc_debug_raster_stats(self._ctx, C.cast(out, C.c_void_p), self._stream(stream)))
+        return {"big": int(out[0]), "clipped": int(out[1]), "tiles": int(out[2]), "overflowed_segments": int(out[3])}
+
     def debug_project_aabb(self, mvp16, near_clip: float, boxes6: torch.Tensor) -> torch.Tensor:
         """boxes6 f32 [n, 6] = {center.xyz, extent.xyz} -> f32 [n, 7] = {min.u, min.v, min.z, max.u, max.v, max.z, valid}."""
         n = boxes6.shape[0]

@@ -254,6 +254,33 @@ def test_gpu_draw_with_the_camera_inside_the_geometry(renderer, oracle_lib, dept
     got, vd = _draw_list_both(renderer, cpu, idx, pv, W, H)
     assert oracle.draw_clipped_count() > 500, oracle.draw_clipped_count()
     assert torch.equal(got, vd) and (vd != 0).any()
+    st = renderer.debug_raster_stats()
+    assert st["clipped"] > 500 and st["big"] > 0, st
+
+
+@pytest.mark.gpu
+def test_gpu_draw_when_the_big_list_overflows(oracle_lib, monkeypatch):
+    """A context whose big list holds 8192 triangles (OXC_RASTER_BIG_CAPACITY, read by the first draw) and a scene with far more
+    triangles whose pixel boxes exceed 8 x 8: segments fill up and the setup lanes walk the excess themselves -- slow, and still
+    the same image."""
+    import oracle
+    from oxylus_amd.renderer import RendererInstance
+
+    monkeypatch.setenv("OXC_RASTER_BIG_CAPACITY", "8192")
+    r = RendererInstance(0)
+    try:
+        cpu = make_scene(SceneSpec(n_mesh_instances=60, meshlets_per_mesh=50, seed=12, scene_depth=12.0), "cpu")
+        cam = cpu.cull_camera()
+        pv = [cam.projection_view[i] for i in range(16)]
+        W, H = 1920, 1080
+        want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances)  # frustum + cone: nothing near or behind the camera plane
+        idx = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, 0, want_vis.numel())
+        got, vd = _draw_list_both(r, cpu, idx, pv, W, H)
+        st = r.debug_raster_stats()
+        assert st["big"] > 8192 and st["overflowed_segments"] > 0, st
+        assert torch.equal(got, vd) and (vd != 0).any()
+    finally:
+        r.close()
 
 
 @pytest.mark.gpu
