@@ -435,7 +435,8 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* context, void* hi
  *           edge with inside end I and outside end O the new vertex is I + t (O - I), t = d(I) / (d(I) - d(O)), binary32, no
  *           contraction, all four clip coordinates -- the same value for both triangles that share the edge.  The polygon
  *           (<= 8 corners) is drawn as the fan (p0, pk, pk+1), each with the vis value of the source triangle; a triangle inside
- *           every plane is untouched (round 1 had no clipper and dropped triangles with a corner at w <= 0);
+ *           every plane is untouched (round 1 had no clipper and dropped triangles with a corner at w <= 0).  Capacity: the
+ *           ids of the triangles that cross a plane are queued, at most 2^22 per call; beyond that they are dropped;
  *   setup   screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel; back faces (fixed-point
  *           area >= 0, the orientation cull_triangles' determinant test calls back-facing) are dropped;
  *   cover   pixel centres, integer edge functions, top-left rule;
