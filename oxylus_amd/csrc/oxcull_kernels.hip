@@ -594,7 +594,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 
   // Work distribution.  A wave step (64 * G meshlets) costs anything between a few hundred cycles (early pass, nothing of it was visible
   // last frame) and several thousand (a visible instance: cone + occlusion), so a fixed stride leaves the CUs half empty while
-  // the unlucky waves finish (average occupancy 69 % of the resident waves, SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES).  With
+  // the unlucky waves finish (SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES: 13.8 of 16 resident waves on average, the tail on a nearly empty machine).  With
   // a.tickets the waves draw their steps from kTicketCounters counters instead -- counter x = blockIdx % K hands out
   // the steps congruent to x mod K (K = min(kTicketCounters, grid)); the next ticket is requested while the current step is worked on.  Results are
   // stored by step index, so the output is the same whatever wave does the step.  Same-address atomics retire at ~13 ns each on
