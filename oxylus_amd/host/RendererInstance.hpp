@@ -82,8 +82,14 @@ struct MainGeometryContext {
   GPU::CullCamera cull_camera = {};
   ImageAttachment depth_attachment = {};
   ImageAttachment hiz_attachment = {};
+  Buffer visbuffer_attachment = {};  // R32_UINT image as a linear buffer of width * height u32 (the reference: vuk::ImageAttachment)
   Buffer draw_geometry_cmd_buffer = {};
   Buffer visibility_buffer = {};
+  // not in the reference struct: the compute rasteriser's packed depth|vis image (u64 per pixel) that persists between the early
+  // and the late draw of a frame, whether this draw starts from a cleared image (the early one), and the wide-index extension
+  Buffer visdepth_buffer = {};
+  bool clear = true;
+  bool wide_triangle_index = false;
 };
 
 class RendererInstance {
@@ -142,6 +148,41 @@ public:
     context.cull_meshlets_cmd_buffer = c.cull_meshlets_cmd_buffer;
     context.cull_triangles_cmd_buffer = c.cull_triangles_cmd_buffer;
     context.draw_geometry_cmd_buffer = c.draw_geometry_cmd_buffer;
+  }
+
+  // Oxylus/src/Render/Passes/DrawGeometry.cpp:104-190 for the compute-only backend: the triangles of context.draw_geometry_cmd_buffer
+  // (prepared_frame.reordered_indices_buffer, as vs_main decodes them) into depth_attachment / visbuffer_attachment, with
+  // context.cull_camera.projection_view as Camera::projection_view.  Rules: include/oxcull.h, oxc_draw_visbuffer.
+  auto draw_for_visbuffer(MainGeometryContext& context) -> void {
+    if (prepared_frame.use_mesh_shaders) throw std::runtime_error("draw_for_visbuffer: the mesh-shader path is not available on the compute-only backend");
+    oxc_prepared_frame f = {};
+    f.mesh_instance_count = prepared_frame.mesh_instance_count;
+    f.max_meshlet_instance_count = prepared_frame.max_meshlet_instance_count;
+    f.meshes_buffer = prepared_frame.meshes_buffer;
+    f.transforms_world_buffer = prepared_frame.transforms_world_buffer;
+    f.mesh_instances_buffer = prepared_frame.mesh_instances_buffer;
+    f.meshlet_instances_buffer = prepared_frame.meshlet_instances_buffer;
+    f.visible_meshlet_instances_indices_buffer = prepared_frame.visible_meshlet_instances_indices_buffer;
+    f.meshlet_instance_visibility_mask_buffer = prepared_frame.meshlet_instance_visibility_mask_buffer;
+    f.reordered_indices_buffer = prepared_frame.reordered_indices_buffer;
+    oxc_draw_context d = {};
+    d.struct_size = sizeof d;
+    d.wide_triangle_index = context.wide_triangle_index;
+    d.clear = context.clear;
+    d.width = context.depth_attachment.width;
+    d.height = context.depth_attachment.height;
+    for (int i = 0; i < 16; i++) d.projection_view[i] = context.cull_camera.projection_view[i];
+    d.draw_geometry_cmd_buffer = context.draw_geometry_cmd_buffer;
+    d.visdepth_buffer = context.visdepth_buffer;
+    d.depth_attachment = context.depth_attachment;
+    d.visbuffer_attachment = context.visbuffer_attachment;
+    check(oxc_draw_visbuffer(ctx_, &f, &d, stream_));
+  }
+
+  // Oxylus/src/Render/Passes/Terrain.cpp:159-216 (the reference's TerrainContext carries the Terrain object; here its GPU-side fields)
+  auto cull_terrain(oxc_terrain_context& context) -> void {
+    context.struct_size = sizeof context;
+    check(oxc_cull_terrain(ctx_, &context, stream_));
   }
 
   // Producers around the cull path: the downsample_hpb_pass of draw_virtual_shadowmap

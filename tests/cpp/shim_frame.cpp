@@ -206,6 +206,24 @@ int main(int argc, char** argv) {
       std::memcpy(&k, out[out.size() - 3].second.data(), sizeof k);
       out.push_back({"A_meshlet_instances", dev.download("meshlet_instances", (uint64_t)k.total_visible_meshlet_instances * 8)});
       out.push_back({"A_mesh_instances", dev.download("mesh_instances", mesh_instances0.size())});
+      // the draw that consumes the lists (DrawGeometry.cpp:104-190), 512 x 384 like the raster fixture
+      const uint32_t W = 512, H = 384;
+      dev.alloc("visdepth", (uint64_t)W * H * 8);
+      dev.alloc("draw_depth", (uint64_t)W * H * 4);
+      dev.alloc("draw_vis", (uint64_t)W * H * 4);
+      auto main_geometry_context = MainGeometryContext{.cull_camera = cam};
+      main_geometry_context.depth_attachment = ImageAttachment{};
+      main_geometry_context.depth_attachment.dptr = dev.ptr.at("draw_depth");
+      main_geometry_context.depth_attachment.width = W;
+      main_geometry_context.depth_attachment.height = H;
+      main_geometry_context.depth_attachment.levels = 1;
+      main_geometry_context.visbuffer_attachment = dev.buf("draw_vis");
+      main_geometry_context.visdepth_buffer = dev.buf("visdepth");
+      main_geometry_context.draw_geometry_cmd_buffer = cull_geometry_context.draw_geometry_cmd_buffer;
+      self.draw_for_visbuffer(main_geometry_context);
+      out.push_back({"A_visdepth", dev.download("visdepth", (uint64_t)W * H * 8)});
+      out.push_back({"A_draw_depth", dev.download("draw_depth", (uint64_t)W * H * 4)});
+      out.push_back({"A_draw_vis", dev.download("draw_vis", (uint64_t)W * H * 4)});
     }
     // ---- sequence B: two-pass occlusion in the reference's order; fresh instance table + the fixture's prior mask
     HIP(hipMemcpy(dev.ptr.at("mesh_instances"), mesh_instances0.data(), mesh_instances0.size(), hipMemcpyHostToDevice));

@@ -118,6 +118,12 @@ def test_cpp_shim_runs_the_reference_sequence_with_data(tmp_path, oracle_lib):
     assert np.array_equal(u32(got["A_visible"]), z["plain_visible"].view(np.uint32))
     assert np.array_equal(u32(got["A_indices"]), z["plain_indices"].view(np.uint32))
     assert np.array_equal(u32(got["A_mesh_instances"]).reshape(-1, 5)[:, 1], z["plain_lod_index"].view(np.uint32))
+    # ... and the draw that consumes them (draw_for_visbuffer) against the committed raster fixture + its two resolves
+    vd = np.load(os.path.join(ROOT, "tests", "golden", "raster_512x384.npz"))["visdepth"]
+    assert np.array_equal(np.asarray([cam.projection_view[i] for i in range(16)], dtype=np.float32), np.asarray(z["camera_pv"], dtype=np.float32).reshape(-1))
+    assert np.array_equal(np.frombuffer(got["A_visdepth"], dtype=np.int64).reshape(384, 512), vd)
+    assert np.array_equal(u32(got["A_draw_depth"]).reshape(384, 512), (vd >> 32).astype(np.uint32))
+    assert np.array_equal(u32(got["A_draw_vis"]).reshape(384, 512), (vd & 0xFFFFFFFF).astype(np.uint32))
 
     # ---- sequence B against the checker, run here in the same order
     sc = s.clone()
