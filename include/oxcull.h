@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define OXC_ABI_VERSION 2u
+#define OXC_ABI_VERSION 3u
 
 typedef struct oxc_ctx oxc_ctx;
 
@@ -154,7 +154,15 @@ typedef struct oxc_cull_geometry_context {
    * (pixel centres sit at k + 0.5: an interval [lo, hi] holds one iff the two roundings differ).  Not supported by
    * the fused path of oxc_cull_geometry_batch (such elements are processed one after the other). */
   uint32_t small_triangle_cull;
-  uint32_t _reserved0;
+  /* Extension (scheduling only, no effect on any output byte): 1 = the triangle stage of this call (cull_triangles test + ordered
+   * emit) is enqueued on a second stream the context owns and runs BESIDE whatever is enqueued on hip_stream next -- typically the
+   * meshlet stage of the following oxc_cull_geometry call (ALU-bound, while the triangle stage is HBM-bound) and oxc_generate_hiz.
+   * reordered_indices_buffer and draw_geometry_cmd_buffer of this call are complete on a stream only after
+   * oxc_join_triangles(ctx, that stream); every oxc_* entry point that reads them (oxc_read_counters, oxc_pack_counters,
+   * oxc_draw_visbuffer) joins by itself.  The context orders everything it owns or writes: a later call waits where it would
+   * overwrite what a pending triangle stage still reads (the visible list, MeshletInstance records rewritten by cull_meshes, its own
+   * scratch).  0 (default) = the whole call is in order on hip_stream, as the reference records it. */
+  uint32_t async_triangles;
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */
@@ -201,6 +209,11 @@ oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* conte
  * atomic-ordered output, and a deterministic one). */
 oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* frame, oxc_cull_geometry_context* context,
                              void* hip_stream);
+
+/* Makes `hip_stream` wait (on the device) for every triangle stage this context still has in flight on its own stream
+ * (calls made with async_triangles = 1).  Cheap when nothing is pending.  While hip_stream is being captured into a HIP graph the
+ * context's stream is part of the capture from the first async call on: join before hipStreamEndCapture. */
+oxc_status oxc_join_triangles(oxc_ctx* ctx, void* hip_stream);
 
 /* Batched form: semantically `for i < count: oxc_cull_geometry(ctx, &frames[i], &contexts[i], stream)` for
  * INDEPENDENT frames (no buffer of one element is written by another) -- several views or scenes culled per

@@ -42,6 +42,7 @@ struct oxc_ctx {
     uint64_t arena_bytes = 0;
     uint32_t cap_mesh_instances = 0, cap_meshlets = 0;
     InstCache* cache = nullptr;
+    InstCache* cache_alt = nullptr;   // second set of rows: calls alternate, so that a triangle stage still in flight on the side stream keeps the rows of ITS call
     InstCache* view_cache = nullptr;  // [views][M] rows for use_hpb
     uint32_t cap_views = 0;
     uint32_t* mesh_counts = nullptr;
@@ -53,6 +54,7 @@ struct oxc_ctx {
     uint64_t* tri_masks = nullptr;
     uint32_t* t_chunk_counts = nullptr;
     uint32_t* t_supers = nullptr;
+    uint32_t* t_supers_alt = nullptr;  // alternates with t_supers like the cache rows (prepare zeroes the next call's accumulators on the caller's stream)
   };
   Lane lane[kMaxBatch];
   BatchElem* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call (kMaxBatch elements)
@@ -77,6 +79,23 @@ struct oxc_ctx {
   hipStream_t last_stream = nullptr;
   bool has_last_stream = false;
   hipEvent_t order_event = nullptr;
+  // async_triangles: the triangle stage of a call runs on `side`, forked from the caller's stream after the meshlet emit.
+  // tri[k % kTriRing] describes the stage of lane-0 call number k (call_seq) while it may still be in flight.
+  hipStream_t side = nullptr;
+  hipEvent_t fork_event = nullptr;
+  struct TriPending {
+    hipEvent_t done = nullptr;
+    bool valid = false;
+    bool late = false;
+    const uint32_t* vis = nullptr;  // the sequence's visibility counters (the late list starts at vis[1])
+    const void* visible = nullptr;  // visible_meshlet_instances_indices_buffer it reads
+  };
+  static constexpr uint32_t kTriRing = 4;
+  TriPending tri[kTriRing];
+  uint64_t call_seq = 0;  // lane-0 oxc_cull_geometry calls so far: parity selects cache / t_supers
+  // resident blocks per CU of the persistent kernels while the two stages share the machine (0 = no limit); the environment
+  // variables OXC_ASYNC_MTEST_BLOCKS_PER_CU / OXC_ASYNC_TRI_BLOCKS_PER_CU, read by oxc_create, override the defaults (tuning aid)
+  uint32_t async_mtest_per_cu = kAsyncMeshletBlocksPerCU, async_tri_per_cu = kAsyncTriangleBlocksPerCU;
   // profiling (oxc_profile_begin/end)
   bool profiling = false;
   struct Rec {
@@ -153,6 +172,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
     return o;
   };
   const uint64_t o_cache = carve((uint64_t)M * sizeof(InstCache));
+  const uint64_t o_cache_alt = carve((uint64_t)M * sizeof(InstCache));
   const uint64_t o_vcache = carve((uint64_t)M * Vw * sizeof(InstCache) + 64);
   const uint64_t o_counts = carve((uint64_t)M * 4);
   const uint64_t o_offsets = carve((uint64_t)M * 4);
@@ -163,7 +183,9 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
-  OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work may still use the old arena
+  const uint64_t o_tsup_alt = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
+  OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work (the side stream's included) may still use the old arena
+  for (auto& tp : ctx->tri) tp.valid = false;
   if (L->arena) OXC_HIP(ctx, hipFree(L->arena));
   L->arena = nullptr;
   hipError_t e = hipMalloc(&L->arena, off);
@@ -174,6 +196,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->arena_bytes = off;
   char* b = static_cast<char*>(L->arena);
   L->cache = reinterpret_cast<InstCache*>(b + o_cache);
+  L->cache_alt = reinterpret_cast<InstCache*>(b + o_cache_alt);
   L->view_cache = reinterpret_cast<InstCache*>(b + o_vcache);
   L->cap_views = Vw;
   L->mesh_counts = reinterpret_cast<uint32_t*>(b + o_counts);
@@ -185,6 +208,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
   L->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
+  L->t_supers_alt = reinterpret_cast<uint32_t*>(b + o_tsup_alt);
   L->cap_mesh_instances = M;
   L->cap_meshlets = N;
   return OXC_OK;
@@ -202,6 +226,23 @@ uint32_t* next_seed_slot(oxc_ctx* ctx) {
   ctx->seed_cursor++;
   return s;
 }
+
+// ---- async_triangles: what is in flight on the context's own stream ----
+// Makes `s` wait for every pending triangle stage for which `needed` says so.
+template <class Pred>
+oxc_status wait_triangles(oxc_ctx* ctx, hipStream_t s, Pred needed) {
+  for (auto& tp : ctx->tri)
+    if (tp.valid && needed(tp)) OXC_HIP(ctx, hipStreamWaitEvent(s, tp.done, 0));
+  return OXC_OK;
+}
+oxc_status join_triangles(oxc_ctx* ctx, hipStream_t s) {
+  return wait_triangles(ctx, s, [](const oxc_ctx::TriPending&) { return true; });
+}
+#define OXC_JOIN(ctx, stream)                                               \
+  do {                                                                      \
+    oxc_status _j = join_triangles(ctx, static_cast<hipStream_t>(stream));  \
+    if (_j != OXC_OK) return _j;                                            \
+  } while (0)
 
 // Brackets one kernel launch with events while profiling is on.
 struct KernelTimer {
@@ -316,6 +357,8 @@ oxc_status oxc_create(int device, oxc_ctx** out) {
   }
   (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
   ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
+  if (const char* ev = std::getenv("OXC_ASYNC_MTEST_BLOCKS_PER_CU")) ctx->async_mtest_per_cu = (uint32_t)std::max(0, std::atoi(ev));
+  if (const char* ev = std::getenv("OXC_ASYNC_TRI_BLOCKS_PER_CU")) ctx->async_tri_per_cu = (uint32_t)std::max(0, std::atoi(ev));
   *out = ctx;
   return OXC_OK;
 }
@@ -333,6 +376,10 @@ void oxc_destroy(oxc_ctx* ctx) {
   if (ctx->comm) (void)oxc_comm_destroy(ctx);
   if (ctx->slots) (void)hipFree(ctx->slots);
   if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
+  if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+  for (auto& tp : ctx->tri)
+    if (tp.done) (void)hipEventDestroy(tp.done);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   delete ctx;
 }
 
@@ -406,6 +453,35 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   if (st != OXC_OK) return st;
   OXC_ORDER(ctx, hip_stream);
 
+  // ---- async_triangles bookkeeping (include/oxcull.h).  Calls alternate between two sets of instance rows / triangle-count
+  // accumulators, so that what this call's prepare kernel writes on `s` is never what a triangle stage still in flight on the
+  // side stream reads; the set of this call was last used by the call before the previous one.
+  oxc_ctx::Lane& L0 = ctx->lane[0];
+  const uint64_t call_no = ctx->call_seq++;
+  const bool async = c->async_triangles != 0 && do_tris;
+  InstCache* const cache = (call_no & 1u) ? L0.cache_alt : L0.cache;
+  uint32_t* const t_supers = (call_no & 1u) ? L0.t_supers_alt : L0.t_supers;
+  oxc_ctx::TriPending& my_tri = ctx->tri[call_no % oxc_ctx::kTriRing];
+  my_tri.valid = false;  // (the stage of call_no - kTriRing: every call since has waited for it where it mattered, and the side stream is in order)
+  if (!async || do_meshes) {
+    // in order on `s`: the triangle stage shares tri_masks / chunk counts with the side stream; cull_meshes rewrites the
+    // MeshletInstance records a pending stage reads
+    OXC_JOIN(ctx, s);
+  } else if (call_no >= 2) {
+    const oxc_ctx::TriPending& old = ctx->tri[(call_no - 2) % oxc_ctx::kTriRing];
+    if (old.valid) OXC_HIP(ctx, hipStreamWaitEvent(s, old.done, 0));
+  }
+  // Two kernels only run side by side when neither fills every wave slot (tools/overlap_probe.py): with async_triangles the
+  // persistent kernels of both stages take a share of the CUs' slots instead of all of them.
+  const uint32_t mtest_limit = (c->async_triangles && ctx->async_mtest_per_cu) ? ctx->async_mtest_per_cu * ctx->num_cus : 0u;
+  const uint32_t tri_grid_cap = (async && ctx->async_tri_per_cu) ? ctx->async_tri_per_cu * ctx->num_cus : ctx->num_cus * 8;
+  const void* const visible_buf = f->visible_meshlet_instances_indices_buffer.dptr;
+  // the meshlet emit of this call overwrites the visible list: wait for the pending stages that still read it -- all but the
+  // early triangle stage of the same sequence when this is its late call (the late list starts behind the early one)
+  auto wait_for_visible_list = [&](const uint32_t* vis_now) -> oxc_status {
+    return wait_triangles(ctx, s, [&](const oxc_ctx::TriPending& tp) { return !(late && !tp.late && tp.vis == vis_now && tp.visible == visible_buf); });
+  };
+
   uint32_t* slot = next_slot(ctx);
   uint32_t* vis;
   uint32_t* meshlets_cmd;
@@ -438,13 +514,13 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.meshes = static_cast<const GpuMesh*>(f->meshes_buffer.dptr);
   pa.transforms = static_cast<const float*>(f->transforms_world_buffer.dptr);
   pa.mesh_instances = static_cast<GpuMeshInstance*>(f->mesh_instances_buffer.dptr);
-  pa.cache = ctx->lane[0].cache;
+  pa.cache = cache;
   pa.mesh_counts = ctx->lane[0].mesh_counts;
   pa.slot = slot;
   pa.vis = vis;
   pa.meshlets_cmd = meshlets_cmd;
   pa.supers_meshlets = ctx->lane[0].m_supers;
-  pa.supers_tris = ctx->lane[0].t_supers;
+  pa.supers_tris = t_supers;
   pa.tickets = ctx->lane[0].m_tickets;
   pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
   pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
@@ -474,7 +550,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   if (do_meshlets && c->use_hpb) {  // CullGeometry.cpp:199-273
     HpbTestArgs ha;
     std::memset(&ha, 0, sizeof ha);
-    ha.cache = ctx->lane[0].cache;
+    ha.cache = cache;
     ha.view_cache = ctx->lane[0].view_cache;
     ha.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ha.vis = vis;
@@ -509,6 +585,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ea.vis = vis;
     ea.tri_cmd = tri_cmd;
     ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+    {
+      oxc_status wst = wait_for_visible_list(vis);
+      if (wst != OXC_OK) return wst;
+    }
     KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
     launch_meshlets_emit(ea, false, false, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
   } else if (do_meshlets) {
@@ -517,7 +597,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     ta.n_host = n_host;
     ta.n_cap = N;
     ta.mask_bits = (uint32_t)std::min<uint64_t>(f->meshlet_instance_visibility_mask_buffer.bytes / 4u * 32u, 0xFFFFFFFEull);
-    ta.cache = ctx->lane[0].cache;
+    ta.cache = cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ta.vis = vis;
     ta.mask = static_cast<uint32_t*>(f->meshlet_instance_visibility_mask_buffer.dptr);
@@ -552,7 +632,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     {
       {
         KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
-        launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, s);
+        launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, mtest_limit, s);
       }
       MeshletEmitArgs ea;
       ea.n_host = n_host;
@@ -564,6 +644,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ea.vis = vis;
       ea.tri_cmd = tri_cmd;
       ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+      {
+        oxc_status wst = wait_for_visible_list(vis);
+        if (wst != OXC_OK) return wst;
+      }
       KernelTimer t(ctx, late ? OXC_K_MESHLETS_EMIT_LATE : OXC_K_MESHLETS_EMIT, s);
       launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
     }
@@ -571,20 +655,28 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
 
   // --- triangle stage: CullGeometry.cpp:337-403
   if (do_tris) {
+    hipStream_t ts = s;
+    if (async) {  // fork: everything enqueued on `s` so far (this call's meshlet emit, the caller's earlier consumers of the index list) precedes the stage
+      if (!ctx->side) OXC_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+      if (!ctx->fork_event) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+      OXC_HIP(ctx, hipEventRecord(ctx->fork_event, s));
+      OXC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_event, 0));
+      ts = ctx->side;
+    }
     TriTestArgs tt;
-    tt.cache = ctx->lane[0].cache;
+    tt.cache = cache;
     tt.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     tt.visible = static_cast<const uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
     tt.vis = vis;
     tt.tri_cmd = tri_cmd;
     tt.tri_masks = ctx->lane[0].tri_masks;
     tt.chunk_counts = ctx->lane[0].t_chunk_counts;
-    tt.supers = ctx->lane[0].t_supers;
+    tt.supers = t_supers;
     tt.resolution[0] = c->cull_camera.resolution[0];
     tt.resolution[1] = c->cull_camera.resolution[1];
     {
-      KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, s);
-      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, max_grid), s);
+      KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
+      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, tri_grid_cap), ts);
     }
     TriEmitArgs te;
     te.tri_masks = ctx->lane[0].tri_masks;
@@ -592,14 +684,30 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     te.vis = vis;
     te.tri_cmd = tri_cmd;
     te.chunk_counts = ctx->lane[0].t_chunk_counts;
-    te.supers = ctx->lane[0].t_supers;
+    te.supers = t_supers;
     te.draw_cmd = draw_cmd;
     te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
-    KernelTimer t(ctx, late ? OXC_K_TRIANGLES_EMIT_LATE : OXC_K_TRIANGLES_EMIT, s);
-    launch_tris_emit(te, late, c->wide_triangle_index != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), max_grid), s);
+    {
+      KernelTimer t(ctx, late ? OXC_K_TRIANGLES_EMIT_LATE : OXC_K_TRIANGLES_EMIT, ts);
+      launch_tris_emit(te, late, c->wide_triangle_index != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), tri_grid_cap), ts);
+    }
+    if (async) {
+      if (!my_tri.done) OXC_HIP(ctx, hipEventCreateWithFlags(&my_tri.done, hipEventDisableTiming));
+      OXC_HIP(ctx, hipEventRecord(my_tri.done, ts));
+      my_tri.valid = true;
+      my_tri.late = late;
+      my_tri.vis = vis;
+      my_tri.visible = visible_buf;
+    }
   }
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
+}
+
+oxc_status oxc_join_triangles(oxc_ctx* ctx, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  return join_triangles(ctx, static_cast<hipStream_t>(hip_stream));
 }
 
 oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepared_frame* frames, oxc_cull_geometry_context* contexts,
@@ -629,6 +737,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     if (st != OXC_OK) return st;
   }
   OXC_ORDER(ctx, hip_stream);
+  OXC_JOIN(ctx, hip_stream);  // the batched call uses lane 0's scratch in order on hip_stream
   if (!ctx->batch_dev) {
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry_batch: the first batched call allocates its argument block; make one un-captured call first");
@@ -769,6 +878,7 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   if (!c || !out) return fail(ctx, OXC_INVALID_ARG, "read_counters: null argument");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   OXC_ORDER(ctx, hip_stream);
+  OXC_JOIN(ctx, hip_stream);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   uint32_t vis[3] = {0, 0, 0}, mc[3] = {0, 0, 0}, tc[3] = {0, 0, 0}, dc[5] = {0, 0, 0, 0, 0};
   if (c->visibility_buffer.dptr) OXC_HIP(ctx, hipMemcpyAsync(vis, c->visibility_buffer.dptr, 12, hipMemcpyDeviceToHost, s));
@@ -1063,6 +1173,7 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   if (d->visbuffer_attachment.dptr && d->visbuffer_attachment.bytes < n * 4u) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: visbuffer_attachment smaller than width*height u32");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   OXC_ORDER(ctx, hip_stream);
+  OXC_JOIN(ctx, hip_stream);  // reads reordered_indices / the draw command
   if (!ctx->raster_scratch) {
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
       return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: the first call allocates its scratch; make one un-captured call first");
@@ -1208,6 +1319,7 @@ oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, v
   if (!c || c->struct_size != sizeof(oxc_cull_geometry_context) || !counts4_dptr) return fail(ctx, OXC_INVALID_ARG, "pack_counters: bad context struct or null output");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   OXC_ORDER(ctx, hip_stream);
+  OXC_JOIN(ctx, hip_stream);
   launch_pack_counters(static_cast<const uint32_t*>(c->visibility_buffer.dptr), static_cast<const uint32_t*>(c->cull_triangles_cmd_buffer.dptr),
                        static_cast<const uint32_t*>(c->draw_geometry_cmd_buffer.dptr), static_cast<uint32_t*>(counts4_dptr), static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());

@@ -1632,8 +1632,9 @@ static uint32_t resident_grid(K kernel, uint32_t block, uint32_t num_cus) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, 0) != hipSuccess || per_cu <= 0) return num_cus * 8u;
   return (uint32_t)per_cu * num_cus;
 }
-void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, hipStream_t s) {
+void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, uint32_t grid_limit, hipStream_t s) {
   constexpr uint32_t hb = 1024 / kHizGroups;
+  if (hiz && grid_limit) grid = std::min(grid, grid_limit);
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
   } else if (occl && late) {

@@ -110,5 +110,10 @@ constexpr uint32_t kHizLdsTexels = OXC_HIZ_LDS_TEXELS;      // LDS budget (float
 constexpr uint32_t kSuperStride = 64;         // words between super-chunk accumulators: one per 256 B so their atomics do not serialise on a cache line
 constexpr uint32_t kTicketCounters = 256;    // dynamic work counters of the HiZ meshlet test: counter x hands out the wave steps congruent to x mod 256
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
+// async_triangles (include/oxcull.h): resident blocks per CU the persistent kernels of the two stages take while they share the machine
+// (0 = no limit).  HiZ meshlet test: 4 waves of <= 96 VGPRs per block; triangle test / emit: 4 waves of <= 64 VGPRs -- per SIMD
+// 2 x 96 + 5 x 64 = 512 VGPRs, 7 of 8 wave slots.
+constexpr uint32_t kAsyncMeshletBlocksPerCU = 2;
+constexpr uint32_t kAsyncTriangleBlocksPerCU = 5;
 
 }  // namespace oxc

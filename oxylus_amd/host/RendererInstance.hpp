@@ -75,6 +75,9 @@ struct CullGeometryContext {
   // extension: wide packed index for meshlets of up to 128 triangles
   bool wide_triangle_index = false;
   bool small_triangle_cull = false;  // extension named by the north star; default OFF = reference behaviour
+  // extension (scheduling only): cull_triangles of this call runs on the backend's own stream beside what the caller enqueues next
+  // (the next cull_geometry's meshlet stage, generate_hiz); join_triangles() before anything of the caller's reads the index list
+  bool async_triangles = false;
 };
 
 struct MainGeometryContext {
@@ -141,6 +144,7 @@ public:
     c.vsm_clipmap_count = context.vsm_clipmap_count;
     c.wide_triangle_index = context.wide_triangle_index;
     c.small_triangle_cull = context.small_triangle_cull;
+    c.async_triangles = context.async_triangles;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));
@@ -149,6 +153,9 @@ public:
     context.cull_triangles_cmd_buffer = c.cull_triangles_cmd_buffer;
     context.draw_geometry_cmd_buffer = c.draw_geometry_cmd_buffer;
   }
+
+  // The stream waits for every cull_triangles stage still in flight (async_triangles); draw_for_visbuffer joins by itself.
+  auto join_triangles() -> void { check(oxc_join_triangles(ctx_, stream_)); }
 
   // Oxylus/src/Render/Passes/DrawGeometry.cpp:104-190 for the compute-only backend: the triangles of context.draw_geometry_cmd_buffer
   // (prepared_frame.reordered_indices_buffer, as vs_main decodes them) into depth_attachment / visbuffer_attachment, with

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liboxcull.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 OXC_OK, OXC_INVALID_ARG, OXC_HIP_ERROR, OXC_RCCL_ERROR, OXC_OUT_OF_MEMORY = range(5)
-ABI_VERSION = 2  # OXC_ABI_VERSION of include/oxcull.h
+ABI_VERSION = 3  # OXC_ABI_VERSION of include/oxcull.h
 
 CULL_TEST_FRUSTUM = 1
 CULL_SELECT_LOD = 2
@@ -99,7 +99,7 @@ class CullGeometryContext(C.Structure):
         ("vsm_clipmap_count", C.c_uint32),
         ("wide_triangle_index", C.c_uint32),
         ("small_triangle_cull", C.c_uint32),
-        ("_reserved0", C.c_uint32),
+        ("async_triangles", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),
@@ -238,6 +238,7 @@ EXPORTS = [
     "oxc_generate_hiz",
     "oxc_cull_geometry",
     "oxc_cull_geometry_batch",
+    "oxc_join_triangles",
     "oxc_seed_meshlet_instances",
     "oxc_read_counters",
     "oxc_stream_read_probe",
@@ -305,6 +306,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_generate_hiz.argtypes = [vp, C.POINTER(MainGeometryContext), vp]
     lib.oxc_cull_geometry.argtypes = [vp, C.POINTER(PreparedFrame), C.POINTER(CullGeometryContext), vp]
     lib.oxc_cull_geometry_batch.argtypes = [vp, C.c_uint32, C.POINTER(PreparedFrame), C.POINTER(CullGeometryContext), vp]
+    lib.oxc_join_triangles.argtypes = [vp, vp]
     lib.oxc_seed_meshlet_instances.argtypes = [vp, C.POINTER(CullGeometryContext), C.c_uint32, vp]
     lib.oxc_read_counters.argtypes = [vp, C.POINTER(CullGeometryContext), C.POINTER(Counters), vp]
     lib.oxc_stream_read_probe.argtypes = [vp, vp, C.c_uint64, vp]

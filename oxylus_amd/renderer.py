@@ -152,6 +152,7 @@ class CullGeometryContext:
     vsm_clipmap_count: int = 0
     wide_triangle_index: bool = False  # extension: (id << 9) | (3t+k), meshlets of up to 128 triangles
     small_triangle_cull: bool = False  # extension (north star): also drop triangles whose screen bbox covers no pixel centre
+    async_triangles: bool = False  # extension (scheduling only): the triangle stage runs on the context's own stream; RendererInstance.join_triangles
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -171,6 +172,7 @@ class CullGeometryContext:
         c.vsm_clipmap_count = self.vsm_clipmap_count
         c.wide_triangle_index = int(self.wide_triangle_index)
         c.small_triangle_cull = int(self.small_triangle_cull)
+        c.async_triangles = int(self.async_triangles)
         return c
 
 
@@ -229,6 +231,10 @@ class RendererInstance:
         assert self.prepared_frame is not None
         f = self.prepared_frame.c()
         self._check(self._lib.oxc_cull_geometry(self._ctx, C.byref(f), C.byref(context.c()), self._stream(stream)))
+
+    def join_triangles(self, stream=None):
+        """`stream` waits for every triangle stage still in flight on the context's own stream (async_triangles)."""
+        self._check(self._lib.oxc_join_triangles(self._ctx, self._stream(stream)))
 
     def cull_geometry_batch(self, frames, contexts, stream=None):
         """Batched cull of independent (PreparedFrame, CullGeometryContext) pairs (oxc_cull_geometry_batch).

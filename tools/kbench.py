@@ -2,6 +2,8 @@
 """tools/kbench.py -- A/B several builds of liboxcull.so on the configs[2] frame in ONE process (one scene generation).
 
   python tools/kbench.py [--libs base=oxylus_amd/liboxcull.so,x=oxylus_amd/variants/liboxcull_x.so] [--frames 60] [--meshlets N]
+  A library entry may carry settings: tag=path@ASYNC=1@OXC_ASYNC_MTEST_BLOCKS_PER_CU=3 -- ASYNC=1 sets async_triangles on every call
+  (the frames then pipeline: triangle stages on the context's own stream), anything else goes into the environment before oxc_create.
 
 For every library: warm up, time `--frames` frames (wall, one stream), then an instrumented pass (HIP-event pair per kernel), and a
 checksum of every output of one frame (visible lists, packed indices, mask, pyramid) -- variants must agree with the first library
@@ -50,7 +52,15 @@ def main():
     mask = frame.meshlet_instance_visibility_mask_buffer
     results, ref_sum = [], None
     for item in a.libs.split(","):
-        tag, path = item.split("=")
+        tag, path = item.split("=", 1)
+        path, *settings = path.split("@")
+        use_async = False
+        for kv in settings:
+            k_, v_ = kv.split("=")
+            if k_ == "ASYNC":
+                use_async = v_ == "1"
+            else:
+                os.environ[k_] = v_
         r = RendererInstance(0, lib_path=os.path.join(ROOT, path) if not os.path.isabs(path) else path)
         lib, ctxp, sp = r._lib, r._ctx, C.c_void_p(stream.cuda_stream)
         r.reserve(M, N)
@@ -58,7 +68,10 @@ def main():
         ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
         with torch.cuda.stream(stream):
             r.seed_meshlet_instances(ctx, N)
+        for kv in settings:  # (read by oxc_create only)
+            os.environ.pop(kv.split("=")[0], None)
         cframe, cctx = frame.c(), ctx.c()
+        cctx.async_triangles = int(use_async)
         mg = L.MainGeometryContext()
         mg.struct_size = C.sizeof(L.MainGeometryContext)
         mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
