@@ -21,6 +21,9 @@
  * only, RenderContext.cpp:585-586) and owns ONE set of scratch buffers (instance cache, survivor
  * bitmaps, chunk counts), so its calls are ordered: a call on a different hipStream_t than the
  * context's previous call first waits (hipStreamWaitEvent, on the device) for that previous call.
+ * (Not across a HIP-graph capture: while hip_stream is being captured that wait is skipped -- work the context still has in flight
+ * on another stream must be complete, or ordered by the caller's own events inside the capture, before the capture begins; and a
+ * stream the context was last used on must outlive the next call on a different stream, or be synchronised before it is destroyed.)
  * Independent work that should overlap -- a main view and a shadow view, several frames in flight
  * -- uses one context per stream.  All work is enqueued asynchronously on the caller's hipStream_t
  * (passed as void*).  Entry points that synchronise the host: oxc_read_counters, oxc_debug_read_u32,
@@ -372,6 +375,9 @@ oxc_status oxc_mesh_blob_finalize(const oxc_mesh_blob_desc* desc, const oxc_mesh
  * max_vertices / max_triangles (64 / 64: Model::MAX_MESHLET_INDICES / _PRIMITIVES, meshopt_buildMeshlets with cone_weight 0), u8
  * micro-index runs 4-byte aligned (:687).  meshoptimizer is a third-party dependency that is not part of the reference tree: its two
  * algorithms are restated in shape, not heuristic for heuristic (oxylus_amd/csrc/oxcull_meshbuild.cpp) -- a valid, different clustering.
+ * LOD 0's `indices` are the input verbatim; triangles with a repeated corner are left out of the meshlets and of the simplifier's input
+ * (no area).  `error` accumulates this simplifier's own relative error measure: it orders a mesh's LODs like meshopt's result_error
+ * does but is not numerically comparable to it, so CULL_SELECT_LOD thresholds tuned against meshoptimizer do not carry over.
  * Host pointers in, host views out (owned by the handle); feed them to oxc_build_meshlet_bounds / oxc_quantize_vertex_streams /
  * oxc_mesh_blob_* to obtain what oxc_cull_geometry consumes. */
 typedef struct oxc_mesh_build oxc_mesh_build;
@@ -449,7 +455,8 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* context, void* hi
  *           contraction, all four clip coordinates -- the same value for both triangles that share the edge.  The polygon
  *           (<= 8 corners) is drawn as the fan (p0, pk, pk+1), each with the vis value of the source triangle; a triangle inside
  *           every plane is untouched (round 1 had no clipper and dropped triangles with a corner at w <= 0).  Capacity: the
- *           ids of the triangles that cross a plane are queued, at most 2^22 per call; beyond that they are dropped;
+ *           ids of the triangles that cross a plane are queued, 2^22 per call; when more cross, an overflow pass walks the index
+ *           list again and clips every crossing triangle it finds (slow, and the same image: drawing a triangle twice changes nothing);
  *   setup   screen = (clip.xy / clip.w * 0.5 + 0.5) * extent, snapped to 1/256 pixel; back faces (fixed-point
  *           area >= 0, the orientation cull_triangles' determinant test calls back-facing) are dropped;
  *   cover   pixel centres, integer edge functions, top-left rule;

@@ -130,11 +130,17 @@ oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hi
     if (_e != hipSuccess) return fail(ctx, OXC_HIP_ERROR, #expr, _e); \
   } while (0)
 
-// Device-side ordering of a context's calls across streams (see oxc_ctx::last_stream).
+bool stream_is_capturing(hipStream_t s);
+
+// Device-side ordering of a context's calls across streams (see oxc_ctx::last_stream).  Not across a capture boundary: an event
+// recorded outside a capture cannot be waited for inside it (and the reverse), so when `s` is being captured the wait for a
+// previous call on ANOTHER stream is skipped -- include/oxcull.h asks the caller to have that stream's work complete (or inside the
+// same capture through the caller's own events) before the capture begins.
 oxc_status order_stream(oxc_ctx* ctx, hipStream_t s) {
-  if (ctx->has_last_stream && ctx->last_stream != s) {
+  if (ctx->has_last_stream && ctx->last_stream != s && !stream_is_capturing(s)) {
     if (!ctx->order_event) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
-    // (the previous stream may have been destroyed by its owner since: its work is complete then, nothing to wait for)
+    // (the previous stream may have been destroyed by its owner since -- its work is complete then, nothing to wait for -- or be
+    // inside a capture of its own: the record fails, and the error is dropped)
     if (hipEventRecord(ctx->order_event, ctx->last_stream) == hipSuccess)
       OXC_HIP(ctx, hipStreamWaitEvent(s, ctx->order_event, 0));
     else
@@ -849,14 +855,9 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   if (do_meshlets) {
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
-      // OXC_TEST_GRID (experiment knob): blocks per batch element for the meshlet test kernel
-      static const uint32_t grid_env = [] {
-        const char* e = std::getenv("OXC_TEST_GRID");
-        return e ? (uint32_t)std::atoi(e) : 0u;
-      }();
       // At 64 VGPRs (8 waves/SIMD) the test kernel wants every block it can get: with 16 x 1M meshlets, blocks per element
       // 384 -> 74.6 us, 512 -> 73.7, 768 -> 73.2, 1024 -> 70.7, 2048 -> 70.0 (>= 977 blocks: one 1024-meshlet step per block)
-      launch_meshlets_test_batch(ctx->batch_dev, count, grid_env ? std::min(g_test, grid_env) : g_test, s);
+      launch_meshlets_test_batch(ctx->batch_dev, count, g_test, s);
     }
     KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
     launch_meshlets_emit_batch(ctx->batch_dev, count, std::min(g_emit, cap), s);
@@ -1120,6 +1121,10 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   const oxc_image& h = c->hiz_attachment;
   if (needs_hiz && (!h.dptr || h.levels == 0 || h.levels > 13 || h.width == 0 || h.height == 0)) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: TestOcclusion / LatePass need hiz_attachment");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  if (total > 1024u) {  // the two-kernel form borrows the meshlet stage's ballot / count scratch (one ballot per 64, one count per 1024 patches)
+    oxc_status cst = ensure_capacity(ctx, 0, total, 0, 0, static_cast<hipStream_t>(hip_stream));
+    if (cst != OXC_OK) return cst;
+  }
   OXC_ORDER(ctx, hip_stream);
   uint32_t* slot = next_slot(ctx);
   TerrainArgs a;
@@ -1146,6 +1151,8 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   a.mask = static_cast<uint32_t*>(c->patch_visibility_mask_buffer.dptr);
   a.visible = static_cast<uint32_t*>(c->visible_patches_buffer.dptr);
   a.draw_cmd = slot + SLOT_DRAW_CMD;
+  a.emit_bits = ctx->lane[0].bits;
+  a.block_counts = ctx->lane[0].m_chunk_counts;
   c->cull_camera.mesh_instance_count = total;  // Terrain.cpp:171
   c->draw_cmd_buffer = {a.draw_cmd, 16};
   launch_cull_terrain(a, static_cast<hipStream_t>(hip_stream));
@@ -1153,8 +1160,8 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   return OXC_OK;
 }
 
-// Big triangles (and clipped triangle ids) queued per draw; beyond that the producing lane rasterises the triangle itself (slow,
-// correct) and clipped triangles are dropped.  240 MB of scratch, allocated by the first draw.  OXC_RASTER_BIG_CAPACITY (read by
+// Big triangles (and clipped triangle ids) queued per draw; beyond that the producing lane rasterises the triangle itself and an
+// overflow pass re-walks the index list for the crossing triangles the id queue could not hold (both slow, both correct).  240 MB of scratch, allocated by the first draw.  OXC_RASTER_BIG_CAPACITY (read by
 // that first draw) shrinks it so that the tests can reach the overflow paths with a small scene.
 constexpr uint32_t kRasterBigCapacity = 1u << 22;
 
@@ -1219,7 +1226,7 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   const uint32_t cap = ctx->raster_capacity;
   a.big_seg_capacity = cap / kBigSegs;
   a.big_list = reinterpret_cast<TriSetup*>(rs + kRasterHeaderBytes);
-  a.clip_capacity = cap;  // more clipped triangles than that in one draw: the excess is dropped
+  a.clip_capacity = cap;  // more clipped triangles than that in one draw: k_draw_clipped<RESCAN> finds them again
   a.clip_list = reinterpret_cast<uint32_t*>(rs + kRasterHeaderBytes + (size_t)cap * kTriSetupBytes);
   a.tile_capacity = cap * 2;
   a.tile_list = reinterpret_cast<uint2*>(rs + kRasterHeaderBytes + (size_t)cap * (kTriSetupBytes + 4));

@@ -449,11 +449,7 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         }
       }
       if (!found) break;
-#ifdef OXC_ABL_FIXEDROW  // timing experiment: the row address does not depend on the MeshletInstance load
-      const kconst32p row = const_row(a.cache, chunk & 255u);
-#else
       const kconst32p row = const_row(a.cache, mi_u);
-#endif
       const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
       uint4 bnd[G];
       bool mine[G];
@@ -488,9 +484,6 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         }
       }
       // ---- phase 2: normal cone, only when some frustum survivor of this instance needs it
-#ifdef OXC_ABL_NOCONE
-      any_need = 0;
-#endif
       if (any_need) {
         ConeU cu;
 #pragma unroll
@@ -506,16 +499,12 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         for (int j = 0; j < G; j++) {
           if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
           uint4 b = bnd[j];
-#ifndef OXC_PLAIN_KEEP_DECODED
           // Decode the centre / extent again instead of keeping 24 decoded floats of phase 1 alive across the phases (the
           // opaque asm stops the optimiser from recognising the repeat and keeping them anyway): ~9 more VALU per group for
           // ~24 fewer VGPRs at the pressure peak.
           asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
           const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
           const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-#else
-          const float qx = cx[j], qy = cy[j], qz = cz[j], rx = ex[j], ry = ey[j], rz = ez[j];
-#endif
           const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
           const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
           const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
@@ -691,9 +680,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
         }
       }
       // ---- phase 2: normal cone
-#ifdef OXC_ABL_NOCONE
-      any_need = 0;
-#endif
       if (any_need) {
         ConeU cu;
 #pragma unroll
@@ -740,11 +726,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
           vb[j] = __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
           base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)vb[j]);
         }
-#ifdef OXC_ABL_NOOCCL
-        const uint32_t total = 0;
-#else
         const uint32_t total = base[G];
-#endif
         if (total) {
           float mvp[16];
 #pragma unroll
@@ -784,9 +766,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       const bool visible = (st[j] & 2u) != 0u;
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
-#ifndef OXC_ABL_NOMASKUPDATE
       if (OCCL) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
-#endif
       const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
       const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
       if (lane == 0) gptr(a.bits)[group0 + j] = bits;
@@ -1604,12 +1584,7 @@ void launch_expand_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hi
   hipLaunchKernelGGL(k_expand_batch, dim3(grid, count), dim3(256), 0, s, dev);
 }
 void launch_meshlets_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
-  // OXC_LDS_PAD (bytes of unused dynamic LDS per block) throttles residency for occupancy experiments
-  static const uint32_t lds_pad = [] {
-    const char* e = std::getenv("OXC_LDS_PAD");
-    return e ? (uint32_t)std::atoi(e) : 0u;
-  }();
-  hipLaunchKernelGGL(k_cull_meshlets_test_batch, dim3(grid * (4 / kPlainBlockWaves), count), dim3(64 * kPlainBlockWaves), lds_pad, s, dev);
+  hipLaunchKernelGGL(k_cull_meshlets_test_batch, dim3(grid * (4 / kPlainBlockWaves), count), dim3(64 * kPlainBlockWaves), 0, s, dev);
 }
 void launch_meshlets_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_cull_meshlets_emit_batch, dim3(grid, count), dim3(256), 0, s, dev);

@@ -362,6 +362,9 @@ struct TerrainArgs {
   uint32_t* mask;
   uint32_t* visible;
   uint32_t* draw_cmd;
+  // scratch of the two-kernel form (more than 1024 patches): one emit ballot per wave, one count per 1024-patch block
+  uint64_t* emit_bits;
+  uint32_t* block_counts;
 };
 void launch_cull_terrain(const TerrainArgs& a, hipStream_t s);
 // oxcull_hpb.hip: hierarchical page buffer producer

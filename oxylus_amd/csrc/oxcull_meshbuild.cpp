@@ -440,16 +440,22 @@ oxc_status oxc_mesh_build_create(const oxc_mesh_build_desc* d, oxc_mesh_build** 
   oxc_mesh_build* b = new (std::nothrow) oxc_mesh_build();
   if (!b) return OXC_OUT_OF_MEMORY;
   try {
-    std::vector<uint32_t> last;
+    std::vector<uint32_t> last;  // the previous LOD's triangles without the degenerate ones (no area: neither clustered nor simplified)
+    size_t last_count = 0;       // the previous LOD's index count as the reference sees it (LOD 0: the verbatim input)
     float last_error = 0.f;
+    auto without_degenerates = [](const std::vector<uint32_t>& in) {
+      std::vector<uint32_t> o;
+      o.reserve(in.size());
+      for (size_t i = 0; i + 2 < in.size(); i += 3)
+        if (in[i] != in[i + 1] && in[i + 1] != in[i + 2] && in[i] != in[i + 2]) o.insert(o.end(), in.begin() + i, in.begin() + i + 3);
+      return o;
+    };
     for (uint32_t lod = 0; lod < max_lods; lod++) {  // AssetManager_GLTF.cpp:599-682
       Lod cur;
       if (lod == 0) {
-        for (uint32_t i = 0; i + 2 < d->index_count; i += 3)  // degenerate input triangles carry no area: dropped here as the simplifier drops them
-          if (d->indices[i] != d->indices[i + 1] && d->indices[i + 1] != d->indices[i + 2] && d->indices[i] != d->indices[i + 2])
-            cur.indices.insert(cur.indices.end(), d->indices + i, d->indices + i + 3);
+        cur.indices.assign(d->indices, d->indices + d->index_count);  // LOD 0 = the input indices, verbatim (:604-606)
       } else {
-        const size_t target = ((last.size() + 5) / 6) * 3;  // :609
+        const size_t target = ((last_count + 5) / 6) * 3;  // :609
         Simplifier s;
         s.pos = d->positions;
         s.nrm = d->normals;
@@ -461,9 +467,10 @@ oxc_status oxc_mesh_build_create(const oxc_mesh_build_desc* d, oxc_mesh_build** 
         if (cur.indices.size() > target + target / 2 || err > 0.5 || cur.indices.size() < 6) break;  // :639-645
       }
       if (cur.indices.size() < 3) break;
-      last = cur.indices;
+      last = without_degenerates(cur.indices);
+      last_count = cur.indices.size();
       last_error = cur.error;
-      build_meshlets(cur.indices, d->positions, d->vertex_count, max_v, max_t, cur);
+      build_meshlets(last, d->positions, d->vertex_count, max_v, max_t, cur);
       if (cur.meshlets.empty()) break;
       b->lods.push_back(std::move(cur));
     }

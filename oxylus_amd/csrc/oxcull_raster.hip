@@ -426,15 +426,22 @@ __global__ __launch_bounds__(256) void k_draw_setup(DrawArgs a) {
 // Sutherland-Hodgman against the five planes, fan triangulation, then the same setup as an unclipped triangle.  A new vertex on a
 // crossing edge is always interpolated from its inside end I to its outside end O -- t = d(I) / (d(I) - d(O)), v = I + t (O - I), IEEE
 // operations in that order -- so the two triangles that share the edge get the same vertex whatever their winding.
+// RESCAN: the overflow pass.  More triangles crossed a clip plane than the id queue holds (clip_capacity): the ids beyond it were
+// not recorded, so this instantiation walks the whole index list again and clips every crossing triangle it finds.  Drawing a
+// triangle twice leaves the image unchanged (per-pixel maximum), so no bookkeeping of which ones the queue did hold is needed.
+// It returns at once when the queue did not overflow.
+template <bool RESCAN>
 __global__ __launch_bounds__(64) void k_draw_clipped(DrawArgs a) {
   set_half_denorm_flush();
-  const uint32_t count = min(*a.clip_count, a.clip_capacity);
+  if (RESCAN && *a.clip_count <= a.clip_capacity) return;
+  const uint32_t count = RESCAN ? a.draw_cmd[0] / 3u : min(*a.clip_count, a.clip_capacity);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     float clip[3][4];
     uint32_t vis;
-    const uint32_t tri = a.clip_list[i];
+    const uint32_t tri = RESCAN ? i : a.clip_list[i];
     const uint32_t idx[3] = {a.indices[tri * 3u], a.indices[tri * 3u + 1u], a.indices[tri * 3u + 2u]};
     tri_clip_coords(a, idx, clip, vis);
+    if (RESCAN && tri_clip_class(clip) != 1) continue;
     float poly[2][9][4];
     int n = 3, cur = 0;
     for (int k = 0; k < 3; k++)
@@ -586,7 +593,8 @@ void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint
   (void)hipMemsetAsync(a.clip_count, 0, kRasterHeaderBytes, s);  // clip / tile counters and the big list's segment counters
   hipLaunchKernelGGL(k_draw_rows, dim3(std::max(1u, std::min((a.mesh_instance_count + 255u) / 256u, max_grid))), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_draw_setup, dim3(max_grid), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_draw_clipped, dim3(256), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_draw_clipped<false>, dim3(256), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_draw_clipped<true>, dim3(max_grid), dim3(64), 0, s, a);  // (returns at once unless the id queue overflowed)
   hipLaunchKernelGGL(k_draw_big, dim3(max_grid), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_draw_big_tiles, dim3(max_grid), dim3(256), 0, s, a);
   if (depth_out || vis_out)

@@ -21,6 +21,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a box without a GPU: every gpu-marked test skips (whether or not it goes through the `renderer` fixture)."""
+    if not any("gpu" in it.keywords for it in items):
+        return
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     import oracle

@@ -31,6 +31,7 @@ def _canon(tris):  # multiset of triangles, rotation-normalised (winding kept)
 
 def _border_edges(idx):
     t = idx.view(-1, 3).numpy()
+    t = t[(t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])]  # (LOD 0 keeps the input's degenerate triangles: no area, no edges)
     e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
     e.sort(axis=1)
     u, c = np.unique(e, axis=0, return_counts=True)
@@ -48,14 +49,14 @@ def test_every_lod_is_a_valid_clustering(liboxcull, kind, n):
         assert bool((m[:, 1] % 4 == 0).all()) and lod["micro"].numel() % 4 == 0            # 4-byte aligned micro-index runs
         assert m[:, 0].tolist() == (torch.cumsum(m[:, 2], 0) - m[:, 2]).tolist()            # vertex runs packed back to back
         assert int(m[-1, 0] + m[-1, 2]) == lod["vidx"].numel()
-        # every triangle of the LOD in exactly one meshlet, winding preserved; no vertex listed twice in a meshlet
-        assert _canon(_triangles_of(lod)) == _canon(lod["indices"].view(-1, 3).long())
+        # every triangle of the LOD (bar the degenerate ones: no area) in exactly one meshlet, winding preserved; no vertex listed twice in a meshlet
+        li = lod["indices"].view(-1, 3).long()
+        assert _canon(_triangles_of(lod)) == _canon(li[(li[:, 0] != li[:, 1]) & (li[:, 1] != li[:, 2]) & (li[:, 0] != li[:, 2])])
         for k in range(m.shape[0]):
             v = lod["vidx"][int(m[k, 0]):int(m[k, 0] + m[k, 2])]
             assert v.unique().numel() == v.numel()
-    # LOD 0 = the input minus degenerate triangles
-    src = tris[(tris[:, 0] != tris[:, 1]) & (tris[:, 1] != tris[:, 2]) & (tris[:, 0] != tris[:, 2])]
-    assert _canon(lods[0]["indices"].view(-1, 3).long()) == _canon(src)
+    # LOD 0 = the input indices, verbatim (AssetManager_GLTF.cpp:604-606)
+    assert torch.equal(lods[0]["indices"].view(-1, 3).long(), tris.long())
 
 
 def test_lod_chain_follows_the_reference_loop_rules(liboxcull):

@@ -284,6 +284,30 @@ def test_gpu_draw_when_the_big_list_overflows(oracle_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_draw_when_the_clip_queue_overflows(oracle_lib, monkeypatch):
+    """The id queue of the triangles that cross a clip plane holds 4096 entries here; the camera sits inside a scene in which more
+    than that cross: the overflow pass walks the index list again and clips what the queue could not record -- same image."""
+    import oracle
+    from oxylus_amd.renderer import RendererInstance
+
+    monkeypatch.setenv("OXC_RASTER_BIG_CAPACITY", "4096")
+    r = RendererInstance(0)
+    try:
+        cpu = make_scene(SceneSpec(n_mesh_instances=160, meshlets_per_mesh=40, seed=19, scene_depth=0.5), "cpu")
+        cam = cpu.cull_camera()
+        pv = [cam.projection_view[i] for i in range(16)]
+        tris = cpu.meshlets[cpu.meshlet_instances[:, 1].long(), 3].tolist()
+        idx = torch.tensor([(i << 8) | c for i, t in enumerate(tris) for c in range(3 * t)], dtype=torch.int32)
+        got, vd = _draw_list_both(r, cpu, idx, pv, 480, 270)
+        assert oracle.draw_clipped_count() > 4096, oracle.draw_clipped_count()
+        st = r.debug_raster_stats()
+        assert st["clipped"] > 4096, st
+        assert torch.equal(got, vd) and (vd != 0).any()
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 def test_gpu_clipped_triangles_match_oracle(renderer, oracle_lib):
     """The hand-made clip cases of the CPU tests (one / two corners behind the camera, guard band, w = 0) drawn by the device."""
     import oracle

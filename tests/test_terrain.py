@@ -61,7 +61,8 @@ def test_oracle_frustum_only_keeps_the_patches_in_front(oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pcx,pcy,flags", [(64, 64, L.CULL_TEST_FRUSTUM), (64, 64, L.CULL_TEST_FRUSTUM | L.CULL_TEST_OCCLUSION),
-                                           (37, 29, L.CULL_TEST_FRUSTUM | L.CULL_TEST_OCCLUSION), (1, 1, L.CULL_TEST_ALL), (130, 9, L.CULL_TEST_ALL)])
+                                           (37, 29, L.CULL_TEST_FRUSTUM | L.CULL_TEST_OCCLUSION), (1, 1, L.CULL_TEST_ALL), (130, 9, L.CULL_TEST_ALL),
+                                           (32, 32, L.CULL_TEST_ALL), (333, 257, L.CULL_TEST_ALL)])  # 32 x 32: exactly one block (appends in the test kernel); 333 x 257: 84 blocks
 def test_gpu_terrain_cull_early_then_late(renderer, oracle_lib, pcx, pcy, flags):
     import oracle
     from oxylus_amd.renderer import ImageAttachment

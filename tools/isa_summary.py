@@ -72,6 +72,11 @@ def summarize(src):
 
 
 def main():
+    import argparse
+
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("out", nargs="?", default="", help="write the summary as JSON to this path (default: print only)")
+    args = ap.parse_args()
     out = {"note": "hipcc --offload-arch=gfx950 %s --cuda-device-only -S; code-object metadata + static instruction counts "
                    "(both branches of every conditional are counted: NOT a dynamic mix)" % " ".join(f for f in FLAGS if not f.startswith("-I")),
            "files": {}}
@@ -79,8 +84,8 @@ def main():
         if f.endswith(".hip"):
             out["files"][f] = summarize(os.path.join(CSRC, f))
     text = json.dumps(out, indent=1, sort_keys=True)
-    if len(sys.argv) > 1:
-        open(sys.argv[1], "w").write(text + "\n")
+    if args.out:
+        open(args.out, "w").write(text + "\n")
     for f, ks in out["files"].items():
         for k, v in ks.items():
             print("%-22s %-70s vgpr %3d  sgpr %3d  spills %2d/%d  lds %6d  waves/SIMD %d" % (f, k[:70], v["vgprs"], v["sgprs"], v["sgpr_spills"], v["vgpr_spills"],
