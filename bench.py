@@ -65,6 +65,12 @@ def parse():
     ap.add_argument("--streams", type=int, default=3, help="config2: independent batches in flight (contexts on their own HIP streams)")
     ap.add_argument("--batch", type=int, default=16, help="config2 / config5: frames (views) per oxc_cull_geometry_batch call (max 16)")
     ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement")
+    ap.add_argument("--no-configs4", action="store_true", help="config3: skip the nested configs[4] measurement (10M meshlets x 16 views)")
+    ap.add_argument("--no-real-geometry", action="store_true", help="config3: skip the nested run of the same frame over instanced real meshes (clusteriser-built)")
+    ap.add_argument("--async-triangles", action="store_true",
+                    help="config3: time the main line with async_triangles = 1 (triangle stages on the context's own stream, frames pipeline); the default line is in "
+                         "order on one stream and carries the pipelined figure as the nested object \"async_triangles\"")
+    ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the short timed run with the other --hiz-exchange form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: build + broadcast the pyramid on the cull stream instead of one frame ahead on a second stream")
     ap.add_argument("--hiz-exchange", default="top", choices=["whole", "top"],
@@ -147,12 +153,22 @@ def barrier(e):
         e.dist.barrier()
 
 
+PER_RANK_SECONDS = []  # of the last timed_steps(): every rank's own wall time (rank order)
+
+
 def max_over_ranks(e, seconds: float) -> float:
+    PER_RANK_SECONDS[:] = [seconds]
     if e.dist is None:
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=e.dev)
-    e.dist.all_reduce(t, op=e.dist.ReduceOp.MAX)
-    return float(t.item())
+    if e.debug_backend:
+        allt = [torch.zeros(1, dtype=torch.float64) for _ in range(e.world)]
+        e.dist.all_gather(allt, t.cpu())
+    else:
+        allt = [torch.zeros(1, dtype=torch.float64, device=e.dev) for _ in range(e.world)]
+        e.dist.all_gather(allt, t)
+    PER_RANK_SECONDS[:] = [float(x.item()) for x in allt]
+    return max(PER_RANK_SECONDS)
 
 
 def usable_cores() -> int:
@@ -320,7 +336,7 @@ def bench_config3(args, e):
         c2.hiz_attachment = hz.c()
         cctx.append(c2)
     mgs, mgs_low = [], []
-    top = world > 1 and args.hiz_exchange == "top"
+    xmode = {"top": world > 1 and args.hiz_exchange == "top"}  # (mutable: the A/B run at the end times the other form)
     k_top = max(1, min(args.hiz_top_level, hiz[0].levels - 1))
     for hz in hiz:
         mg = L.MainGeometryContext()
@@ -333,7 +349,8 @@ def bench_config3(args, e):
         lo.hiz_attachment.levels = k_top
         mgs_low.append(lo)
     hiz_bytes = hiz[0].data.numel() * 4
-    hiz_wire_bytes = hiz_bytes - (hiz[0].level_offset[k_top] if top else 0)
+    wire_bytes = lambda top_: hiz_bytes - (hiz[0].level_offset[k_top] if top_ else 0)  # noqa: E731
+    hiz_wire_bytes = wire_bytes(xmode["top"])
 
     # ---- multi-GPU plumbing: second context + stream for the pyramid producer, events, counter all-gather ----
     overlap = world > 1 and not args.no_overlap
@@ -354,6 +371,7 @@ def bench_config3(args, e):
 
     def produce_hiz(b):
         """Rank 0 builds pyramid buffer b from the depth image; everybody receives it (RCCL broadcast over xGMI)."""
+        top = xmode["top"]
         if rank == 0 or top:  # 'top': the other ranks build levels < k_top from their own copy of the depth image
             st = r_hiz._lib.oxc_generate_hiz(r_hiz._ctx, C.byref(mgs[b] if rank == 0 else mgs_low[b]), csp)
             if st != L.OXC_OK:
@@ -380,6 +398,7 @@ def bench_config3(args, e):
             dist.all_gather_into_tensor(gathered, my_counts)
 
     frame_no = [0]
+    use_async = [bool(args.async_triangles)]  # async_triangles (include/oxcull.h): triangle stages on the context's own stream, frames pipeline
 
     def run_frame(record=None):
         f = frame_no[0]
@@ -400,6 +419,7 @@ def bench_config3(args, e):
         else:
             produce_hiz(b)  # (comm_stream is the cull stream here)
         c = cctx[b]
+        c.async_triangles = int(use_async[0])
         c.cull_flags = L.CULL_TEST_ALL
         check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
         if record is not None:
@@ -447,11 +467,51 @@ def bench_config3(args, e):
     v_early, v_late = counts["early"], counts["late"]
     t_early, t_late = counts["early_index_count"] // 3, counts["late_index_count"] // 3
 
+    def outputs_checksum():
+        """Every output of the last frame folded into a few integers (device-side sums): what a scheduling variant must reproduce."""
+        torch.cuda.synchronize()
+        out = L.Counters()
+        check(lib.oxc_read_counters(ctxp, C.byref(cctx[(frame_no[0] - 1) % len(hiz)]), C.byref(out), sp))
+        nv = out.early_visible_meshlet_instances + out.late_visible_meshlet_instances
+        vis = frame.visible_meshlet_instances_indices_buffer[:nv].to(torch.int64)
+        idx = frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64) & 0xFFFFFFFF
+        wv = torch.arange(1, 1 + vis.numel(), device=dev, dtype=torch.int64) % 1000003
+        wi = torch.arange(1, 1 + idx.numel(), device=dev, dtype=torch.int64) % 1000003
+        return (out.early_visible_meshlet_instances, out.late_visible_meshlet_instances, out.draw_index_count, int((vis * wv).sum().item()),
+                int((idx * wi).sum().item()), int(mask.to(torch.int64).sum().item()))
+
     ramp_clocks(e)
     elapsed = timed_steps(e, run_step, args.steps, args.warmup)
+    per_rank_ms_per_frame = [round(t * 1e3 / (args.steps * inner), 6) for t in PER_RANK_SECONDS]
     frames = args.steps * inner
     ms_per_frame = elapsed * 1e3 / frames
     value = n_meshlets * world * frames / elapsed
+    sum_main = outputs_checksum()
+
+    # ---- the same frames with the other scheduling (async_triangles on <-> off), a short run: what overlapping the HBM-bound triangle
+    # stage with the next call's ALU-bound meshlet stage / the next frame's HiZ build is worth on this box ----
+    use_async[0] = not use_async[0]
+    ab_steps = max(2, args.steps // 4)
+    el_ab = timed_steps(e, run_step, ab_steps, 1)
+    sum_ab = outputs_checksum()
+    use_async[0] = not use_async[0]
+    sched_ab = {"async_triangles": not use_async[0], "ms_per_frame": round(el_ab * 1e3 / (ab_steps * inner), 6), "value": round(n_meshlets * world * ab_steps * inner / el_ab, 1),
+                "frames_timed": ab_steps * inner, "outputs_match_main_line": sum_ab == sum_main,
+                "note": "triangle stages on the context's own stream (hipStreamWaitEvent fork / join inside liboxcull), meshlet test grids cut to "
+                        "leave wave slots: frames pipeline without a host synchronisation; all outputs folded into checksums and compared with the in-order run"}
+
+    # ---- N > 1: the other --hiz-exchange form, a short run, so that one multi-GPU run decides between them ----
+    exchange_ab = None
+    if world > 1 and not args.no_exchange_ab:
+        exchange_ab = {("top" if xmode["top"] else "whole"): {"ms_per_frame": round(ms_per_frame, 6), "broadcast_bytes_per_frame": wire_bytes(xmode["top"])}}
+        xmode["top"] = not xmode["top"]
+        el_x = timed_steps(e, run_step, ab_steps, 1)
+        exchange_ab["top" if xmode["top"] else "whole"] = {"ms_per_frame": round(el_x * 1e3 / (ab_steps * inner), 6), "broadcast_bytes_per_frame": wire_bytes(xmode["top"]),
+                                                            "frames_timed": ab_steps * inner}
+        xmode["top"] = not xmode["top"]
+        with torch.cuda.stream(stream):
+            run_frame()  # (leaves the pyramids in the main mode's state for the kernel profile below)
+        torch.cuda.synchronize()
 
     # ---- per-kernel times (>= 50 launches each) and rooflines: algorithmic bytes of SURVEY 8d ----
     n_prof = max(50, min(inner, 96))
@@ -561,17 +621,65 @@ def bench_config3(args, e):
                         "late_triangles_tested": int(want["late"][0].numel()) * min(args.tris, 64), "late_triangles_ill_conditioned": int(flags.sum()),
                         "note": "canonical checker vs its fast-math-envelope build (oracle/Makefile); tools/unpinned_gap.py, profiles/r02_unpinned_gap.json"}
         if world == 1 and not args.no_cpu_baseline:
-            reps = int(max(1, min(args.cpu_seconds / max(t_seq, 1e-3), 200)))
+            reps = int(max(1, min(args.cpu_seconds / 2 / max(t_seq, 1e-3), 200)))
             t_c0 = time.perf_counter()
             for _ in range(reps):
                 cpu_sequence()
             dt = (time.perf_counter() - t_c0) / reps
             share = t_hiz_cpu * (m0 * K) / n_meshlets  # the pyramid build serves all N meshlets: its share for the sample
-            cpu_baseline = {"value": round(m0 * K / (dt + share), 1), "unit": "meshlets/s", "cores": 1, "kind": "port",
-                            "sample": f"{reps} runs of the same sequence (cull_meshlets_hiz early + cull_triangles, late + cull_triangles; oracle/oxcull_oracle.c, scalar, "
-                                      f"one thread) over the first {m0 * K} meshlet instances of the same arrays ({dt:.2f} s per run) + that sample's share of the "
-                                      f"scalar 4096^2 pyramid build ({t_hiz_cpu:.2f} s for the whole image)",
-                            "hiz_build_s": round(t_hiz_cpu, 3), "sequence_s_per_run": round(dt, 3)}
+            single = m0 * K / (dt + share)
+
+            # All host cores: the instance range split into word-aligned pieces (4 instances x 1000 meshlets = 125 mask words, so no two
+            # threads share a mask word), each thread runs both passes + both triangle passes over its piece with private output buffers,
+            # then the pieces are concatenated in order (ids and packed indices rebased) -- and must equal the one-thread result.
+            import threading
+
+            cores = usable_cores()
+            piece = -(-(-(-m0 // cores)) // 4) * 4  # ceil(m0 / cores) rounded up to a multiple of 4 instances
+            cuts = list(range(0, m0, piece)) + [m0]
+            ranges = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+            shift = 9 if wide else 8
+
+            def cpu_piece(a, b, mk, box, slot):
+                mli = sub.meshlet_instances[a * K:b * K]
+                v = oracle.Visibility((b - a) * K, 0, 0)
+                out = torch.zeros((b - a) * K, dtype=torch.int32)
+                res = {}
+                for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+                    n_e = oracle.cull_meshlets_hiz(sub, cam, mli, flags, hz, v, mk, out)
+                    first = v.early if tag == "late" else 0
+                    res[tag] = (out[first:first + n_e].clone(),
+                                oracle.cull_triangles(sub, cam, mli, out, first, n_e, wide=wide, small_triangle_cull=args.small_triangle_cull))
+                box[slot] = res
+
+            def cpu_sequence_mt():
+                mk = mask_cpu0.clone()
+                box = [None] * len(ranges)
+                th = [threading.Thread(target=cpu_piece, args=(a, b, mk, box, i)) for i, (a, b) in enumerate(ranges)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                res = {}
+                for tag in ("early", "late"):
+                    res[tag] = (torch.cat([box[i][tag][0] + a * K for i, (a, b) in enumerate(ranges)]),
+                                torch.cat([box[i][tag][1] + ((a * K) << shift) for i, (a, b) in enumerate(ranges)]))
+                return res, mk
+
+            got_mt, mask_mt = cpu_sequence_mt()
+            mt_ok = bool(all(torch.equal(got_mt[t][0], want[t][0]) and torch.equal(got_mt[t][1], want[t][1]) for t in ("early", "late")) and torch.equal(mask_mt, mask_want))
+            reps_mt = int(max(2, min(args.cpu_seconds / 2 / max(t_seq / max(1, min(cores, len(ranges))), 1e-3), 400)))
+            t_c0 = time.perf_counter()
+            for _ in range(reps_mt):
+                cpu_sequence_mt()
+            dt_mt = (time.perf_counter() - t_c0) / reps_mt
+            cpu_baseline = {"value": round(m0 * K / (dt_mt + share), 1), "unit": "meshlets/s", "cores": min(cores, len(ranges)), "host_cores_usable": cores, "kind": "port",
+                            "sample": f"{reps_mt} runs of the same sequence (cull_meshlets_hiz early + cull_triangles, late + cull_triangles; oracle/oxcull_oracle.c, scalar C) over the "
+                                      f"first {m0 * K} meshlet instances of the same arrays, the instance range split over {len(ranges)} threads in word-aligned pieces with private "
+                                      f"outputs concatenated in order ({dt_mt:.3f} s per run; equals the one-thread result: {mt_ok}) + that sample's share of the scalar, "
+                                      f"one-thread 4096^2 pyramid build ({t_hiz_cpu:.2f} s for the whole image)",
+                            "matches_single_thread": mt_ok, "single_thread_value": round(single, 1), "single_thread_sequence_s_per_run": round(dt, 3),
+                            "hiz_build_s": round(t_hiz_cpu, 3), "sequence_s_per_run": round(dt_mt, 4)}
 
     line = {
         "metric": "meshlets/s culled", "value": round(value, 1), "unit": "meshlets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -585,12 +693,14 @@ def bench_config3(args, e):
             "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
             "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
             "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
-                                                         "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if top else "whole pyramid broadcast from rank 0"),
+                                                         "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if xmode["top"] else "whole pyramid broadcast from rank 0"),
                                                          "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": overlap,
-                                                         "counters_all_gather_bytes_per_rank": 16},
+                                                         "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame, "hiz_exchange_ab": exchange_ab},
+            "async_triangles": bool(use_async[0]),
         },
         "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
         "unpinned_gap": unpinned, "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "scheduling_ab": sched_ab,
     }
     # free the 25 GB of this workload before the nested one
     del scene, frame, depth, hiz, mask0
@@ -849,6 +959,16 @@ def main():
         line = bench_config3(args, e)
         if e.world == 1 and not args.no_configs1:
             line["configs1"] = bench_config2(args, e, steps=8, warmup=1, with_cpu=not args.no_cpu_baseline)
+        if e.world == 1 and not args.no_configs4:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_aux
+
+            line["configs4"] = bench_aux.bench_config5(args, e.r, e.dev, e.stream, e.rank, e.world, e.dist, nested=True)
+        if e.world == 1 and not args.no_real_geometry:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_aux
+
+            line["real_geometry"] = bench_aux.bench_real_geometry(args, e.r, e.dev, e.stream, e.rank)
         if e.rank == 0:
             print(json.dumps(line))
     if e.dist is not None:

@@ -83,3 +83,53 @@ def make_scene_from_lods(n_mesh_instances: int, lods: List[dict], bounds_per_lod
     s.lod_meshlet_counts = counts.tolist()
     s.spec = SceneSpec(**{**spec.__dict__, "with_geometry": True, "tris_per_meshlet": int(s.meshlets[:, 3].max().item()), "verts_per_meshlet": int(s.meshlets[:, 2].max().item())})
     return s.bind()
+
+
+def make_scene_from_meshes(n_mesh_instances: int, meshes: List[dict], seed: int = 0x0A1DE5, device="cpu", **spec_kw):
+    """A scene of randomly placed instances of SEVERAL built meshes (round robin), each with its own LOD chain.  `meshes`: one dict per
+    mesh {"lods": build_mesh_lods(...), "bounds": [GPU::MeshletBounds tensor per LOD], "positions": u16x4 tensor, "mesh_bounds": 6 floats}.
+    Arrays are mesh-major, then LOD-major (as one blob per mesh would hold them); meshes with a shorter chain leave their last
+    GPU::MeshLOD rows empty (Mesh::lod_count says how many are valid).  meshlet_instances = the LOD-0 expansion of every instance,
+    meshlet_instance_visibility_offset = running sum of the LOD-0 meshlet counts (Scene.cpp:1248-1260)."""
+    from .synth import SceneSpec, make_scene
+
+    n_meshes = len(meshes)
+    Lmax = max(len(m["lods"]) for m in meshes)
+    spec = SceneSpec(n_mesh_instances=n_mesh_instances, meshlets_per_mesh=1, share_meshes=n_meshes, lod_count=Lmax, with_geometry=False, seed=seed, **spec_kw)
+    s = make_scene(spec, device)
+    dev = s.device
+    empty = {"meshlets": torch.zeros((0, 4), dtype=torch.int32), "vidx": torch.zeros(0, dtype=torch.int32), "micro": torch.zeros(0, dtype=torch.uint8),
+             "indices": torch.zeros(0, dtype=torch.int32), "error": 0.0}
+    rows = [(m["lods"][i] if i < len(m["lods"]) else empty, m["bounds"][i] if i < len(m["lods"]) else torch.zeros((0, 8), dtype=torch.int16))
+            for m in meshes for i in range(Lmax)]
+    s.meshlets = torch.cat([r[0]["meshlets"] for r in rows]).to(dev).contiguous()
+    s.vidx = torch.cat([r[0]["vidx"] for r in rows]).to(dev).contiguous()
+    s.micro = torch.cat([r[0]["micro"] for r in rows] + [torch.zeros(4, dtype=torch.uint8)]).to(dev).contiguous()
+    s.bounds = torch.cat([r[1].cpu() for r in rows]).to(dev).contiguous()
+    s.positions = torch.cat([m["positions"].cpu() for m in meshes]).to(dev).contiguous()
+    sizes = lambda key: torch.tensor([int(r[0][key].shape[0]) for r in rows], dtype=torch.int64)  # noqa: E731
+    start = lambda t: torch.cumsum(t, 0) - t  # noqa: E731
+    counts = sizes("meshlets")
+    nverts = torch.tensor([int(m["positions"].shape[0]) for m in meshes], dtype=torch.int64)
+    s._lod_tables = {"meshlet_start": start(counts), "vidx_start": start(sizes("vidx")), "micro_start": start(sizes("micro")), "mesh_vertex_start": start(nverts)}
+    l32 = s.lods.view(torch.int32)
+    l32[:, 10] = sizes("indices").to(torch.int32)
+    l32[:, 11] = counts.to(torch.int32)
+    l32[:, 12] = counts.to(torch.int32)
+    l32[:, 13] = sizes("micro").to(torch.int32)
+    l32[:, 14] = sizes("vidx").to(torch.int32)
+    l32[:, 15] = torch.tensor([r[0]["error"] for r in rows], dtype=torch.float32).view(torch.int32)
+    m32 = s.meshes.view(torch.int32)
+    m32[:, 6] = nverts.to(torch.int32)
+    m32[:, 7] = torch.tensor([len(m["lods"]) for m in meshes], dtype=torch.int32)
+    m32[:, 10:16] = torch.stack([m["mesh_bounds"].cpu().to(torch.float32).view(torch.int32) for m in meshes]).to(dev)
+    k0 = counts.view(n_meshes, Lmax)[:, 0]  # LOD-0 meshlets per mesh
+    per_inst = k0.to(dev)[s.mesh_instances[:, 0].to(torch.int64)]
+    offs = torch.cumsum(per_inst, 0) - per_inst
+    s.mesh_instances[:, 4] = offs.to(torch.int32)
+    owner = torch.repeat_interleave(torch.arange(n_mesh_instances, device=dev, dtype=torch.int64), per_inst)
+    k = torch.arange(int(per_inst.sum().item()), device=dev, dtype=torch.int64) - offs[owner]
+    s.meshlet_instances = torch.stack([owner.to(torch.int32), k.to(torch.int32)], 1).contiguous()
+    s.lod_meshlet_counts = None
+    s.spec = SceneSpec(**{**spec.__dict__, "with_geometry": True, "tris_per_meshlet": int(s.meshlets[:, 3].max().item()), "verts_per_meshlet": int(s.meshlets[:, 2].max().item())})
+    return s.bind()

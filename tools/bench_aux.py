@@ -256,22 +256,25 @@ def bench_vsm(args, r, dev, stream, rank, world, dist):
 
 
 
-def bench_config5(args, r, dev, stream, rank, world, dist):
+def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
     """--workload config5 = BASELINE configs[4]: 10M meshlets x `--views` orthographic cascade views (Shadowmaps.cpp:9-63
     generalised: doubling extents around the camera), per-view cull_meshes (frustum + LOD select, cull_meshes.slang:35-57) +
     cull_meshlets, up to 16 views per oxc_cull_geometry_batch call.  `value` counts the meshlets the meshlet stage actually
-    PROCESSED (per view: the list cull_meshes produced), not candidates x views."""
+    PROCESSED (per view: the list cull_meshes produced), not candidates x views.  nested=True: return the result (bench.py hangs
+    it into the driver's default line as "configs4") instead of printing it."""
     import dataclasses
+    import os
 
     from oxylus_amd.synth import virtual_shadow_matrices
 
-    n_meshlets = args.meshlets or 10_000_000
+    n_meshlets = (args.meshlets if not nested else 0) or 10_000_000
     K = 1000
     M = max(1, n_meshlets // K)
     n_meshlets = M * K
     views, vb = args.views, max(1, min(16, args.batch))
-    steps, warmup = min(args.steps, 200), min(max(args.warmup, 2), 10)
+    steps, warmup = (min(args.steps, 200), min(max(args.warmup, 2), 10)) if not nested else (40, 3)
     lib, ctxp, sp = r._lib, r._ctx, C.c_void_p(stream.cuda_stream)
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
     with torch.cuda.stream(stream):
         base = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=False, lod_count=3, seed=0x0A1DE5 + 4 + rank), dev)
         r.reserve(M, n_meshlets)
@@ -280,19 +283,22 @@ def bench_config5(args, r, dev, stream, rank, world, dist):
         for e in range(min(vb, views)):
             sc = base if e == 0 else dataclasses.replace(base, mesh_instances=base.mesh_instances.clone())
             lanes.append(PreparedFrame.create(sc, with_triangles=False, expand=False))
+
+    def camera_of(scene, v):
+        cam = scene.cull_camera()
+        for k in range(16):
+            cam.projection_view[k] = float(mats[v][k])
+        cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
+        cam.near_clip = zn
+        return cam
+
     groups = []
     for v0 in range(0, views, vb):
         n = min(vb, views - v0)
         cf = (L.PreparedFrame * n)(*[lanes[e].c() for e in range(n)])
         cc = (L.CullGeometryContext * n)()
         for e in range(n):
-            cam = base.cull_camera()
-            for k in range(16):
-                cam.projection_view[k] = float(mats[v0 + e][k])
-            cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
-            cam.near_clip = zn
-            ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD, cull_camera=cam,
-                                      stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+            ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=camera_of(base, v0 + e), stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
             C.memmove(C.byref(cc[e]), C.byref(ctx.c()), C.sizeof(L.CullGeometryContext))
         groups.append((n, cf, cc))
 
@@ -308,12 +314,14 @@ def bench_config5(args, r, dev, stream, rank, world, dist):
         for _ in range(warmup):
             one()
     torch.cuda.synchronize()
-    per_view = []
-    for n, cf, cc in groups:  # the last step's counters are still in the slots of each element
+    per_view, got_lists = [], []
+    for gi, (n, cf, cc) in enumerate(groups):  # the last step's counters are still in the slots of each element
         for e in range(n):
             out = L.Counters()
             check(lib.oxc_read_counters(ctxp, C.byref(cc[e]), C.byref(out), sp))
             per_view.append((out.total_visible_meshlet_instances, out.cull_triangles_cmd_x))
+            if gi == len(groups) - 1 or len(groups) == 1:  # lists of the views whose lanes were not overwritten by a later group
+                got_lists.append((gi * vb + e, lanes[e].visible_meshlet_instances_indices_buffer[:out.cull_triangles_cmd_x].cpu()))
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -329,15 +337,254 @@ def bench_config5(args, r, dev, stream, rank, world, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     processed = sum(t for t, _ in per_view)
+    visible = sum(v for _, v in per_view)
+
+    # ---- per-kernel times (HIP-event pair per launch) and rooflines: SURVEY 8d per meshlet-view, the per-view list included ----
+    n_prof = 30
+    r.profile_begin()
+    with torch.cuda.stream(stream):
+        for _ in range(n_prof):
+            one()
+    prof = r.profile_end()
+    launches_per_step = len(groups)
+    alg = {  # per step (all views), bytes
+        # cull_meshes: 212 B of tables per mesh instance and view read, one 384 B row + count written
+        "prepare_instances": views * M * (212 + 384 + 4),
+        "meshes_scan": views * M * 8,
+        # the per-view MeshletInstance list is an OUTPUT of cull_meshes (8 B per processed meshlet-view written) ...
+        "meshes_expand": processed * 8.0,
+        # ... and the meshlet test reads it back with the 16 B bounds record: the reference's 24.2 B per meshlet
+        "cull_meshlets_test": processed * (24.0 + 212.0 / K),
+        "cull_meshlets_emit": processed / 8.0 + 4.0 * visible,
+    }
+    kernels, step_alg, step_kernel_us = {}, 0.0, 0.0
+    for name, k in prof["kernels"].items():
+        per_step_us = k["total_ms"] / n_prof * 1e3
+        ent = {"launches_per_step": round(k["launches"] / n_prof, 2), "us_per_step": round(per_step_us, 2)}
+        b = alg.get(name)
+        if b is not None:
+            ent["algorithmic_bytes_per_step"] = round(b)
+            ent["achieved_GBps"] = round(b / (per_step_us * 1e-6) / 1e9, 1)
+            ent["frac"] = round(b / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+            step_alg += b
+        step_kernel_us += per_step_us
+        kernels[name] = ent
+    kernels["_empty_event_pair_us"] = round(prof["empty_pair_ms"] * 1e3, 3)
+    roofline = None
+    if "cull_meshlets_test" in kernels:
+        kt = kernels["cull_meshlets_test"]
+        roofline = {"bound": "hbm", "kernel": "meshlet test of all views (launches of one step summed)", "achieved": kt["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": kt["frac"], "traffic": None, "algorithmic_bytes_per_step": kt["algorithmic_bytes_per_step"], "kernel_us_per_step": kt["us_per_step"],
+                    "note": "24.2 B per processed meshlet-view (8 B list record + 16 B bounds + 212 / K B of per-instance tables, SURVEY 8d a9); HIP-event time"}
+    ms_per_step = dt / steps * 1e3
+    stage = {"algorithmic_bytes_per_step": round(step_alg), "ms_per_step": round(ms_per_step, 6), "achieved_GBps": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1),
+             "stage_frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "sum_of_kernel_us_per_step": round(step_kernel_us, 1)}
+
+    # ---- the checker over the same arrays: parity of the lists still in the lanes + cpu_baseline (all host cores, per view) ----
+    bit_match, cpu_baseline = None, None
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+
+        oracle.build()
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cpu = base.to("cpu")
+        want, t_views = {}, 0.0
+        for v in range(views):
+            s = cpu.clone()  # cull_meshes writes lod_index
+            cam = camera_of(s, v)
+            t1 = time.perf_counter()
+            mli, _ = oracle.cull_meshes(s, cam, flags)
+            vis = oracle.cull_meshlets(s, cam, mli, nthreads=cores)
+            t_views += time.perf_counter() - t1
+            want[v] = (mli.shape[0], vis)
+        bit_match = bool(all(want[v][0] == per_view[v][0] and want[v][1].numel() == per_view[v][1] for v in range(views)) and
+                         all(torch.equal(want[v][1], lst) for v, lst in got_lists))
+        cpu_baseline = {"value": round(processed / t_views, 1), "unit": "meshlets/s", "cores": cores, "kind": "port",
+                        "sample": f"one pass over all {views} views of the same arrays: oracle cull_meshes (one thread) + cull_meshlets (static range split over {cores} "
+                                  f"pthreads) per view, {t_views:.2f} s for {processed} processed meshlet-views"}
+    res = {
+        "metric": "meshlets/s culled (meshlets the meshlet stage processed, summed over views)", "value": round(processed * world * steps / dt, 1),
+        "unit": "meshlets/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[4]: {n_meshlets} LOD-0 meshlets x {views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets",
+                   "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "views": views, "views_per_call": vb, "calls_per_step": launches_per_step,
+                   "candidate_meshlet_views_per_step": n_meshlets * views, "processed_meshlet_views_per_step": processed,
+                   "per_view_processed": [t for t, _ in per_view], "per_view_visible": [v for _, v in per_view]},
+        "bit_match": bit_match, "bit_match_sample": f"per-view list lengths and visible counts of all {views} views; the visible lists of views {[v for v, _ in got_lists][:1]}..{[v for v, _ in got_lists][-1:]} byte for byte",
+        "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
+    if nested:
+        del base, lanes
+        torch.cuda.empty_cache()
+        return res
     if rank == 0:
-        print(json.dumps({
-            "metric": "meshlets/s culled (meshlets the meshlet stage processed, summed over views)", "value": round(processed * world * steps / dt, 1),
-            "unit": "meshlets/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[4]: {n_meshlets} LOD-0 meshlets x {views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets",
-                       "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "views": views, "views_per_call": vb,
-                       "candidate_meshlet_views_per_step": n_meshlets * views, "processed_meshlet_views_per_step": processed,
-                       "per_view_processed": [t for t, _ in per_view], "per_view_visible": [v for _, v in per_view]},
-            "roofline": None, "cpu_baseline": None}))
+        print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_real_geometry(args, r, dev, stream, rank=0):
+    """The configs[2] frame (HiZ build -> early cull -> late cull, all stages) over ~10M meshlet instances of REAL meshes: a UV sphere, a
+    height field and a triangle soup run through the repo's own asset path -- oxc_mesh_build_* (host clusteriser + LOD chain,
+    AssetManager_GLTF.cpp:599-682) and oxc_build_meshlet_bounds (GPU, :683-744) -- and instanced round robin.  Geometry is shared between
+    the instances of a mesh (the engine's case), so the triangle stage reads it out of the caches: a different regime from the
+    unique-geometry scene of the main line, reported next to it with its own visible fraction, triangles per meshlet and unpinned gap.
+    Returns the nested object bench.py hangs into the default line as "real_geometry"."""
+    import numpy as np
+
+    from oxylus_amd.mesh_build import build_mesh_lods, make_scene_from_meshes
+    from oxylus_amd.synth import make_depth, make_mesh
+
+    lib, ctxp, sp = r._lib, r._ctx, C.c_void_p(stream.cuda_stream)
+    HW = 4096
+
+    def check(st):
+        if st != L.OXC_OK:
+            raise RuntimeError(lib.oxc_last_error(ctxp).decode())
+
+    t_build0 = time.perf_counter()
+    meshes, fill = [], {}
+    with torch.cuda.stream(stream):
+        for kind, n in (("sphere", 120), ("terrain", 170), ("soup", 130)):
+            pos, tris = make_mesh(kind, n=n, seed=31)
+            nrm = pos - pos.mean(0)
+            nrm = nrm / nrm.norm(dim=1, keepdim=True).clamp_min(1e-6)
+            lods = build_mesh_lods(pos, tris, normals=nrm)
+            bounds, m6, qpos = [], None, None
+            for i, lod in enumerate(lods):
+                b, mb, q = r.build_meshlet_bounds(pos.to(dev), lod["meshlets"].to(dev), lod["vidx"].to(dev), lod["micro"].to(dev), stream=stream)
+                bounds.append(b)
+                if i == 0:
+                    m6, qpos = mb, q
+            meshes.append({"lods": lods, "bounds": bounds, "positions": qpos, "mesh_bounds": m6})
+            fill[kind] = {"triangles": int(tris.shape[0]), "vertices": int(pos.shape[0]), "lod_meshlets": [int(l["meshlets"].shape[0]) for l in lods],
+                          "mean_triangles_over_64_per_lod": [round(float(l["meshlets"][:, 3].float().mean()) / 64.0, 3) for l in lods],
+                          "mean_vertices_over_64_per_lod": [round(float(l["meshlets"][:, 2].float().mean()) / 64.0, 3) for l in lods],
+                          "lod_error": [round(l["error"], 5) for l in lods]}
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t_build0
+        k0 = [int(m["lods"][0]["meshlets"].shape[0]) for m in meshes]
+        M = max(3, int(round(10_000_000 / (sum(k0) / len(k0)))) // 12 * 12)  # (a multiple of 4 per mesh keeps instance ranges easy to cut)
+        scene = make_scene_from_meshes(M, meshes, seed=0x0A1DE5 + 7, device=dev)
+        N = scene.n_meshlet_instances
+        r.reserve(M, N)
+        frame = PreparedFrame.create(scene, with_triangles=True)
+        depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))
+        hiz = ImageAttachment.hiz(HW, HW, dev)
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
+        r.prepared_frame = frame
+        r.seed_meshlet_instances(ctx, N)
+        g = torch.Generator(device=dev).manual_seed(5)
+        words = frame.meshlet_instance_visibility_mask_buffer.numel()
+        bits = (torch.rand((words, 32), generator=g, device=dev) < 0.3).to(torch.int64)
+        mask0 = (bits << torch.arange(32, device=dev)).sum(1).to(torch.int32)
+        del bits
+        mask = frame.meshlet_instance_visibility_mask_buffer
+    torch.cuda.synchronize()
+    cframe, cctx = frame.c(), ctx.c()
+    mg = L.MainGeometryContext()
+    mg.struct_size = C.sizeof(L.MainGeometryContext)
+    mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
+    snap = {}
+
+    def one(record=False):
+        mask.copy_(mask0, non_blocking=True)
+        check(lib.oxc_generate_hiz(ctxp, C.byref(mg), sp))
+        for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+            cctx.cull_flags = flags
+            check(lib.oxc_cull_geometry(ctxp, C.byref(cframe), C.byref(cctx), sp))
+            if record:
+                torch.cuda.synchronize()
+                out = L.Counters()
+                check(lib.oxc_read_counters(ctxp, C.byref(cctx), C.byref(out), sp))
+                first = out.early_visible_meshlet_instances if tag == "late" else 0
+                snap[tag] = {"emitted": out.cull_triangles_cmd_x, "index_count": out.draw_index_count, "first": first,
+                             "visible": frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x].clone(),
+                             "indices": frame.reordered_indices_buffer[:out.draw_index_count].clone()}
+
+    with torch.cuda.stream(stream):
+        one(record=True)
+        mask_after = mask.clone()
+        for _ in range(5):
+            one()
+    torch.cuda.synchronize()
+    frames = 96
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(frames):
+            one()
+    torch.cuda.synchronize()
+    ms_per_frame = (time.perf_counter() - t0) / frames * 1e3
+    r.profile_begin()
+    with torch.cuda.stream(stream):
+        for _ in range(48):
+            one()
+    prof = r.profile_end()
+    kernels = {k: round(v["total_ms"] / v["launches"] * 1e3, 2) for k, v in prof["kernels"].items()}
+    v_e, v_l = snap["early"]["emitted"], snap["late"]["emitted"]
+    t_e, t_l = snap["early"]["index_count"] // 3, snap["late"]["index_count"] // 3
+
+    # ---- the checker over a prefix of the same arrays (the scene minus most of its instances): parity + the unpinned gap ----
+    bit_match, unpinned = None, None
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+
+        oracle.build()
+        cpu = scene.to("cpu")
+        m0 = min(M, 600)
+        P = int(cpu.mesh_instances[m0, 4].item()) if m0 < M else N  # meshlet instances of the first m0 mesh instances (a multiple of 32: m0 is a multiple of 12)
+        mli = cpu.meshlet_instances[:P]
+        cam = cpu.cull_camera()
+        hz = oracle.make_hiz(hiz.data.cpu(), HW, HW, hiz.levels, hiz.level_offset)
+        mk0 = mask0[: (P + 31) // 32].cpu()
+
+        def sequence():
+            v = oracle.Visibility(P, 0, 0)
+            out = torch.zeros(P, dtype=torch.int32)
+            mk = mk0.clone()
+            res = {}
+            for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+                n_e = oracle.cull_meshlets_hiz(cpu, cam, mli, flags, hz, v, mk, out)
+                first = v.early if tag == "late" else 0
+                res[tag] = (out[first:first + n_e].clone(), oracle.cull_triangles(cpu, cam, mli, out, first, n_e))
+            return res, mk
+
+        want, mask_want = sequence()
+        got_mask = mask_after[: (P + 31) // 32].cpu()
+        ok = torch.equal(mask_want[: P // 32], got_mask[: P // 32])
+        if P % 32:  # the word the sample shares with the first instance beyond it: only the sample's bits are comparable
+            low = (1 << (P % 32)) - 1
+            ok = ok and (int(mask_want[-1].item()) & low) == (int(got_mask[-1].item()) & low)
+        for tag in ("early", "late"):
+            vis = snap[tag]["visible"]
+            nv = int(torch.searchsorted(vis, torch.tensor([P], dtype=torch.int32, device=dev)).item())
+            idx = snap[tag]["indices"].to(torch.int64) & 0xFFFFFFFF
+            ni = int(torch.searchsorted(idx, torch.tensor([P << 8], dtype=torch.int64, device=dev)).item())
+            ok = ok and torch.equal(want[tag][0], vis[:nv].cpu()) and torch.equal(want[tag][1], snap[tag]["indices"][:ni].cpu())
+        bit_match = bool(ok)
+        with oracle.variant("fast"):
+            fast, mask_fast = sequence()
+        tri1 = lambda t: (t.view(-1, 3)[:, 0].numpy().astype("int64") & 0xFFFFFFFF) if t.numel() else np.zeros(0, dtype="int64")  # noqa: E731
+        flags_b = oracle.triangle_boundary_flags(cpu, cam, mli, want["late"][0], 0, want["late"][0].numel())
+        unpinned = {"sample": f"the {P} meshlet instances of the first {m0} mesh instances, both passes",
+                    "visible_meshlets_differ": sum(int(np.setxor1d(want[t][0].numpy(), fast[t][0].numpy()).size) for t in ("early", "late")),
+                    "mask_bits_differ": int(np.unpackbits((mask_want.numpy() ^ mask_fast.numpy()).view(np.uint8)).sum()),
+                    "triangles_differ": sum(int(np.setxor1d(tri1(want[t][1]), tri1(fast[t][1])).size) for t in ("early", "late")),
+                    "triangles_emitted": sum(int(want[t][1].numel() // 3) for t in ("early", "late")),
+                    "late_triangles_ill_conditioned": int(flags_b.sum())}
+        # triangles the late pass tested on the sample: the sum of triangle_count over its visible meshlets
+        inst = mli[want["late"][0].to(torch.int64)]
+        mesh_of = cpu.mesh_instances[inst[:, 0].to(torch.int64), 0].to(torch.int64)
+        first_meshlet = cpu._lod_tables["meshlet_start"][mesh_of * cpu.spec.lod_count]
+        unpinned["late_triangles_tested"] = int(cpu.meshlets[first_meshlet + inst[:, 1].to(torch.int64), 3].clamp(max=64).sum().item())
+    res = {"workload": "the configs[2] frame over real meshes: UV sphere, height field, triangle soup -> oxc_mesh_build_* (clusteriser + LOD chain) -> oxc_build_meshlet_bounds, "
+                       "instanced round robin (shared geometry), LOD-0 lists, 4096^2 HiZ from the same 8192^2 depth, prior mask p = 0.3",
+           "meshlets": N, "mesh_instances": M, "meshes": fill, "asset_build_seconds": round(t_build, 2), "ms_per_frame": round(ms_per_frame, 6),
+           "value": round(N / (ms_per_frame * 1e-3), 1), "unit": "meshlets/s", "frames_timed": frames,
+           "visible_fraction": round((v_e + v_l) / N, 4), "triangles_per_visible_meshlet": round((t_e + t_l) / max(1, v_e + v_l), 2),
+           "counts": {"early": v_e, "late": v_l, "early_triangles": t_e, "late_triangles": t_l}, "kernels_avg_us": kernels, "bit_match": bit_match, "unpinned_gap": unpinned}
+    del scene, frame, depth, hiz, mask0
+    torch.cuda.empty_cache()
+    return res
