@@ -111,9 +111,11 @@ constexpr uint32_t kSuperStride = 64;         // words between super-chunk accum
 constexpr uint32_t kTicketCounters = 256;    // dynamic work counters of the HiZ meshlet test: counter x hands out the wave steps congruent to x mod 256
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
 // async_triangles (include/oxcull.h): resident blocks per CU the persistent kernels of the two stages take while they share the machine
-// (0 = no limit).  HiZ meshlet test: 4 waves of <= 96 VGPRs per block; triangle test / emit: 4 waves of <= 64 VGPRs -- per SIMD
-// 2 x 96 + 5 x 64 = 512 VGPRs, 7 of 8 wave slots.
-constexpr uint32_t kAsyncMeshletBlocksPerCU = 2;
-constexpr uint32_t kAsyncTriangleBlocksPerCU = 5;
+// (0 = no limit).  Measured on configs[2] (tools/kbench.py, us per frame; in order on one stream: 613): no limit 623, meshlet / triangle
+// blocks per CU 3 / 8: 628, 3 / 5: 639, 4 / 4: 640, 3 / 4: 648, 2 / 5: 685, 2 / 6: 689, 1 / 6: 954 -- the kernels do run side by
+// side (their HIP-event times add up to 1.8x the frame) but each slows down by what the other takes: the frame is bound by HBM
+// traffic, which both stages draw on (2.4-3.7 TB/s by the meshlet tests, ~5 TB/s by the triangle stage).  Hence no limit by default.
+constexpr uint32_t kAsyncMeshletBlocksPerCU = 0;
+constexpr uint32_t kAsyncTriangleBlocksPerCU = 0;
 
 }  // namespace oxc

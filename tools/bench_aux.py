@@ -13,6 +13,28 @@ from oxylus_amd.synth import SceneSpec, make_scene
 HBM_PEAK_GBPS = 8000.0
 
 
+def _usable_cores() -> int:
+    """Host threads that can run at once: the affinity mask cut down by a cgroup CPU quota (bench.py usable_cores)."""
+    import os
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(period) + 0.999)))
+    except (OSError, ValueError):
+        try:
+            q, period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                cores = max(1, min(cores, int(q / period + 0.999)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def bench_bounds(args, r, dev, stream, rank, world, dist):
     """--workload bounds: the asset-side meshlet bounds producer (oxc_build_meshlet_bounds) over a
     procedural terrain cut into 8x4-quad patches (64 triangles, 45 vertices per meshlet, vertices not shared
@@ -386,10 +408,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         import oracle
 
         oracle.build()
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count() or 1
+        cores = _usable_cores()
         cpu = base.to("cpu")
         want, t_views = {}, 0.0
         for v in range(views):
@@ -537,7 +556,8 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
         P = int(cpu.mesh_instances[m0, 4].item()) if m0 < M else N  # meshlet instances of the first m0 mesh instances (a multiple of 32: m0 is a multiple of 12)
         mli = cpu.meshlet_instances[:P]
         cam = cpu.cull_camera()
-        hz = oracle.make_hiz(hiz.data.cpu(), HW, HW, hiz.levels, hiz.level_offset)
+        hz_cpu = hiz.data.cpu()  # (kept alive: make_hiz only stores its address)
+        hz = oracle.make_hiz(hz_cpu, HW, HW, hiz.levels, hiz.level_offset)
         mk0 = mask0[: (P + 31) // 32].cpu()
 
         def sequence():
