@@ -224,7 +224,11 @@ oxc_status oxc_join_triangles(oxc_ctx* ctx, void* hip_stream);
  * element uses the plain pipeline (use_hiz == use_hpb == 0, no LatePass) with the same `stages` and
  * `init_cull_meshes`, and count <= 16, each stage is ONE launch with grid.y = count; otherwise the elements
  * are processed one after the other.  A 1M-meshlet call is launch-latency bound on MI355X (a HIP graph
- * sustains ~3 us per kernel node); batching is what amortises it. */
+ * sustains ~3 us per kernel node); batching is what amortises it.
+ * When, in addition, every element runs cull_meshes (init_cull_meshes, OXC_STAGE_MESHES) over the SAME meshes_buffer and
+ * transforms_world_buffer with the same flags -- several views of one scene: shadow cascades, BASELINE configs[4] -- the meshlet
+ * stage runs once for all views: the views that kept a mesh instance at the same LOD are tested against one load of its
+ * MeshletBounds records.  Outputs are the per-element outputs of the plain form, byte for byte. */
 oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepared_frame* frames,
                                    oxc_cull_geometry_context* contexts, void* hip_stream);
 
@@ -266,6 +270,7 @@ enum {
   OXC_K_TRIANGLES_EMIT_LATE = 11,
   OXC_K_DRAW_VISBUFFER = 12, /* every launch of one oxc_draw_visbuffer call (clear, setup, clipped, big, resolve) */
   OXC_K_MESHLET_BOUNDS = 13, /* oxc_build_meshlet_bounds */
+  OXC_K_MULTIVIEW_SETUP = 14, /* batched views of one scene: view groups per mesh instance, chunk numbering, step list (three small launches) */
   OXC_K_COUNT = 16
 };
 typedef struct oxc_kernel_times {

@@ -58,6 +58,8 @@ struct oxc_ctx {
   };
   Lane lane[kMaxBatch];
   BatchElem* batch_dev = nullptr;  // device copy of the argument blocks of the current batched call (kMaxBatch elements)
+  void* mv_arena = nullptr;        // multi-view meshlet stage (batched views of one scene): view table, groups, step list, per-view chunk arrays
+  uint64_t mv_arena_bytes = 0;
   // oxc_build_meshlet_bounds: per-meshlet {min xyz, max xyz} for all meshlets, then per chunk of kBoundsChunk
   // meshlets the compacted triangle normals (768 B each) and their counts
   float* bounds_scratch = nullptr;
@@ -376,6 +378,7 @@ void oxc_destroy(oxc_ctx* ctx) {
   for (auto& ln : ctx->lane)
     if (ln.arena) (void)hipFree(ln.arena);
   if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
+  if (ctx->mv_arena) (void)hipFree(ctx->mv_arena);
   if (ctx->bounds_scratch) (void)hipFree(ctx->bounds_scratch);
   if (ctx->raster_scratch) (void)hipFree(ctx->raster_scratch);
   if (ctx->raster_rows) (void)hipFree(ctx->raster_rows);
@@ -737,6 +740,16 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     }
     return OXC_OK;
   }
+  // Several VIEWS of one scene (every element runs cull_meshes + cull_meshlets over the same meshes / transforms with its own camera --
+  // shadow cascades, BASELINE configs[4]): the meshlet stage then runs once over the scene for all views (k_mv_test) instead of
+  // once per view over that view's list.  Same outputs, element by element.
+  bool multiview = ci[0].do_meshes && ci[0].do_meshlets && ci[0].M > 0;
+  bool same_pos = true;
+  for (uint32_t e = 1; multiview && e < count; e++) {
+    multiview = ci[e].M == ci[0].M && frames[e].meshes_buffer.dptr == frames[0].meshes_buffer.dptr &&
+                frames[e].transforms_world_buffer.dptr == frames[0].transforms_world_buffer.dptr && contexts[e].cull_flags == contexts[0].cull_flags;
+    same_pos = same_pos && std::memcmp(contexts[e].cull_camera.position, contexts[0].cull_camera.position, 12) == 0;
+  }
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   for (uint32_t e = 0; e < count; e++) {
     oxc_status st = ensure_capacity(ctx, ci[e].M, ci[e].N, 0, e, static_cast<hipStream_t>(hip_stream));
@@ -852,7 +865,93 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
     launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, cap), s);
   }
-  if (do_meshlets) {
+  if (do_meshlets && multiview) {
+    const uint32_t Mv = ci[0].M;
+    // scratch: view table | groups [M][views] | chunks per instance, their prefix [M] | totals | step list | per view: vchunks, vchunk0 [M],
+    // ballots [chunks][4], counts, idbase [chunks], supers, totals
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) {
+      uint64_t o = off;
+      off = align_up(off + bytes, 256);
+      return o;
+    };
+    uint32_t vchunks_max[kMaxBatch];
+    uint64_t steps_max = 0;
+    uint32_t max_vchunks = 0;
+    for (uint32_t e = 0; e < count; e++) {
+      vchunks_max[e] = cdiv(std::max(ci[e].N, 1u), 256u) + Mv;  // sum over instances of ceil(count / 256) <= N / 256 + M
+      steps_max += vchunks_max[e];
+      max_vchunks = std::max(max_vchunks, vchunks_max[e]);
+    }
+    const uint64_t o_table = carve(sizeof(MvView) * kMaxBatch);
+    const uint64_t o_groups = carve((uint64_t)Mv * count * sizeof(MvGroup));
+    const uint64_t o_gch = carve((uint64_t)Mv * 4), o_st0 = carve((uint64_t)Mv * 4), o_tot = carve(64);
+    const uint64_t o_steps = carve(steps_max * 8);
+    uint64_t o_vch[kMaxBatch], o_vc0[kMaxBatch], o_bits[kMaxBatch], o_cnt[kMaxBatch], o_idb[kMaxBatch], o_sup[kMaxBatch], o_vtot[kMaxBatch];
+    for (uint32_t e = 0; e < count; e++) {
+      o_vch[e] = carve((uint64_t)Mv * 4);
+      o_vc0[e] = carve((uint64_t)Mv * 4);
+      o_bits[e] = carve((uint64_t)vchunks_max[e] * 32);
+      o_cnt[e] = carve((uint64_t)vchunks_max[e] * 4);
+      o_idb[e] = carve((uint64_t)vchunks_max[e] * 4);
+      o_sup[e] = carve((uint64_t)cdiv(vchunks_max[e], kChunksPerSuper) * 4 * kSuperStride);
+      o_vtot[e] = carve(64);
+    }
+    if (off > ctx->mv_arena_bytes) {
+      if (stream_is_capturing(s)) return fail(ctx, OXC_INVALID_ARG, "cull_geometry_batch: the multi-view scratch must grow but the stream is being captured; make one un-captured call of this size first");
+      OXC_HIP(ctx, hipDeviceSynchronize());
+      if (ctx->mv_arena) OXC_HIP(ctx, hipFree(ctx->mv_arena));
+      ctx->mv_arena = nullptr;
+      ctx->mv_arena_bytes = 0;
+      hipError_t me = hipMalloc(&ctx->mv_arena, off);
+      if (me != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(multi-view scratch)", me);
+      ctx->mv_arena_bytes = off;
+    }
+    char* const mb = static_cast<char*>(ctx->mv_arena);
+    MvArgs ma;
+    std::memset(&ma, 0, sizeof ma);
+    ma.views = count;
+    ma.M = Mv;
+    ma.same_pos = same_pos ? 1u : 0u;
+    ma.dev = reinterpret_cast<MvView*>(mb + o_table);
+    ma.groups = reinterpret_cast<MvGroup*>(mb + o_groups);
+    ma.grp_chunks = reinterpret_cast<uint32_t*>(mb + o_gch);
+    ma.inst_step0 = reinterpret_cast<uint32_t*>(mb + o_st0);
+    ma.step_total = reinterpret_cast<uint32_t*>(mb + o_tot);
+    ma.steps = reinterpret_cast<uint2*>(mb + o_steps);
+    ma.tickets = ctx->lane[0].m_tickets;
+    MvBlob blob;
+    std::memset(&blob, 0, sizeof blob);
+    for (uint32_t e = 0; e < count; e++) {
+      MvView& w = blob.v[e];
+      oxc_ctx::Lane& L = ctx->lane[e];
+      w.rows = L.cache;
+      w.mesh_counts = L.mesh_counts;
+      w.mesh_offsets = L.mesh_offsets;
+      w.vchunks = reinterpret_cast<uint32_t*>(mb + o_vch[e]);
+      w.vchunk0 = reinterpret_cast<uint32_t*>(mb + o_vc0[e]);
+      w.bits = reinterpret_cast<uint64_t*>(mb + o_bits[e]);
+      w.counts = reinterpret_cast<uint32_t*>(mb + o_cnt[e]);
+      w.idbase = reinterpret_cast<uint32_t*>(mb + o_idb[e]);
+      w.supers = reinterpret_cast<uint32_t*>(mb + o_sup[e]);
+      w.scan_total = reinterpret_cast<uint32_t*>(mb + o_vtot[e]);
+      w.out = static_cast<uint32_t*>(frames[e].visible_meshlet_instances_indices_buffer.dptr);
+      w.tri_cmd = cores[e].slot + SLOT_TRI_CMD;
+      w.n_cap = ci[e].N;
+      w.n_supers = cdiv(vchunks_max[e], kChunksPerSuper);
+      std::memcpy(w.cam_pos, contexts[e].cull_camera.position, 12);
+    }
+    {
+      KernelTimer t(ctx, OXC_K_MULTIVIEW_SETUP, s);
+      launch_mv_setup(ma, blob, std::max(1u, std::min(cdiv(Mv, 16u), max_grid)), s);  // 16 lanes per mesh instance
+    }
+    {
+      KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
+      launch_mv_test(ma, ctx->num_cus, s);
+    }
+    KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
+    launch_mv_emit(ma, max_vchunks, max_grid, s);
+  } else if (do_meshlets) {
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
       // At 64 VGPRs (8 waves/SIMD) the test kernel wants every block it can get: with 16 x 1M meshlets, blocks per element

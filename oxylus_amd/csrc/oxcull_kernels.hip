@@ -194,6 +194,7 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       float sz = len3(OXC_M(w, 2, 0), OXC_M(w, 2, 1), OXC_M(w, 2, 2));
       out->scale_max = fmaxf(sx, fmaxf(sy, sz));
       out->vis_offset = inst.meshlet_instance_visibility_offset;
+      out->transform_index = inst.transform_index;
       out->_pad0[0] = out->_pad0[1] = out->_pad0[2] = 0u;  // zero dwords: dummy index source for degenerate meshlets (tris_test_body)
 
       const GpuMeshLOD* lods = reinterpret_cast<const GpuMeshLOD*>(mesh.lods);
@@ -985,6 +986,8 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
 // ------------------------------------------------------------------------------------------
 template <bool HIZ, bool LATE>
 OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
+  // (One wave per span instead of one block -- the form k_mv_emit uses -- was measured here too: 10.9 -> 12.4 us per launch at 10 M
+  // meshlets, every wave then sums all the super-chunk counts in front of its span on its own.)
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_off[64];
   __shared__ uint64_t s_bits[64];
@@ -1559,6 +1562,248 @@ __global__ __launch_bounds__(256, 8) void k_cull_triangles_test_batch(const Batc
 }
 __global__ __launch_bounds__(256) void k_cull_triangles_emit_batch(const BatchElem* __restrict__ dev) {
   tris_emit_body<false, false>(dev[blockIdx.y].temit);
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-view meshlet stage (oxcull_kernels.hpp, MvArgs): several views of ONE scene in one pass.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMvChunk = 256;  // meshlets per wave step: 4 groups of 64
+
+// (1) per mesh instance: group the views, count chunks.  Sixteen lanes per instance, lane = view.  Also publishes the view table to
+// device memory and zeroes the counters the later kernels accumulate into.
+__global__ __launch_bounds__(256) void k_mv_group(MvArgs a, MvBlob blob) {
+  static_assert(kMaxBatch == 16, "one lane per view in a 16-lane segment");
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t v = (uint32_t)lane & 15u, seg = (uint32_t)lane & ~15u;
+  const MvView* const table = blob.v;  // (kernarg segment: indexed by lane)
+  if (tid < a.views) a.dev[tid] = table[tid];
+  for (uint32_t u = 0; u < a.views; u++)
+    for (uint32_t i = tid; i < table[u].n_supers; i += nthreads) table[u].supers[i * kSuperStride] = 0;
+  if (tid < kTicketCounters) a.tickets[tid * kSuperStride] = 0;
+  const uint32_t per_round = nthreads >> 4, rounds = (a.M + per_round - 1) / per_round;
+  for (uint32_t r = 0; r < rounds; r++) {
+    const uint32_t mi = r * per_round + (tid >> 4);
+    const bool live = mi < a.M && v < a.views;
+    uint64_t kb = 0;
+    uint32_t kt = 0, cnt = 0;
+    if (live) {
+      const MvView& w = table[v];
+      const uint32_t c = w.mesh_counts[mi], off = w.mesh_offsets[mi];
+      cnt = off >= w.n_cap ? 0u : min(c, w.n_cap - off);  // records beyond the view's list capacity do not exist (expand_body)
+      const InstCache* row = w.rows + mi;
+      kb = row->bounds;
+      kt = row->transform_index;
+      w.vchunks[mi] = (cnt + kMvChunk - 1) / kMvChunk;
+    }
+    uint32_t same = 0;  // views of this instance with my key
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++) {
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)kb, (int)(seg + u), 64), hi = (uint32_t)__shfl((int)(uint32_t)(kb >> 32), (int)(seg + u), 64);
+      const uint32_t tu = (uint32_t)__shfl((int)kt, (int)(seg + u), 64), cu = (uint32_t)__shfl((int)cnt, (int)(seg + u), 64);
+      if (cnt != 0u && cu == cnt && tu == kt && (((uint64_t)hi << 32) | lo) == kb) same |= 1u << u;
+    }
+    const bool leader = cnt != 0u && (uint32_t)__builtin_ctz(same | 0x10000u) == v;
+    const uint32_t leaders = (uint32_t)(__ballot(leader) >> seg) & 0xFFFFu;
+    const uint32_t g = (uint32_t)__popc(leaders & ((1u << v) - 1u)), ngroups = (uint32_t)__popc(leaders);
+    uint32_t chunks = leader ? (cnt + kMvChunk - 1) / kMvChunk : 0u;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) chunks += (uint32_t)__shfl_xor((int)chunks, o, 64);
+    if (mi < a.M) {
+      MvGroup* out = a.groups + (size_t)mi * a.views;
+      if (leader) out[g] = MvGroup{kb, cnt, same};
+      if (v >= ngroups && v < a.views) out[v] = MvGroup{0, 0, 0};
+      if (v == 0) a.grp_chunks[mi] = chunks;
+    }
+  }
+}
+
+// (2) exclusive prefixes: per view over vchunks (the view's chunk numbering), and over grp_chunks (the step list)
+__global__ __launch_bounds__(1024) void k_mv_scan(MvArgs a) {
+  ScanArgs sa;
+  if (blockIdx.y < a.views) {
+    const MvView& w = a.dev[blockIdx.y];
+    sa = ScanArgs{w.vchunks, w.vchunk0, a.M, 0xFFFFFFFFu, w.scan_total, w.scan_total + 1};
+  } else {
+    sa = ScanArgs{a.grp_chunks, a.inst_step0, a.M, 0xFFFFFFFFu, a.step_total, a.step_total + 1};
+  }
+  scan_body(sa);
+}
+
+// (3) the step list: one wave per mesh instance writes {instance, group | chunk << 8} for every chunk of every group
+__global__ __launch_bounds__(256) void k_mv_steps(MvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t mi = wave; mi < a.M; mi += nwaves) {
+    uint32_t at = a.inst_step0[mi];
+    const MvGroup* g = a.groups + (size_t)mi * a.views;
+    for (uint32_t k = 0; k < a.views; k++) {
+      const uint32_t count = g[k].count;
+      if (count == 0u) break;
+      const uint32_t chunks = (count + kMvChunk - 1) / kMvChunk;
+      for (uint32_t c = lane; c < chunks; c += 64) reinterpret_cast<uint32_t*>(a.steps)[(size_t)(at + c) * 2] = mi, reinterpret_cast<uint32_t*>(a.steps)[(size_t)(at + c) * 2 + 1] = k | (c << 8);
+      at += chunks;
+    }
+  }
+}
+
+// (4) the test: cull_meshlets.slang:23-73 for every view of the step's group over one load of the bounds records.
+// SAME_POS: every view has the same camera position -- the normal cone (world matrix, normal matrix and scale are the group's: same
+// transform) is then evaluated once per meshlet and kept as a 64-bit lane mask per 64-meshlet group; otherwise once per view.
+template <bool SAME_POS>
+__global__ __launch_bounds__(256) void k_mv_test(MvArgs a) {
+  set_half_denorm_flush();
+  constexpr int G = 4;
+  const int lane = threadIdx.x & 63;
+  const uint32_t nsteps = gptr(a.step_total)[0];
+  const uint32_t K = min(kTicketCounters, gridDim.x), kx = blockIdx.x % K;
+  uint32_t* const ticket = a.tickets + kx * kSuperStride;
+  auto draw_ticket = [&]() -> uint32_t {
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  uint32_t step = OXC_TICKET_STEP(readlane_u(draw_ticket(), 0), K, kx);
+  while (step < nsteps) {
+    const uint32_t next_ticket = draw_ticket();
+    const uint2 sd = load_global_u2(reinterpret_cast<uint64_t>(a.steps), step);
+    const uint32_t mi = readfirst_u(sd.x), gi = readfirst_u(sd.y) & 0xFFu, c = readfirst_u(sd.y) >> 8;
+    const kconst32p grp = (kconst32p)(reinterpret_cast<uint64_t>(a.groups + (size_t)mi * a.views + gi));
+    const uint64_t bounds = (uint64_t)grp[0] | ((uint64_t)grp[1] << 32);
+    const uint32_t count = grp[2], vmask = grp[3];
+    const uint32_t k0 = c * kMvChunk;
+    uint4 bnd[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) bnd[j] = load_stream_u4(bounds, min(k0 + (uint32_t)j * 64u + (uint32_t)lane, count - 1u));
+    float cx[G], cy[G], cz[G], ex[G], ey[G], ez[G];
+    uint64_t okb[G];  // lanes that exist and pass the cone test (per view when the views have different camera positions)
+    auto cone_pass = [&](const kconst32p row, float camx, float camy, float camz) {
+      ConeU cu;
+#pragma unroll
+      for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
+#pragma unroll
+      for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
+#pragma unroll
+      for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
+      cu.scale_max = asf(row[kRowScale]);
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint4 b = bnd[j];
+        const bool valid = k0 + (uint32_t)j * 64u + (uint32_t)lane < count;
+        const bool nc = valid && ((int32_t)b.w >> 24) != 127;  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
+        bool ok = valid;
+        if (__builtin_amdgcn_ballot_w64(nc)) {  // wave-uniform
+          const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
+          const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
+          const int tier1 = cone_visible_fast(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+          bool cone_ok = tier1 == 1;
+          if (__builtin_amdgcn_ballot_w64(nc && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
+            const bool exact = cone_visible(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+            cone_ok = tier1 == 2 ? exact : cone_ok;
+          }
+          ok = nc ? cone_ok : ok;
+        }
+        okb[j] = __builtin_amdgcn_ballot_w64(ok);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      const uint4 b = bnd[j];
+      cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
+      ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
+    }
+    if (SAME_POS) {
+      const MvView* w0 = a.dev + (uint32_t)__builtin_ctz(vmask);
+      cone_pass(const_row(w0->rows, mi), w0->cam_pos[0], w0->cam_pos[1], w0->cam_pos[2]);
+    }
+    for (uint32_t m = vmask; m; m &= m - 1u) {
+      const uint32_t v = (uint32_t)__builtin_ctz(m);
+      const MvView* w = a.dev + v;
+      const kconst32p row = const_row(w->rows, mi);
+      if (!SAME_POS) cone_pass(row, w->cam_pos[0], w->cam_pos[1], w->cam_pos[2]);
+      const uint32_t p = gptr(w->vchunk0)[mi] + c;  // this chunk in the view's own numbering
+      const uint32_t id0 = gptr(w->mesh_offsets)[mi] + k0;
+      float pl[24], sg[18];
+#pragma unroll
+      for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+#pragma unroll
+      for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
+      uint32_t cnt = 0;
+      uint64_t bits[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        bits[j] = __builtin_amdgcn_ballot_w64(test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j])) & okb[j];
+        cnt += (uint32_t)__popcll((unsigned long long)bits[j]);
+      }
+      if (lane < G) {  // lane j stores ballot j: one 32-byte run
+        const uint64_t mine = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+        gptr(w->bits)[(size_t)p * G + lane] = mine;
+      }
+      if (lane == 0) {
+        gptr(w->counts)[p] = cnt;
+        gptr(w->idbase)[p] = id0;
+        if (cnt) __hip_atomic_fetch_add(gptr(w->supers) + (p / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    step = OXC_TICKET_STEP(readlane_u(next_ticket, 0), K, kx);
+  }
+}
+
+// (5) per view: ordered expansion of the view's chunk ballots into its visible list.  One WAVE per span of 16 chunks (64 ballots): its
+// loads (ballots, id bases, the counts in front of it) are all issued at once and nothing waits for a block barrier -- the
+// block-per-span form of the single-view emit kernel spent its time in two dependent round trips per span (74 -> us per 16 views).
+__global__ __launch_bounds__(256) void k_mv_emit(MvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const MvView& w = a.dev[blockIdx.y];
+  const uint32_t nchunks = gptr(w.scan_total)[0];
+  const uint32_t nwords = nchunks * 4u;
+  const uint32_t nspans = (nchunks + 15u) / 16u;
+  if (nspans == 0u && blockIdx.x == 0 && threadIdx.x == 0) gptr(w.tri_cmd)[0] = 0u;
+  for (uint32_t span = blockIdx.x * 4u + (uint32_t)wave; span < nspans; span += gridDim.x * 4u) {
+    const uint32_t wd = span * 64u + (uint32_t)lane;
+    const uint32_t wc = min(wd, nwords - 1u);
+    uint64_t bits = gptr(w.bits)[wc];
+    const uint32_t idb = gptr(w.idbase)[wc >> 2] + (wc & 3u) * 64u;
+    // exclusive base of the span: all supers before its super + the chunk counts inside it
+    const uint32_t c0 = span * 16u, sup = c0 / kChunksPerSuper;
+    uint32_t acc = 0;
+    for (uint32_t i = (uint32_t)lane; i < sup; i += 64u) acc += gptr(w.supers)[i * kSuperStride];
+    const uint32_t j = sup * kChunksPerSuper + (uint32_t)lane;
+    if (j < c0) acc += gptr(w.counts)[j];
+    const uint32_t base = wave_sum(acc);
+    if (wd >= nwords) bits = 0ull;
+    const uint32_t cnt = (uint32_t)__popcll((unsigned long long)bits);
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    const uint32_t off = base + incl - cnt;
+    if (lane == 63 && span == nspans - 1u) gptr(w.tri_cmd)[0] = base + incl;  // cull_triangles_cmd.x
+    const uint32_t blo = (uint32_t)bits, bhi = (uint32_t)(bits >> 32);
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll 4
+    for (int k = 0; k < 64; k++) {
+      const uint64_t bk = (uint64_t)readlane_u(blo, k) | ((uint64_t)readlane_u(bhi, k) << 32);
+      if (bk == 0ull) continue;  // wave-uniform
+      const uint32_t ok = readlane_u(off, k), ik = readlane_u(idb, k);
+      if ((bk >> lane) & 1ull) gptr(w.out)[ok + (uint32_t)__popcll((unsigned long long)(bk & below))] = ik + (uint32_t)lane;
+    }
+  }
+}
+
+void launch_mv_setup(const MvArgs& a, const MvBlob& blob, uint32_t grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_mv_group, dim3(grid), dim3(256), 0, s, a, blob);
+  hipLaunchKernelGGL(k_mv_scan, dim3(1, a.views + 1), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(k_mv_steps, dim3(std::max(1u, std::min((a.M + 3u) / 4u, grid))), dim3(256), 0, s, a);
+}
+void launch_mv_test(const MvArgs& a, uint32_t num_cus, hipStream_t s) {
+  if (a.same_pos)
+    hipLaunchKernelGGL(k_mv_test<true>, dim3(num_cus * 8u), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_mv_test<false>, dim3(num_cus * 8u), dim3(256), 0, s, a);
+}
+void launch_mv_emit(const MvArgs& a, uint32_t max_chunks_per_view, uint32_t max_grid, hipStream_t s) {
+  const uint32_t blocks = std::max(1u, ((max_chunks_per_view + 15u) / 16u + 3u) / 4u);  // one wave per span
+  hipLaunchKernelGGL(k_mv_emit, dim3(std::min(blocks, std::max(max_grid / std::max(1u, a.views), max_grid / 4u)), a.views), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -272,6 +272,52 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   te.out = c.reordered_out;
 }
 
+// ---- multi-view meshlet stage: oxc_cull_geometry_batch over several VIEWS of one scene (cull_meshes + cull_meshlets per view) ----
+// One pass over the scene's meshlets instead of one per view: the views that kept a mesh instance at the same LOD form a group,
+// a wave loads a 256-meshlet chunk of the group's bounds records once and tests it against every view of the group
+// (cull_meshlets_hpb.slang:59-79 is the reference's own one-thread-many-views shape).  Per view the output is what the per-view
+// kernels write: the view's own ascending list of indices into the view's own MeshletInstance list.
+struct MvView {
+  const InstCache* rows;         // this view's instance rows (prepare_body with this view's camera)
+  const uint32_t* mesh_counts;   // [M] meshlets of the instance in this view's list (0: culled by this view's cull_meshes)
+  const uint32_t* mesh_offsets;  // [M] first record of the instance in this view's list
+  uint32_t* vchunks;             // [M] 256-meshlet chunks of the instance in this view ...
+  uint32_t* vchunk0;             // [M] ... and their exclusive prefix: the view's own chunk numbering
+  uint64_t* bits;                // [chunks][4] survivor ballots per view chunk
+  uint32_t* counts;              // [chunks]
+  uint32_t* idbase;              // [chunks] list index of the chunk's first meshlet
+  uint32_t* supers;              // per 64 chunks (stride kSuperStride)
+  uint32_t* scan_total;          // [2] number of chunks of this view
+  uint32_t* out;                 // visible_meshlet_instances_indices of this view
+  uint32_t* tri_cmd;
+  uint32_t n_cap;                // the view's list capacity
+  uint32_t n_supers;
+  float cam_pos[3];
+  uint32_t _pad;
+};
+struct MvGroup {  // the views of one mesh instance that read the same bounds array with the same transform and the same count
+  uint64_t bounds;
+  uint32_t count;
+  uint32_t view_mask;
+};
+struct MvBlob {
+  MvView v[kMaxBatch];
+};
+struct MvArgs {
+  uint32_t views, M;
+  uint32_t same_pos;  // every view has the same camera position: the normal cone is evaluated once per meshlet, not once per view
+  MvView* dev;        // device copy of the table (written by k_mv_group)
+  MvGroup* groups;    // [M][views]
+  uint32_t* grp_chunks;  // [M] chunks of all groups of the instance
+  uint32_t* inst_step0;  // [M] exclusive prefix
+  uint32_t* step_total;  // [2]
+  uint2* steps;          // [total] {mesh instance, group | chunk << 8}
+  uint32_t* tickets;
+};
+void launch_mv_setup(const MvArgs& a, const MvBlob& blob, uint32_t grid, hipStream_t s);  // groups, chunk numbering, step list
+void launch_mv_test(const MvArgs& a, uint32_t num_cus, hipStream_t s);
+void launch_mv_emit(const MvArgs& a, uint32_t max_chunks_per_view, uint32_t max_grid, hipStream_t s);
+
 struct HizArgs {
   const float* depth;
   float* hiz;

@@ -54,7 +54,7 @@ struct alignas(64) InstCache {
   uint32_t _pad0[3];
   // dwords 64..95 (second load)
   float nm[9];             // 64..72: TransformWorld::normal_matrix(), column-major (scene.slang:292-299)
-  float _pad1;             // 73
+  uint32_t transform_index;  // 73: MeshInstance::transform_index (the multi-view meshlet test groups the views that share it)
   float world2[3][2];      // 74..79: world2[c][k] = world(row k, col c), rows 0 and 1 side by side
   float world_t2[2];       // 80..81: world(row 0, col 3), world(row 1, col 3)
   float world_r2[4];       // 82..85: row 2 of world
@@ -68,7 +68,7 @@ static_assert(sizeof(InstCache) == 384, "layout");
 // dword offsets of the fields: what the kernels' scalar loads index
 enum : int {
   kRowPlanes = 0, kRowSigns = 24, kRowVisOffset = 42, kRowMeshletCount = 43, kRowMvp = 44, kRowScale = 60,
-  kRowNm = 64, kRowWorld2 = 74, kRowWorldT2 = 80, kRowWorldR2 = 82, kRowBounds = 86,
+  kRowNm = 64, kRowTransformIndex = 73, kRowWorld2 = 74, kRowWorldT2 = 80, kRowWorldR2 = 82, kRowBounds = 86,
 };
 static_assert(offsetof(InstCache, signs2) == kRowSigns * 4 && offsetof(InstCache, vis_offset) == kRowVisOffset * 4 &&
               offsetof(InstCache, mvp) == kRowMvp * 4 && offsetof(InstCache, scale_max) == kRowScale * 4 &&

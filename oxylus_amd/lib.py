@@ -362,7 +362,7 @@ class KernelTimes(C.Structure):
 KERNEL_NAMES = ["prepare_instances", "cull_meshes_scan", "cull_meshes_expand", "cull_meshlets_test", "cull_meshlets_emit",
                 "cull_triangles_test", "cull_triangles_emit", "hiz", "cull_meshlets_test_late", "cull_meshlets_emit_late",
                 "cull_triangles_test_late", "cull_triangles_emit_late", "draw_visbuffer", "build_meshlet_bounds",
-                "_14", "_15"]
+                "multiview_setup", "_15"]
 
 
 class OxcError(RuntimeError):
