@@ -166,6 +166,52 @@ def test_config5_full_size_properties(renderer, oracle_lib):
         assert torch.equal(frame.visible_meshlet_instances_indices_buffer[:c.cull_triangles_cmd_x].cpu(), got[v]["visible"])
 
 
+@pytest.mark.parametrize("views,move_cameras,cap_frac", [(2, False, 1.0), (5, True, 1.0), (16, True, 1.0), (7, False, 0.4)],
+                         ids=["2-views", "5-views-own-positions", "16-views-own-positions", "7-views-short-lists"])
+def test_multiview_batch_equals_single_calls(renderer, oracle_lib, views, move_cameras, cap_frac):
+    """The batched views of one scene take the one-pass multi-view meshlet stage; every element's outputs -- the LOD-selected
+    MeshletInstance list, the visible list, the counters -- must equal what a single oxc_cull_geometry call of that view writes.  Own camera
+    positions per view (the normal cone is then evaluated per view), a view that sees nothing, and lists cut short by the caller's
+    buffers (max_meshlet_instance_count smaller than what cull_meshes emits) included."""
+    import dataclasses
+
+    gpu = make_scene(SceneSpec(n_mesh_instances=700, meshlets_per_mesh=150, lod_count=3, seed=0x0A1DE5 + 9, with_geometry=False), "cuda")
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+    cams = _cascade_cameras(gpu, views)
+    if move_cameras:
+        for v, cam in enumerate(cams):
+            cam.position[0], cam.position[1], cam.position[2] = 3.0 * v, -2.0 * v, -60.0 + 11.0 * v
+        for k in range(16):  # the last view looks away from everything: no instance survives its cull_meshes
+            cams[-1].projection_view[k] = float(gpu.cull_camera().projection_view[k]) * (-1.0 if k % 4 == 2 else 1.0)
+    cap = max(64, int(gpu.n_meshlet_instances * cap_frac))
+
+    def frame_of(e):
+        f = PreparedFrame.create(gpu if e == 0 else dataclasses.replace(gpu, mesh_instances=gpu.mesh_instances.clone()), with_triangles=False, expand=False)
+        if cap_frac < 1.0:
+            f.max_meshlet_instance_count = cap
+        return f
+
+    frames = [frame_of(e) for e in range(views)]
+    ctxs = [CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cam, stages=L.STAGE_MESHES | L.STAGE_MESHLETS) for cam in cams]
+    renderer.cull_geometry_batch(frames, ctxs)
+    nonempty = 0
+    for v in range(views):
+        got = renderer.read_counters(ctxs[v])
+        single = frame_of(1)
+        renderer.prepared_frame = single
+        c1 = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cams[v], stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+        renderer.cull_geometry(c1)
+        want = renderer.read_counters(c1)
+        assert (got.total_visible_meshlet_instances, got.cull_triangles_cmd_x) == (want.total_visible_meshlet_instances, want.cull_triangles_cmd_x), f"view {v}"
+        n, e = want.total_visible_meshlet_instances, want.cull_triangles_cmd_x
+        assert torch.equal(frames[v].meshlet_instances_buffer[:n], single.meshlet_instances_buffer[:n]), f"view {v}: expansion differs"
+        assert torch.equal(frames[v].visible_meshlet_instances_indices_buffer[:e], single.visible_meshlet_instances_indices_buffer[:e]), f"view {v}: visible list differs"
+        nonempty += int(e > 0)
+        if cap_frac < 1.0:
+            assert n <= cap
+    assert nonempty >= 2
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # opt-in small-triangle cull (include/oxcull.h: oxc_cull_geometry_context::small_triangle_cull)
 # ------------------------------------------------------------------------------------------------------------------
