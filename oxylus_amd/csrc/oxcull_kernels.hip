@@ -553,7 +553,8 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   __shared__ uint32_t s_level_off[13];
   __shared__ uint32_t s_lds_off[13];
   __shared__ float s_hiz_top[kHizLdsTexels];
-  __shared__ uint4 s_strip[OCCL_OR_LATE ? kWaves : 1][G * 64];  // occlusion candidates of one round, per wave
+  __shared__ uint4 s_strip[OCCL_OR_LATE ? kWaves : 1][G * 64];  // frustum survivors (then cone survivors) of one round, per wave
+  __shared__ uint32_t s_flags[OCCL_OR_LATE ? kWaves : 1][G * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
@@ -680,8 +681,94 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
           st[j] = mine[j] ? ((vis ? 2u : 0u) | (was_visible ? 4u : 0u)) : st[j];
         }
       }
-      // ---- phase 2: normal cone
-      if (any_need) {
+      // ---- phases 2 + 3: normal cone, then occlusion against the pyramid (cull_meshlets_hiz.slang:52-66).  Both run on DENSE lanes:
+      // the frustum survivors of the round's G groups (10-40 % of the lanes) are compacted through a per-wave LDS strip, the cone test
+      // runs over ceil(survivors / 64) batches and compacts ITS survivors in place (a survivor's record moves to a position at or below
+      // its own, behind what the batch has already read), and the occlusion test -- 8 projected corners, 24 divisions: by far the longest
+      // piece of straight-line code -- runs over ceil(cone survivors / 64) batches.  Round 2 ran the cone test once per group on sparse
+      // lanes (4 passes per step) and compacted only in front of the occlusion test; compacting once and running cone + occlusion back to
+      // back on the frustum survivors was measured too and is slower (more occlusion passes: 78 -> 83 / 102 -> 108 us).  All lanes of a
+      // round share the instance, hence the cone and mvp operands.
+      if constexpr (OCCL_OR_LATE) {
+        uint64_t vb[G];
+        uint32_t base[G + 1];
+        base[0] = 0;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          vb[j] = __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
+          base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)vb[j]);
+        }
+        const uint32_t total = base[G];
+        if (total) {
+          uint4* strip = s_strip[wave];
+          uint32_t* flg = s_flags[wave];  // per frustum survivor (strip position): still visible?
+          uint32_t slot[G];
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb[j], 0u));
+            if ((vb[j] >> lane) & 1ull) strip[slot[j]] = bnd[j];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
+          ConeU cu;
+#pragma unroll
+          for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
+#pragma unroll
+          for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
+#pragma unroll
+          for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
+#pragma unroll
+          for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
+          cu.scale_max = asf(row[kRowScale]);
+          uint32_t nb = 0;  // cone survivors so far: they occupy strip[0 .. nb)
+          for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const bool act = t < total;
+            const uint4 b = strip[act ? t : total - 1u];
+            bool ok = act;
+            const bool nc = act && ((int32_t)b.w >> 24) != 127;  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
+            if (__builtin_amdgcn_ballot_w64(nc)) {
+              const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
+              const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
+              const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
+              const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
+              const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
+              bool cone_ok = tier1 == 1;
+              if (__builtin_amdgcn_ballot_w64(nc && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
+                const bool exact = cone_visible(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
+                cone_ok = tier1 == 2 ? exact : cone_ok;
+              }
+              ok = nc ? cone_ok : ok;
+            }
+            const uint64_t okb = __builtin_amdgcn_ballot_w64(ok);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(okb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okb, 0u));
+            if (act) flg[t] = ok ? 1u : 0u;
+            // (nb + rank <= t, and every lane of this batch has read its record: the LDS queue of a wave is in order)
+            if (ok) strip[nb + rank] = make_uint4(b.x, b.y, b.z, (b.w & 0x00FFFFFFu) | (t << 24));  // the cutoff byte now carries the survivor's strip position
+            nb += (uint32_t)__popcll((unsigned long long)okb);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (nb) {
+            float mvp[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) mvp[k] = asf(row[kRowMvp + k]);
+            for (uint32_t u0 = 0; u0 < nb; u0 += 64) {
+              const uint32_t u = u0 + (uint32_t)lane;
+              const bool act = u < nb;
+              const uint4 b = strip[act ? u : nb - 1u];
+              const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
+              const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
+              const bool occluded = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, act);
+              if (act && occluded) flg[b.w >> 24] = 0u;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            if ((vb[j] >> lane) & 1ull) st[j] = flg[slot[j]] ? st[j] : (st[j] & ~2u);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip and flags are rewritten by the next round
+        }
+      } else if (any_need) {  // no occlusion phase: the cone test where it stands, one pass per group that needs it
         ConeU cu;
 #pragma unroll
         for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
@@ -696,66 +783,18 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
         for (int j = 0; j < G; j++) {
           if (__builtin_amdgcn_ballot_w64(need[j] != 0u) == 0) continue;  // wave-uniform
           uint4 b = bnd[j];
-          // decode again instead of keeping phase 1's 24 floats alive across the phase boundary (see meshlets_plain_body): 103 / 116 -> 89
-          // VGPRs, 5 waves per SIMD (measured -2 us per launch; also recomputing the mask index, 81 VGPRs, costs more than it gives)
-          asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+          asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));  // decode again instead of keeping phase 1's floats alive (see meshlets_plain_body)
           const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
           const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
           const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
           const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
           const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
           bool cone_ok = tier1 == 1;
-          if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
+          if (__builtin_amdgcn_ballot_w64(need[j] != 0u && tier1 == 2)) {
             const bool exact = cone_visible(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
             cone_ok = tier1 == 2 ? exact : cone_ok;
           }
           st[j] = (need[j] != 0u && !cone_ok) ? (st[j] & ~2u) : st[j];
-        }
-      }
-      // ---- phase 3: occlusion against the pyramid (cull_meshlets_hiz.slang:56-66).  Only the survivors
-      // of phases 1-2 need it (typically 5-25 % of the lanes), and it is by far the longest piece of
-      // straight-line code (8 projected corners, 24 IEEE divisions), so the survivors of the round's G
-      // groups are first compacted into dense lanes through a per-wave LDS strip: the occlusion code
-      // then runs ceil(survivors / 64) times instead of once per group with mostly idle lanes.  All
-      // lanes of a round share the instance, hence the mvp operands.
-      if (OCCL_OR_LATE) {
-        uint64_t vb[G];
-        uint32_t base[G + 1];
-        base[0] = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          vb[j] = __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
-          base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)vb[j]);
-        }
-        const uint32_t total = base[G];
-        if (total) {
-          float mvp[16];
-#pragma unroll
-          for (int k = 0; k < 16; k++) mvp[k] = asf(row[kRowMvp + k]);
-          uint4* strip = s_strip[wave];
-          uint32_t slot[G];
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb[j], 0u));
-            if ((vb[j] >> lane) & 1ull) strip[slot[j]] = bnd[j];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
-          for (uint32_t t0 = 0; t0 < total; t0 += 64) {
-            const uint32_t t = t0 + (uint32_t)lane;
-            const bool act = t < total;
-            const uint4 b = strip[act ? t : total - 1u];
-            const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
-            const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-            const bool occluded = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, act);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (act) strip[t].x = occluded ? 1u : 0u;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            if ((vb[j] >> lane) & 1ull) st[j] = strip[slot[j]].x ? (st[j] & ~2u) : st[j];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next round
         }
       }
     }
