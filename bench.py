@@ -269,18 +269,45 @@ def profile_kernels(e, renderers, run, n: int) -> dict:
     return out
 
 
-def pmc_traffic(profile_name: str, match) -> tuple:
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate
-    passes, as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", profile_name)) as f:
-            pm = json.load(f)
-        vals = [cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0) for k, cs in pm.get("pmc", {}).items() if match(k) and "hbm_read_bytes_corrected" in cs]
-        if vals:
-            return round(sum(vals) / len(vals)), f"profiles/{profile_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)"
-    except (OSError, KeyError, ValueError):
-        pass
+def kernel_source_sha16() -> str:
+    """sha256 over oxylus_amd/csrc/*.hip|*.hpp: what tools/summarize_profiles.py stamps into a committed profile."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "oxylus_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "oxylus_amd", "csrc", "*.hpp"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(names):
+    for n in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", n)) as f:
+                return n, json.load(f)
+        except (OSError, ValueError):
+            continue
     return None, None
+
+
+def pmc_traffic(profile_names, match) -> tuple:
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate
+    passes, as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the figure belongs to the
+    build the profile was taken from: the third value says whether that is the device code of this tree (kernel_source_sha16)."""
+    name, pm = committed_profile([profile_names] if isinstance(profile_names, str) else profile_names)
+    if pm is None:
+        return None, None, None
+    vals = [cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0) for k, cs in pm.get("pmc", {}).items() if match(k) and "hbm_read_bytes_corrected" in cs]
+    if not vals:
+        return None, None, None
+    same = pm.get("kernel_source_sha16") == kernel_source_sha16() if pm.get("kernel_source_sha16") else None
+    return round(sum(vals) / len(vals)), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)", same
+
+
+def rocprof_kernel_us(profile_names) -> dict:
+    """Average kernel durations of the committed rocprofv3 --kernel-trace --stats summary: the second clock beside the HIP-event times."""
+    _, pm = committed_profile([profile_names] if isinstance(profile_names, str) else profile_names)
+    return {r["kernel"]: r["avg_us"] for r in (pm or {}).get("kernel_trace_stats", [])}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -314,7 +341,7 @@ def bench_config3(args, e):
         r.reserve(M, n_meshlets)
         frame = PreparedFrame.create(scene, with_triangles=True, max_tris=128 if wide else 64)
         depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))  # the same image on every rank
-        hiz = [ImageAttachment.hiz(HW, HW, dev) for _ in range(2 if (world > 1 and not args.no_overlap) else 1)]
+        hiz = [ImageAttachment.hiz(HW, HW, dev) for _ in range(2)]  # double-buffered: the pyramid of the next frame can be built beside the cull of this one
         ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz[0],
                                   stages=L.STAGE_ALL, wide_triangle_index=wide, small_triangle_cull=args.small_triangle_cull)
         r.prepared_frame = frame
@@ -353,34 +380,40 @@ def bench_config3(args, e):
     hiz_wire_bytes = wire_bytes(xmode["top"])
 
     # ---- multi-GPU plumbing: second context + stream for the pyramid producer, events, counter all-gather ----
-    overlap = world > 1 and not args.no_overlap
-    r_hiz, comm_stream, ev_ready, ev_free = r, stream, None, None
-    if overlap:
-        r_hiz = RendererInstance(e.local_rank)  # its own context: the producer runs beside the cull (one context = one ordered queue)
-        if e.native_comm:  # ... and its own communicator: the broadcast must not queue behind the cull context's calls
-            box = [r_hiz.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            r_hiz.comm_init(box[0], rank, world)
-        comm_stream = torch.cuda.Stream(device=dev)
-        ev_ready = [torch.cuda.Event() for _ in hiz]
-        ev_free = [torch.cuda.Event() for _ in hiz]
+    # "one frame ahead": the pyramid a frame culls against is given (the prior frame's), so its build (+ broadcast) can run on a second
+    # stream beside the previous frame's cull.  Default for N > 1 (the exchange must not sit in the frame); at N = 1 the main line keeps
+    # the strict in-order frame on one stream and the pipelined form is timed as a variant (scheduling_ab).
+    use_overlap = [world > 1 and not args.no_overlap]
+    overlap = use_overlap[0]
+    r_hiz = RendererInstance(e.local_rank)  # its own context: the producer runs beside the cull (one context = one ordered queue)
+    if e.native_comm:  # ... and its own communicator: the broadcast must not queue behind the cull context's calls
+        box = [r_hiz.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        r_hiz.comm_init(box[0], rank, world)
+    comm_stream = torch.cuda.Stream(device=dev)
+    ev_ready = [torch.cuda.Event() for _ in hiz]
+    ev_free = [torch.cuda.Event() for _ in hiz]
+    have_free = [False for _ in hiz]
+    primed = [False]
     if world > 1:
         my_counts = torch.zeros(4, dtype=torch.int32, device=dev)
         gathered = torch.zeros(world * 4, dtype=torch.int32, device=dev)
     csp = C.c_void_p(comm_stream.cuda_stream)
 
-    def produce_hiz(b):
-        """Rank 0 builds pyramid buffer b from the depth image; everybody receives it (RCCL broadcast over xGMI)."""
+    def produce_hiz(b, ahead):
+        """Rank 0 builds pyramid buffer b from the depth image; everybody receives it (RCCL broadcast over xGMI).  ahead: on the second
+        stream with the producer's own context; otherwise in order on the cull stream with the cull context."""
         top = xmode["top"]
+        rr, st_, sp_ = (r_hiz, comm_stream, csp) if ahead else (r, stream, sp)
         if rank == 0 or top:  # 'top': the other ranks build levels < k_top from their own copy of the depth image
-            st = r_hiz._lib.oxc_generate_hiz(r_hiz._ctx, C.byref(mgs[b] if rank == 0 else mgs_low[b]), csp)
+            st = rr._lib.oxc_generate_hiz(rr._ctx, C.byref(mgs[b] if rank == 0 else mgs_low[b]), sp_)
             if st != L.OXC_OK:
-                raise RuntimeError(r_hiz._lib.oxc_last_error(r_hiz._ctx).decode())
+                raise RuntimeError(rr._lib.oxc_last_error(rr._ctx).decode())
         if dist is not None:
             if e.native_comm:
-                r_hiz.broadcast_hiz(hiz[b], 0, comm_stream, first_level=k_top if top else 0)
+                r_hiz.broadcast_hiz(hiz[b], 0, st_, first_level=k_top if top else 0)
             else:
-                with torch.cuda.stream(comm_stream):
+                with torch.cuda.stream(st_):
                     dist.broadcast(hiz[b].data[hiz[b].level_offset[k_top] // 4:] if top else hiz[b].data, src=0)
 
     def gather_counts(c):
@@ -405,19 +438,24 @@ def bench_config3(args, e):
         frame_no[0] += 1
         b = f % len(hiz)
         mask.copy_(mask0, non_blocking=True)  # restore the synthetic prior-visibility mask (1.25 MB copy)
-        if overlap:
-            if f == 0:
-                produce_hiz(0)
-                ev_ready[0].record(comm_stream)
+        if use_overlap[0]:
+            if not primed[0]:  # entering the pipelined form: this frame's own pyramid first
+                comm_stream.wait_stream(stream)
+                produce_hiz(b, True)
+                ev_ready[b].record(comm_stream)
+                primed[0] = True
             # next frame's pyramid: produced now, on the side stream, into the other buffer (free once frame f-1 has culled)
             nb = (f + 1) % len(hiz)
-            if f >= 1:
+            if have_free[nb]:
                 comm_stream.wait_event(ev_free[nb])
-            produce_hiz(nb)
+            produce_hiz(nb, True)
             ev_ready[nb].record(comm_stream)
             stream.wait_event(ev_ready[b])
         else:
-            produce_hiz(b)  # (comm_stream is the cull stream here)
+            if primed[0]:  # leaving the pipelined form: nothing of the producer may still be in flight
+                stream.wait_stream(comm_stream)
+                primed[0] = False
+            produce_hiz(b, False)
         c = cctx[b]
         c.async_triangles = int(use_async[0])
         c.cull_flags = L.CULL_TEST_ALL
@@ -428,8 +466,9 @@ def bench_config3(args, e):
         check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
         if record is not None:
             record("late", c)
-        if overlap:
+        if use_overlap[0]:
             ev_free[b].record(stream)
+            have_free[b] = True
         if world > 1:
             gather_counts(c)
 
@@ -488,17 +527,31 @@ def bench_config3(args, e):
     value = n_meshlets * world * frames / elapsed
     sum_main = outputs_checksum()
 
-    # ---- the same frames with the other scheduling (async_triangles on <-> off), a short run: what overlapping the HBM-bound triangle
-    # stage with the next call's ALU-bound meshlet stage / the next frame's HiZ build is worth on this box ----
-    use_async[0] = not use_async[0]
+    # ---- the same frames under other schedulings, short runs: (a) async_triangles flipped -- the triangle stage of a call on the context's
+    # own stream beside the next call's meshlet stage / the next HiZ build; (b, N = 1) the pyramid of the NEXT frame built on a second
+    # stream beside this frame's cull (what N > 1 does by default); (c) both.  Every variant must leave the outputs of the in-order run.
     ab_steps = max(2, args.steps // 4)
-    el_ab = timed_steps(e, run_step, ab_steps, 1)
-    sum_ab = outputs_checksum()
-    use_async[0] = not use_async[0]
-    sched_ab = {"async_triangles": not use_async[0], "ms_per_frame": round(el_ab * 1e3 / (ab_steps * inner), 6), "value": round(n_meshlets * world * ab_steps * inner / el_ab, 1),
-                "frames_timed": ab_steps * inner, "outputs_match_main_line": sum_ab == sum_main,
-                "note": "triangle stages on the context's own stream (hipStreamWaitEvent fork / join inside liboxcull), meshlet test grids cut to "
-                        "leave wave slots: frames pipeline without a host synchronisation; all outputs folded into checksums and compared with the in-order run"}
+
+    def timed_variant(async_on, ahead_on):
+        use_async[0], use_overlap[0] = async_on, ahead_on
+        el = timed_steps(e, run_step, ab_steps, 1)
+        return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
+                "value": round(n_meshlets * world * ab_steps * inner / el, 1), "frames_timed": ab_steps * inner, "outputs_match_main_line": outputs_checksum() == sum_main}
+
+    main_async, main_ahead = use_async[0], use_overlap[0]
+    variants = [timed_variant(not main_async, main_ahead)]
+    if world == 1:
+        variants.append(timed_variant(main_async, not main_ahead))
+        variants.append(timed_variant(not main_async, not main_ahead))
+    use_async[0], use_overlap[0] = main_async, main_ahead
+    with torch.cuda.stream(stream):
+        run_frame()  # (back in the main line's form before the kernel profile below)
+    torch.cuda.synchronize()
+    sched_ab = {"main_line": {"async_triangles": main_async, "hiz_one_frame_ahead_on_second_stream": main_ahead, "ms_per_frame": round(ms_per_frame, 6)},
+                "variants": variants,
+                "note": "async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "
+                        "events both ways, double-buffered pyramid -- legal here because the depth image a frame's pyramid is built from is given; in the engine the "
+                        "pyramid is built from the early draw's depth between the two culls of a frame (RendererInstance.cpp:842-884), which is why the main line stays in order"}
 
     # ---- N > 1: the other --hiz-exchange form, a short run, so that one multi-GPU run decides between them ----
     exchange_ab = None
@@ -515,7 +568,7 @@ def bench_config3(args, e):
 
     # ---- per-kernel times (>= 50 launches each) and rooflines: algorithmic bytes of SURVEY 8d ----
     n_prof = max(50, min(inner, 96))
-    renderers = [r] + ([r_hiz] if r_hiz is not r else [])
+    renderers = [r, r_hiz]
     kern = profile_kernels(e, renderers, lambda i: run_frame(), n_prof)
     tri_bytes_per_meshlet = 4 + 8 + 16 + (3 * args.tris + 3) // 4 * 4 + 4 * 64 + 8 * 64  # 988 B (V=64, T=64), SURVEY 8d a11
     H = 2 if wide else 1
@@ -533,6 +586,14 @@ def bench_config3(args, e):
         "cull_triangles_emit": v_early * (8.0 * H + 4.0) + 12.0 * t_early,
         "cull_triangles_emit_late": v_late * (8.0 * H + 4.0) + 12.0 * t_late,
     }
+    # the second clock: the committed rocprofv3 --kernel-trace --stats averages of the same kernels (of the build the profile was taken
+    # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
+    rp = rocprof_kernel_us(["r03_config3_pmc.json", "r02_config3_pmc.json"])
+    rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
+                "cull_meshlets_test": ["oxc::k_cull_meshlets_test<true, true, false, 4>"], "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test<true, true, true, 4>"],
+                "cull_meshlets_emit": ["oxc::k_cull_meshlets_emit<true, false>"], "cull_meshlets_emit_late": ["oxc::k_cull_meshlets_emit<true, true>"],
+                "cull_triangles_test": ["oxc::k_cull_triangles_test<false, false, false>"], "cull_triangles_test_late": ["oxc::k_cull_triangles_test<true, false, false>"],
+                "cull_triangles_emit": ["oxc::k_cull_triangles_emit<false, false>"], "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit<true, false>"]}
     kernels, frame_alg, frame_kernel_us = {}, 0.0, 0.0
     for name, k in kern.items():
         if name.startswith("_"):
@@ -540,6 +601,8 @@ def bench_config3(args, e):
             continue
         per_frame = k["launches"] / n_prof
         ent = {"launches_per_frame": round(per_frame, 3), "launches_timed": k["launches"], "avg_us": round(k["avg_us"], 3)}
+        if all(n in rp for n in rp_names.get(name, ["?"])):
+            ent["kernel_avg_us_rocprof"] = round(sum(rp[n] for n in rp_names[name]), 3)
         b = alg.get(name)
         if b is not None:
             ent["algorithmic_bytes_per_launch"] = round(b)
@@ -556,10 +619,10 @@ def bench_config3(args, e):
         dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
         dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic("r02_config3_pmc.json", lambda k: "k_cull_triangles_test" in k)
+        traffic, traffic_src, traffic_same = pmc_traffic(["r03_config3_pmc.json", "r02_config3_pmc.json"], lambda k: "k_cull_triangles_test" in k)
         roofline = {"bound": "hbm", "kernel": "k_cull_triangles_test (early + late launch of a frame, averaged)", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
+                    "traffic_profile_is_of_this_device_code": traffic_same, "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
                     "launches_averaged": sum(k["launches"] for k in tt), "measured_stream_read_GBps": round(stream_gbps, 1),
                     "frac_of_measured_stream_read": round(achieved / stream_gbps, 4)}
     stage = {"algorithmic_bytes_per_frame": round(frame_alg), "ms_per_frame": round(ms_per_frame, 6),
@@ -693,7 +756,7 @@ def bench_config3(args, e):
             "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
             "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
                                                          "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if xmode["top"] else "whole pyramid broadcast from rank 0"),
-                                                         "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": overlap,
+                                                         "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": use_overlap[0],
                                                          "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame, "hiz_exchange_ab": exchange_ab},
             "async_triangles": bool(use_async[0]),
         },
@@ -834,11 +897,10 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
         bytes_per_launch = n_meshlets * batch * (24.0 + 212.0 / K + 0.125)
         us = kern["cull_meshlets_test"]["avg_us"]
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
-        traffic, src = pmc_traffic("r02_config2_pmc.json", lambda k: "k_cull_meshlets_test_batch" in k)
-        if traffic is None:
-            traffic, src = pmc_traffic("r01_config2_pmc.json", lambda k: "k_cull_meshlets_test_batch" in k)
+        traffic, src, traffic_same = pmc_traffic(["r03_config2_pmc.json", "r02_config2_pmc.json", "r01_config2_pmc.json"], lambda k: "k_cull_meshlets_test_batch" in k)
         roofline = {"bound": "hbm", "kernel": f"k_cull_meshlets_test_batch ({batch} frames per launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, "traffic_profile_is_of_this_device_code": traffic_same,
+                    "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "kernel_avg_us": round(us, 3), "launches_averaged": kern["cull_meshlets_test"]["launches"], "measured_stream_read_GBps": round(stream_gbps, 1),
                     "frac_of_measured_stream_read": round(achieved / stream_gbps, 4)}
         stage_bytes = n_meshlets * (24.0 + 212.0 / K + 4.0 * visible_fraction)

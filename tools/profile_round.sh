@@ -3,7 +3,7 @@
 # configs[1], condensed by tools/summarize_profiles.py into gpurun_out/profiles_out/ (raw CSVs are deleted: they exceed what gpurun
 # copies back).  Copy the JSONs into profiles/ afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 rm -rf gpurun_out/raw; mkdir -p gpurun_out/raw gpurun_out/profiles_out
@@ -18,5 +18,7 @@ python tools/summarize_profiles.py ${TAG}_config2_pmc --stats $(find gpurun_out/
   --note "bench.py --workload config2 (1M meshlets x 48 rotating copies), --streams 1, 16 frames per launch; kernel_trace_stats from rocprofv3 --kernel-trace --stats, pmc from separate --pmc passes"
 cp gpurun_out/raw/trace_c2/bench.json gpurun_out/profiles_out/${TAG}_config2_trace_bench.json
 mv profiles/${TAG}_config2_pmc.json profiles/${TAG}_config3_pmc.json gpurun_out/profiles_out/ 2>/dev/null
+# the same frames with async_triangles: a kernel trace with timestamps, condensed to who ran beside whom
+./tools/async_trace.sh ${TAG} > /dev/null
 rm -rf gpurun_out/raw
 ls -la gpurun_out/profiles_out

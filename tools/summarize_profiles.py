@@ -46,6 +46,18 @@ def pmc(dirpath):
     return out
 
 
+def kernel_source_sha16():
+    """Identifies the device code a profile belongs to: sha256 over oxylus_amd/csrc/*.hip|*.hpp (bench.py compares it with the tree it runs from)."""
+    import glob
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "oxylus_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "oxylus_amd", "csrc", "*.hpp"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
@@ -53,7 +65,7 @@ def main():
     ap.add_argument("--pmc")
     ap.add_argument("--note", default="")
     a = ap.parse_args()
-    doc = {"tag": a.tag, "note": a.note}
+    doc = {"tag": a.tag, "note": a.note, "kernel_source_sha16": kernel_source_sha16()}
     if a.stats:
         doc["kernel_trace_stats"] = kernel_stats(a.stats)
         doc["kernel_trace_source"] = a.stats
