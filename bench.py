@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--async-triangles", action="store_true",
                     help="config3: time the main line with async_triangles = 1 (triangle stages on the context's own stream, frames pipeline); the default line is in "
                          "order on one stream and carries the pipelined figure as the nested object \"async_triangles\"")
+    ap.add_argument("--no-scheduling-ab", action="store_true", help="config3: skip the short timed runs of the other schedulings (profiling runs: their concurrent kernels would "
+                                                                    "be averaged into the per-kernel durations of a kernel trace)")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the short timed run with the other --hiz-exchange form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: build + broadcast the pyramid on the cull stream instead of one frame ahead on a second stream")
@@ -539,14 +541,16 @@ def bench_config3(args, e):
                 "value": round(n_meshlets * world * ab_steps * inner / el, 1), "frames_timed": ab_steps * inner, "outputs_match_main_line": outputs_checksum() == sum_main}
 
     main_async, main_ahead = use_async[0], use_overlap[0]
-    variants = [timed_variant(not main_async, main_ahead)]
-    if world == 1:
-        variants.append(timed_variant(main_async, not main_ahead))
-        variants.append(timed_variant(not main_async, not main_ahead))
-    use_async[0], use_overlap[0] = main_async, main_ahead
-    with torch.cuda.stream(stream):
-        run_frame()  # (back in the main line's form before the kernel profile below)
-    torch.cuda.synchronize()
+    variants = []
+    if not args.no_scheduling_ab:
+        variants.append(timed_variant(not main_async, main_ahead))
+        if world == 1:
+            variants.append(timed_variant(main_async, not main_ahead))
+            variants.append(timed_variant(not main_async, not main_ahead))
+        use_async[0], use_overlap[0] = main_async, main_ahead
+        with torch.cuda.stream(stream):
+            run_frame()  # (back in the main line's form before the kernel profile below)
+        torch.cuda.synchronize()
     sched_ab = {"main_line": {"async_triangles": main_async, "hiz_one_frame_ahead_on_second_stream": main_ahead, "ms_per_frame": round(ms_per_frame, 6)},
                 "variants": variants,
                 "note": "async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "

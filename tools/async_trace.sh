@@ -48,8 +48,8 @@ per = {n: {"launches": sum(1 for r in rows if r[2] == n), "avg_us": round(sum(r[
            "fraction_of_its_time_beside_another_kernel": round(shared[n] / max(1, shared[n] + alone[n]), 3)} for n in sorted({r[2] for r in rows})}
 bench = json.load(open(sys.argv[2]))
 doc = {"tag": sys.argv[3].split("/")[-1][:-5], "source": "rocprofv3 --kernel-trace (timestamps) of bench.py --async-triangles --steps 2 --warmup 1 --inner-reps 16; last two thirds of the launches",
-       "queues_seen": queues, "ms_per_frame_async": bench["config"]["ms_per_frame"], "in_order_ms_per_frame_same_run": bench["scheduling_ab"]["ms_per_frame"],
-       "outputs_match": bench["scheduling_ab"]["outputs_match_main_line"], "span_ms": round(span / 1e6, 3),
+       "queues_seen": queues, "ms_per_frame_async": bench["config"]["ms_per_frame"], "in_order_ms_per_frame_same_run": next((v["ms_per_frame"] for v in bench["scheduling_ab"]["variants"] if not v["async_triangles"] and not v["hiz_one_frame_ahead_on_second_stream"]), None),
+       "outputs_match": all(v["outputs_match_main_line"] for v in bench["scheduling_ab"]["variants"]), "span_ms": round(span / 1e6, 3),
        "time_with_two_or_more_kernels_running_ms": round(sum(pair.values()) / 1e6, 3), "kernels": per,
        "pairs_running_side_by_side_ms": {k: round(v / 1e6, 3) for k, v in pair.most_common(12)}}
 json.dump(doc, open(sys.argv[3], "w"), indent=1)
