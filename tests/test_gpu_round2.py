@@ -212,6 +212,35 @@ def test_multiview_batch_equals_single_calls(renderer, oracle_lib, views, move_c
     assert nonempty >= 2
 
 
+def test_multiview_batch_with_the_triangle_stage(renderer, oracle_lib):
+    """Three views of one scene with every stage: the per-view triangle kernels consume the visible lists the multi-view meshlet stage
+    wrote; packed indices and draw commands must equal those of single calls."""
+    import dataclasses
+
+    gpu = make_scene(SceneSpec(n_mesh_instances=300, meshlets_per_mesh=120, lod_count=2, seed=0x0A1DE5 + 11, with_geometry=True), "cuda")
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+    cams = _cascade_cameras(gpu, 6)[3:]
+
+    def frame_of(e):
+        return PreparedFrame.create(gpu if e == 0 else dataclasses.replace(gpu, mesh_instances=gpu.mesh_instances.clone()), with_triangles=True, expand=False)
+
+    frames = [frame_of(e) for e in range(3)]
+    ctxs = [CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cam, stages=L.STAGE_ALL) for cam in cams]
+    renderer.cull_geometry_batch(frames, ctxs)
+    emitted = 0
+    for v in range(3):
+        got = renderer.read_counters(ctxs[v])
+        single = frame_of(1)
+        renderer.prepared_frame = single
+        c1 = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cams[v], stages=L.STAGE_ALL)
+        renderer.cull_geometry(c1)
+        want = renderer.read_counters(c1)
+        assert (got.cull_triangles_cmd_x, got.draw_index_count) == (want.cull_triangles_cmd_x, want.draw_index_count), f"view {v}"
+        assert torch.equal(frames[v].reordered_indices_buffer[:want.draw_index_count], single.reordered_indices_buffer[:want.draw_index_count]), f"view {v}: packed indices differ"
+        emitted += want.draw_index_count
+    assert emitted > 10_000
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # opt-in small-triangle cull (include/oxcull.h: oxc_cull_geometry_context::small_triangle_cull)
 # ------------------------------------------------------------------------------------------------------------------
