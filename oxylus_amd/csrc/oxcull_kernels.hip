@@ -799,6 +799,42 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       }
     }
     // ---- mask update, ballots, per-wave survivor count
+    // The usual step is 64 * G consecutive meshlets of one instance: its mask bits are ONE run of 64 * G bits at bit offset d0 -- 2 G
+    // whole words (+ one partial word at either end when d0 is not a multiple of 32).  Lane k builds word k from the G visibility
+    // ballots and the run is written in one go, instead of once per 64-meshlet group through update_visibility_mask (~40 VALU
+    // instructions each, 13 % of a late step's instructions).  Same stores / atomics as the per-group path would issue, merged.
+    // Late pass only: measured 99.5 -> 97.0 us there and 74.4 -> 75.2 us in the early pass (more SGPR spills than instructions saved).
+    bool step_run = false;
+    if (OCCL && LATE && G == 4 && (group0 + G) * 64u <= N) {  // (wave-uniform)
+      const uint32_t d0 = readfirst_u(mask_idx[0]);
+      uint64_t bad = 0;
+#pragma unroll
+      for (int j = 0; j < G; j++) bad |= __builtin_amdgcn_ballot_w64(mask_idx[j] != d0 + 64u * (uint32_t)j + (uint32_t)lane);  // (kMaskNone lanes differ)
+      if (bad == 0ull && d0 <= 0xFFFFFFFFu - 64u * G) {
+        step_run = true;
+        uint32_t cur = 0, prev = 0;  // lane k: dword k of the run's G * 64 visibility bits, and dword k - 1
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          const uint64_t vb = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u);
+          cur = lane == 2 * j ? (uint32_t)vb : (lane == 2 * j + 1 ? (uint32_t)(vb >> 32) : cur);
+          prev = lane == 2 * j + 1 ? (uint32_t)vb : (lane == 2 * j + 2 ? (uint32_t)(vb >> 32) : prev);
+        }
+        const uint32_t sh = d0 & 31u, w0 = d0 >> 5;
+        if (sh == 0u) {
+          if (lane < 2 * G) a.mask[w0 + (uint32_t)lane] = cur;
+        } else {
+          const uint32_t word = __builtin_amdgcn_alignbit(cur, prev, 32u - sh);  // (cur << sh) | (prev >> (32 - sh))
+          if (lane >= 1 && lane < 2 * G) {
+            a.mask[w0 + (uint32_t)lane] = word;
+          } else if (lane == 0 || lane == 2 * G) {  // the run's first / last word: only its own bits
+            const uint32_t own = lane == 0 ? (0xFFFFFFFFu << sh) : (0xFFFFFFFFu >> (32u - sh));
+            const uint32_t zero = own & ~word;
+            if (zero) atomicAnd(&a.mask[w0 + (uint32_t)lane], ~zero);
+            if (word) atomicOr(&a.mask[w0 + (uint32_t)lane], word);
+          }
+        }
+      }
+    }
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < G; j++) {
@@ -806,7 +842,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       const bool visible = (st[j] & 2u) != 0u;
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
       // reference's and/or hit word 0 with an empty bit (no-op), so nothing to do.
-      if (OCCL) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
+      if (OCCL && !step_run) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
       const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
       const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
       if (lane == 0) gptr(a.bits)[group0 + j] = bits;
