@@ -108,18 +108,20 @@ OXC_DEV f2 s8_over_127_x2(int32_t x, int32_t y) {
   return __builtin_elementwise_fma(e, r, q);
 }
 
-// float -> u32 / i32 with v_cvt semantics (saturating, NaN -> 0), spelled out so that the
-// C++ conversion is never undefined.
+// float -> u32 / i32, saturating, NaN -> 0: exactly what v_cvt_u32_f32 / v_cvt_i32_f32 do (truncation toward zero inside the
+// range) -- tools/cvt_check.hip sweeps 2^27 bit patterns on the device against the spelled-out rule.  A C++ cast would be undefined out of
+// range, and spelling the rule out compiled into two nested exec-mask branches per conversion: ~50 of the ~340 instructions of an
+// occlusion batch in the HiZ meshlet kernels, which are bound by instruction issue.  Hence one instruction through an asm statement
+// (VGPR in, VGPR out: no scalar hazards to pad).  (v_cvt_flr_i32_f32 does NOT equal cvt_i32(floor(x)) on this part: same sweep.)
 OXC_DEV uint32_t cvt_u32_sat(float f) {
-  if (!(f > 0.0f)) return 0u;
-  if (f >= 4294967296.0f) return 0xFFFFFFFFu;
-  return (uint32_t)f;
+  uint32_t r;
+  asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
 }
 OXC_DEV int32_t cvt_i32_sat(float f) {
-  if (f != f) return 0;
-  if (f >= 2147483648.0f) return 2147483647;
-  if (f <= -2147483648.0f) return (int32_t)0x80000000;
-  return (int32_t)f;
+  int32_t r;
+  asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
 }
 
 // Column-major 4x4 helpers: element (r,c) = m[c*4+r].
@@ -275,7 +277,12 @@ struct HizView {
   const float* lds;
   const uint32_t* lds_off;
   uint32_t lds_first;
+  // x / width == x * (1 / width) bit for bit when width is a power of two (the reference sizes the pyramid with bit_ceil,
+  // RendererInstance.cpp:573-577): one multiply instead of a ~12-instruction IEEE division per axis.  0: not a power of two -> divide.
+  float inv_width, inv_height;
 };
+// 1 / d when d is a power of two (exact), else 0
+OXC_DEV float exact_reciprocal_or_zero(uint32_t d) { return (d != 0u && (d & (d - 1u)) == 0u) ? 1.0f / (float)d : 0.0f; }
 
 OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
   uint32_t v = d >> mip;
@@ -412,8 +419,9 @@ OXC_DEV bool aabb_occluded(const float* mvp, float near_clip, float cx, float cy
   uint32_t mip = ms <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(ms - 1u);
   uint32_t top = hiz.levels - 1u;
   mip = mip > top ? top : mip;
-  float u = (((float)minx + (float)maxx) * 0.5f) / sw;
-  float v = (((float)miny + (float)maxy) * 0.5f) / sh;
+  const float uc = ((float)minx + (float)maxx) * 0.5f, vc = ((float)miny + (float)maxy) * 0.5f;
+  float u = hiz.inv_width != 0.0f ? uc * hiz.inv_width : uc / sw;  // (wave-uniform choice)
+  float v = hiz.inv_height != 0.0f ? vc * hiz.inv_height : vc / sh;
 
   // sample_level_min_reduction_2x2, cull.slang:86-112
   uint32_t mw = mip_dim(hiz.width, mip), mh = mip_dim(hiz.height, mip);

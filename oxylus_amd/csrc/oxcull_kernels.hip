@@ -579,6 +579,8 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   hiz.lds = s_hiz_top;
   hiz.lds_off = s_lds_off;
   hiz.lds_first = a.hiz_lds_first;
+  hiz.inv_width = exact_reciprocal_or_zero(a.hiz_w);
+  hiz.inv_height = exact_reciprocal_or_zero(a.hiz_h);
   const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
   const uint32_t last_index = N ? N - 1u : 0u;
   const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
@@ -1563,8 +1565,9 @@ __global__ __launch_bounds__(1024) void k_scan_mesh_counts(ScanArgs a) { scan_bo
 __global__ __launch_bounds__(256) void k_expand_meshlet_instances(ExpandArgs a) { expand_body(a); }
 // (Capping SGPRs at 80 for 8 waves/SIMD -- the compiler otherwise keeps ~106 live -- was measured:
 // plain kernel 36.7 -> 38.8 us per 4M meshlets, HiZ variant 183 -> 175 us; not kept.)
+// (The occlusion variants sit at 96-98 VGPRs: the second bound keeps them at the 5 waves per SIMD they have always run with.)
 template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
-__global__ __launch_bounds__(1024 / G) void k_cull_meshlets_test(MeshletTestArgs a) {
+__global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_cull_meshlets_test(MeshletTestArgs a) {
   if constexpr (!HIZ)
     meshlets_plain_body<G>(a);
   else

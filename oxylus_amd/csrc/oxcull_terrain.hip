@@ -39,6 +39,8 @@ __global__ __launch_bounds__(1024) void k_cull_terrain_test(TerrainArgs a) {
   hiz.lds = nullptr;
   hiz.lds_off = nullptr;
   hiz.lds_first = a.hiz_levels;  // nothing staged in LDS
+  hiz.inv_width = exact_reciprocal_or_zero(a.hiz_w);
+  hiz.inv_height = exact_reciprocal_or_zero(a.hiz_h);
   const uint32_t first = blockIdx.x * 1024u;
   const uint32_t patch_index = first + threadIdx.x;
   const bool valid = patch_index < total;
