@@ -1263,8 +1263,11 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
           passed = passed && !(w_all && small);
         }
         const uint64_t mask = valid ? __builtin_amdgcn_ballot_w64(passed) : 0ull;
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mlo[h]) : "s"(readfirst_u((uint32_t)mask)), "n"(j));
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mhi[h]) : "s"(readfirst_u((uint32_t)(mask >> 32))), "n"(j));
+        // (s_nop 1: the SGPR read by v_writelane was written by a VALU instruction -- v_readfirstlane here -- and this target wants two
+        // wait states between the two; the compiler pads its own code but cannot see into an asm statement.  Round 3 found the rule the
+        // hard way: with a v_cmp-written pair fed to the asm directly, the masks came out stale.)
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mlo[h]) : "s"(readfirst_u((uint32_t)mask)), "n"(j));
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mhi[h]) : "s"(readfirst_u((uint32_t)(mask >> 32))), "n"(j));
         cnt += (uint32_t)__popcll((unsigned long long)mask);
       }
     }
