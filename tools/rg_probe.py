@@ -1,0 +1,10 @@
+import sys, os, json, types
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import torch
+import bench_aux
+from oxylus_amd.renderer import RendererInstance
+args = types.SimpleNamespace(no_cpu_baseline=(len(sys.argv) > 1 and sys.argv[1] == "nocpu"))
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+r = RendererInstance(0); stream = torch.cuda.Stream(device=dev)
+res = bench_aux.bench_real_geometry(args, r, dev, stream, 0)
+print(json.dumps({k: res[k] for k in ("ms_per_frame", "bit_match", "kernels_avg_us", "visible_fraction")}))
