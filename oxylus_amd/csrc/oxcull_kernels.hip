@@ -805,35 +805,43 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
     // whole words (+ one partial word at either end when d0 is not a multiple of 32).  Lane k builds word k from the G visibility
     // ballots and the run is written in one go, instead of once per 64-meshlet group through update_visibility_mask (~40 VALU
     // instructions each, 13 % of a late step's instructions).  Same stores / atomics as the per-group path would issue, merged.
-    // Late pass only: measured 99.5 -> 97.0 us there and 74.4 -> 75.2 us in the early pass (more SGPR spills than instructions saved).
     bool step_run = false;
-    if (OCCL && LATE && G == 4 && (group0 + G) * 64u <= N) {  // (wave-uniform)
-      const uint32_t d0 = readfirst_u(mask_idx[0]);
-      uint64_t bad = 0;
+    if constexpr (OCCL && G == 4) {
+      if ((group0 + G) * 64u <= N) {  // (wave-uniform)
+        const uint32_t d0 = readfirst_u(mask_idx[0]);
+        uint64_t bad = 0;
 #pragma unroll
-      for (int j = 0; j < G; j++) bad |= __builtin_amdgcn_ballot_w64(mask_idx[j] != d0 + 64u * (uint32_t)j + (uint32_t)lane);  // (kMaskNone lanes differ)
-      if (bad == 0ull && d0 <= 0xFFFFFFFFu - 64u * G) {
-        step_run = true;
-        uint32_t cur = 0, prev = 0;  // lane k: dword k of the run's G * 64 visibility bits, and dword k - 1
+        for (int j = 0; j < G; j++) bad |= __builtin_amdgcn_ballot_w64(mask_idx[j] != d0 + 64u * (uint32_t)j + (uint32_t)lane);  // (kMaskNone lanes differ)
+        if (bad == 0ull && d0 <= 0xFFFFFFFFu - 64u * G) {
+          step_run = true;
+          // the G ballots go through the wave's LDS flag row (free between rounds): lane k then picks dword k and dword k - 1 of the run
+          uint32_t* row8 = s_flags[wave];
 #pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint64_t vb = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u);
-          cur = lane == 2 * j ? (uint32_t)vb : (lane == 2 * j + 1 ? (uint32_t)(vb >> 32) : cur);
-          prev = lane == 2 * j + 1 ? (uint32_t)vb : (lane == 2 * j + 2 ? (uint32_t)(vb >> 32) : prev);
-        }
-        const uint32_t sh = d0 & 31u, w0 = d0 >> 5;
-        if (sh == 0u) {
-          if (lane < 2 * G) a.mask[w0 + (uint32_t)lane] = cur;
-        } else {
-          const uint32_t word = __builtin_amdgcn_alignbit(cur, prev, 32u - sh);  // (cur << sh) | (prev >> (32 - sh))
-          if (lane >= 1 && lane < 2 * G) {
-            a.mask[w0 + (uint32_t)lane] = word;
-          } else if (lane == 0 || lane == 2 * G) {  // the run's first / last word: only its own bits
-            const uint32_t own = lane == 0 ? (0xFFFFFFFFu << sh) : (0xFFFFFFFFu >> (32u - sh));
-            const uint32_t zero = own & ~word;
-            if (zero) atomicAnd(&a.mask[w0 + (uint32_t)lane], ~zero);
-            if (word) atomicOr(&a.mask[w0 + (uint32_t)lane], word);
+          for (int j = 0; j < G; j++) {
+            const uint64_t vb = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u);
+            if (lane == 0) {
+              row8[2 * j] = (uint32_t)vb;
+              row8[2 * j + 1] = (uint32_t)(vb >> 32);
+            }
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+          const uint32_t cur = lane < 2 * G ? row8[lane] : 0u;
+          const uint32_t prev = (lane >= 1 && lane <= 2 * G) ? row8[lane - 1] : 0u;
+          const uint32_t sh = d0 & 31u, w0 = d0 >> 5;
+          if (sh == 0u) {
+            if (lane < 2 * G) a.mask[w0 + (uint32_t)lane] = cur;
+          } else {
+            const uint32_t word = __builtin_amdgcn_alignbit(cur, prev, 32u - sh);  // (cur << sh) | (prev >> (32 - sh))
+            if (lane >= 1 && lane < 2 * G) {
+              a.mask[w0 + (uint32_t)lane] = word;
+            } else if (lane == 0 || lane == 2 * G) {  // the run's first / last word: only its own bits
+              const uint32_t own = lane == 0 ? (0xFFFFFFFFu << sh) : (0xFFFFFFFFu >> (32u - sh));
+              const uint32_t zero = own & ~word;
+              if (zero) atomicAnd(&a.mask[w0 + (uint32_t)lane], ~zero);
+              if (word) atomicOr(&a.mask[w0 + (uint32_t)lane], word);
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the flag row is rewritten by the next step
         }
       }
     }
