@@ -291,9 +291,40 @@ OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
 
 // cull.slang:12-47 project_aabb.  Returns false for `none` (box crosses the near plane).
 // out = {min.u, min.v, min.z, max.u, max.v, max.z}.
+// TRY_AFFINE (callers whose matrices are usually orthographic -- the clipmap views of a directional light): when the matrix's last
+// row is exactly (0, 0, 0, 1) every finite corner has w == 1.0f exactly (0 * x is +-0, 1 + +-0 is 1), a division by 1 returns its
+// numerator, and the fold over the eight corners collapses: corner (bx, by, bz) is fl(fl(fl(P0 + bx SX) + by SY) + bz SZ), rounding is
+// monotone in each addend and adding 0 is exact, so min over the corners = ((P0 + min(0, SX)) + min(0, SY)) + min(0, SZ) and max
+// likewise -- the same floats as the 24 divisions and 48 min / max of the general path (up to the sign of a zero, which neither
+// q * 0.5 + 0.5 nor the depth comparison sees) for 36 instructions.  Lanes whose sums could leave the finite range (any |P0| + |SX| +
+// |SY| + |SZ| above 2^120, or a NaN) send the wave down the general path.  (tests: test_project_aabb_matches_ieee_division_bit_for_bit)
+template <bool TRY_AFFINE = false>
 OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez, float* out) {
   float SX[4], SY[4], SZ[4], P[8][4];
   float p0x = cx - ex * 0.5f, p0y = cy - ey * 0.5f, p0z = cz - ez * 0.5f;
+  if (TRY_AFFINE && asu(OXC_M(mvp, 3, 0)) == 0u && asu(OXC_M(mvp, 3, 1)) == 0u && asu(OXC_M(mvp, 3, 2)) == 0u &&
+      asu(OXC_M(mvp, 3, 3)) == 0x3F800000u) {  // (the matrix is wave-uniform in every caller that sets TRY_AFFINE)
+    float lo[3], hi[3];
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float sx = OXC_M(mvp, i, 0) * ex, sy = OXC_M(mvp, i, 1) * ey, sz = OXC_M(mvp, i, 2) * ez;
+      const float p0 = ((OXC_M(mvp, i, 0) * p0x + OXC_M(mvp, i, 1) * p0y) + OXC_M(mvp, i, 2) * p0z) + OXC_M(mvp, i, 3);
+      finite = finite && ((__builtin_fabsf(p0) + __builtin_fabsf(sx)) + (__builtin_fabsf(sy) + __builtin_fabsf(sz))) <= 1.329227995784916e36f;
+      lo[i] = ((p0 + fminf(sx, 0.0f)) + fminf(sy, 0.0f)) + fminf(sz, 0.0f);
+      hi[i] = ((p0 + fmaxf(sx, 0.0f)) + fmaxf(sy, 0.0f)) + fmaxf(sz, 0.0f);
+    }
+    if (__builtin_amdgcn_ballot_w64(!finite) == 0) {
+      if (1.0f < near_clip) return false;  // every w is 1
+      out[0] = lo[0] * 0.5f + 0.5f;
+      out[1] = lo[1] * 0.5f + 0.5f;
+      out[2] = lo[2];
+      out[3] = hi[0] * 0.5f + 0.5f;
+      out[4] = hi[1] * 0.5f + 0.5f;
+      out[5] = hi[2];
+      return true;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     SX[i] = OXC_M(mvp, i, 0) * ex;

@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
             OXC_HPB_DECODE(b);
             float sa[6];
             bool pass = true;  // projection crosses the near plane: visible (cull_meshlets_hpb.slang:70-76)
-            if (project_aabb(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa)) pass = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
+            if (project_aabb<true>(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa)) pass = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (act) strip[t].x = pass ? 1u : 0u;
           }
@@ -2021,11 +2021,17 @@ __global__ __launch_bounds__(256) void k_debug_project_aabb(DebugProjectArgs a) 
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
     const float* b = a.boxes6 + (size_t)i * 6;
     float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool ok = project_aabb(a.mvp, a.near_clip, b[0], b[1], b[2], b[3], b[4], b[5], sa);
+    const bool ok = project_aabb<false>(a.mvp, a.near_clip, b[0], b[1], b[2], b[3], b[4], b[5], sa);
+    // ... and the form with the orthographic short cut, which has to agree (the sign of a zero aside): o[6] = 2 marks a box where it does not
+    float sb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool ok_b = project_aabb<true>(a.mvp, a.near_clip, b[0], b[1], b[2], b[3], b[4], b[5], sb);
+    bool same = ok == ok_b;
+#pragma unroll
+    for (int k = 0; k < 6; k++) same = same && (!ok || asu(sa[k]) == asu(sb[k]) || (sa[k] == 0.0f && sb[k] == 0.0f));
     float* o = a.out7 + (size_t)i * 7;
 #pragma unroll
     for (int k = 0; k < 6; k++) o[k] = ok ? sa[k] : 0.0f;
-    o[6] = ok ? 1.0f : 0.0f;
+    o[6] = !same ? 2.0f : ok ? 1.0f : 0.0f;
   }
 }
 void launch_debug_project_aabb(const DebugProjectArgs& a, hipStream_t s) {

@@ -566,9 +566,19 @@ def test_project_aabb_matches_ieee_division_bit_for_bit(renderer, oracle_lib):
     boxes[64 * 7 + 9] = torch.tensor([3.0e30, 1.0, -50.0, 1.0, 1.0, 1.0])         # |numerator| beyond 2^60
     boxes[64 * 11 + 1] = torch.tensor([1.0, 2.0, -1.0e-25, 1.0e-26, 1.0e-26, 1.0e-26])  # crosses / hugs the near plane
     pv = perspective_reversed_z(60.0, 1.0, 0.1, 1000.0)
-    mats = {"perspective": pv.tolist(), "orthographic-w=1": [0.01, 0, 0, 0, 0, 0.02, 0, 0, 0, 0, 0.001, 0, 0.1, -0.2, 0.5, 1.0]}
+    # (the device entry evaluates both forms of project_aabb -- the general one and the one with the w == 1 short cut the clipmap views
+    #  take -- and marks a box where they disagree with 2 in the seventh float; an orthographic matrix takes the short cut except in
+    #  the waves with the astronomically large / non-finite boxes, the scaled one never does)
+    ortho = [0.01, 0, 0, 0, 0, 0.02, 0, 0, 0, 0, 0.001, 0, 0.1, -0.2, 0.5, 1.0]
+    rot = [0.006, 0.008, 0.0005, 0, -0.016, 0.012, 0.0003, 0, 0.001, -0.002, 0.001, 0, 0.1, -0.2, 0.5, 1.0]
+    mats = {"perspective": pv.tolist(), "orthographic-w=1": ortho, "orthographic-rotated": rot, "orthographic-w=2": [2.0 * x for x in ortho]}
     for name, m in mats.items():
         near = 0.1 if name == "perspective" else 0.01
+        if name == "orthographic-rotated":
+            boxes = boxes.clone()
+            boxes[64 * 20 + 3] = torch.tensor([1.0, 2.0, -3.0, float("inf"), 1.0, 1.0])
+            boxes[64 * 21 + 4] = torch.tensor([3.0e38, 3.0e38, -3.0e38, 3.0e38, 3.0e38, 3.0e38])
+            boxes[64 * 22 + 5] = torch.tensor([float("nan"), 2.0, -3.0, 1.0, 1.0, 1.0])
         got = renderer.debug_project_aabb(m, near, boxes.cuda()).cpu().numpy()
         want = np.zeros((n, 7), dtype=np.float32)
         for i in range(n):
