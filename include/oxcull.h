@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OXC_ABI_VERSION 3u
+#define OXC_ABI_VERSION 4u
 
 typedef struct oxc_ctx oxc_ctx;
 
@@ -166,6 +166,19 @@ typedef struct oxc_cull_geometry_context {
    * overwrite what a pending triangle stage still reads (the visible list, MeshletInstance records rewritten by cull_meshes, its own
    * scratch).  0 (default) = the whole call is in order on hip_stream, as the reference records it. */
   uint32_t async_triangles;
+  /* Extension (caching only, no effect on any output byte): the two HiZ calls of a frame -- early, then OXC_CULL_LATE_PASS, as
+   * RendererInstance.cpp:842-884 records them -- run the same frustum and normal-cone tests on the same operands (the camera, the
+   * transforms and the MeshletInstance list do not change between them; only the pyramid and the mask do).  With 1 on BOTH calls the
+   * early call also evaluates the cone for the meshlets that were not visible last frame and leaves one "passed frustum and cone" bit
+   * per meshlet in the context's scratch, and the late call reads those bits instead of testing again (its meshlets outside the
+   * frustum are not even fetched).  By setting it on the late call the caller states that nothing those tests read has been written
+   * since the early call: meshes / transforms / mesh instances / MeshletInstance list / meshlet bounds.  What the context can
+   * check it checks -- the late call reuses the bits only if the previous flagged early call on this context had the same cull_camera
+   * (all 96 bytes), the same buffers, counts and flags, and no call in between rebuilt the list (init_cull_meshes) or the scratch;
+   * otherwise it silently tests again.  Only with use_hiz and OXC_CULL_TEST_OCCLUSION; ignored elsewhere and by
+   * oxc_cull_geometry_batch.  0 (default) = every call tests on its own. */
+  uint32_t share_pass_tests;
+  uint32_t _reserved0; /* must be 0 */
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */
@@ -522,6 +535,9 @@ oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float n
 
 /* Harness helper: copy n u32 from device memory (e.g. a callee-owned indirect command) to the host; synchronises the stream. */
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream);
+/* Test hook: what share_pass_tests did in the context's last oxc_cull_geometry call -- 0: the call tested on its own, 1: early call that
+ * also published its results, 2: late call that reused them. */
+uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
 
 /* Test hook: what the last oxc_draw_visbuffer on this context did with its triangles; synchronises the stream.
  * out4 = {triangles queued for the big path (pixel box beyond 8 x 8), triangles that crossed a clip plane, 64 x 64 tiles handed to

@@ -51,6 +51,8 @@ struct oxc_ctx {
     uint32_t* m_chunk_counts = nullptr;
     uint32_t* m_supers = nullptr;
     uint32_t* m_tickets = nullptr;
+    uint64_t* frustum_bits = nullptr;  // share_pass_tests: the early call's frustum ballots ...
+    uint2* step_info = nullptr;        // ... and each wave step's run of mask bits, for the late call of the same frame
     uint64_t* tri_masks = nullptr;
     uint32_t* t_chunk_counts = nullptr;
     uint32_t* t_supers = nullptr;
@@ -94,6 +96,19 @@ struct oxc_ctx {
   };
   static constexpr uint32_t kTriRing = 4;
   TriPending tri[kTriRing];
+  // share_pass_tests: what the last flagged early HiZ call tested, i.e. what lane[0].frustum_bits / step_info describe
+  struct SharedTests {
+    bool valid = false;
+    uint32_t N = 0, n_host = 0, M = 0, flags = 0;
+    const void *meshlet_instances = nullptr, *mask = nullptr, *meshes = nullptr, *transforms = nullptr, *mesh_instances = nullptr, *vis = nullptr;
+    oxc_cull_camera camera = {};
+    bool same_inputs(const SharedTests& o) const {
+      return N == o.N && n_host == o.n_host && M == o.M && flags == o.flags && meshlet_instances == o.meshlet_instances && mask == o.mask && meshes == o.meshes &&
+             transforms == o.transforms && mesh_instances == o.mesh_instances && vis == o.vis && std::memcmp(&camera, &o.camera, sizeof camera) == 0;
+    }
+  };
+  SharedTests shared;
+  uint32_t last_share_mode = 0;  // oxc_debug_shared_tests_mode
   uint64_t call_seq = 0;  // lane-0 oxc_cull_geometry calls so far: parity selects cache / t_supers
   // resident blocks per CU of the persistent kernels while the two stages share the machine (0 = no limit); the environment
   // variables OXC_ASYNC_MTEST_BLOCKS_PER_CU / OXC_ASYNC_TRI_BLOCKS_PER_CU, read by oxc_create, override the defaults (tuning aid)
@@ -188,12 +203,15 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_mcc = carve((uint64_t)m_chunks * 4);
   const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4 * kSuperStride);
   const uint64_t o_mtick = carve((uint64_t)kTicketCounters * 4 * kSuperStride);
+  const uint64_t o_fb = carve((uint64_t)cdiv(N, 64) * 8);
+  const uint64_t o_si = carve((uint64_t)m_chunks * 8);
   const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
   const uint64_t o_tcc = carve((uint64_t)t_chunks * 4);
   const uint64_t o_tsup = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
   const uint64_t o_tsup_alt = carve((uint64_t)cdiv(t_chunks, kChunksPerSuper) * 4 * kSuperStride);
   OXC_HIP(ctx, hipDeviceSynchronize());  // in-flight work (the side stream's included) may still use the old arena
   for (auto& tp : ctx->tri) tp.valid = false;
+  if (lane_index == 0) ctx->shared.valid = false;  // the early call's bits go with the arena
   if (L->arena) OXC_HIP(ctx, hipFree(L->arena));
   L->arena = nullptr;
   hipError_t e = hipMalloc(&L->arena, off);
@@ -213,6 +231,8 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
   L->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
   L->m_tickets = reinterpret_cast<uint32_t*>(b + o_mtick);
+  L->frustum_bits = reinterpret_cast<uint64_t*>(b + o_fb);
+  L->step_info = reinterpret_cast<uint2*>(b + o_si);
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
   L->t_supers = reinterpret_cast<uint32_t*>(b + o_tsup);
@@ -314,6 +334,7 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing or < ceil(N/32)*4 bytes");
   }
   if (c->small_triangle_cull > 1u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: small_triangle_cull must be 0 or 1");
+  if (c->share_pass_tests > 1u || c->_reserved0 != 0u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: share_pass_tests must be 0 or 1, _reserved0 0");
   const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
   if (c->use_hpb && do_meshlets) {
     if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
@@ -439,6 +460,7 @@ oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* c
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   OXC_ORDER(ctx, hip_stream);
   uint32_t* slot = next_seed_slot(ctx);
+  ctx->shared.valid = false;  // (share_pass_tests: a new list)
   ctx->seeded_total[(slot - ctx->slots) / SLOT_U32S] = total;
   launch_seed_slot(slot, total, static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
@@ -461,6 +483,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   oxc_status st = ensure_capacity(ctx, M, N, views, 0, s);
   if (st != OXC_OK) return st;
   OXC_ORDER(ctx, hip_stream);
+  ctx->last_share_mode = 0;
+  if (do_meshes) ctx->shared.valid = false;  // (share_pass_tests: the MeshletInstance list is rebuilt; a flagged early call marks its results valid below)
 
   // ---- async_triangles bookkeeping (include/oxcull.h).  Calls alternate between two sets of instance rows / triangle-count
   // accumulators, so that what this call's prepare kernel writes on `s` is never what a triangle stage still in flight on the
@@ -638,6 +662,30 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
+    if (c->use_hiz && occl && c->share_pass_tests) {  // include/oxcull.h: the late call of a frame reuses the early call's frustum + cone results
+      oxc_ctx::SharedTests now;
+      now.N = N;
+      now.n_host = n_host;
+      now.M = M;
+      now.flags = c->cull_flags & ~(uint32_t)OXC_CULL_LATE_PASS;
+      now.meshlet_instances = f->meshlet_instances_buffer.dptr;
+      now.mask = f->meshlet_instance_visibility_mask_buffer.dptr;
+      now.meshes = f->meshes_buffer.dptr;
+      now.transforms = f->transforms_world_buffer.dptr;
+      now.mesh_instances = f->mesh_instances_buffer.dptr;
+      now.vis = vis;
+      now.camera = c->cull_camera;
+      if (!late) {
+        ta.share = 1u;
+        ctx->shared = now;
+        ctx->shared.valid = true;
+      } else if (!do_meshes && ctx->shared.valid && ctx->shared.same_inputs(now)) {
+        ta.share = 2u;
+      }
+      ta.frustum_bits = ctx->lane[0].frustum_bits;
+      ta.step_info = ctx->lane[0].step_info;
+    }
+    ctx->last_share_mode = ta.share;
     {
       {
         KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
@@ -751,6 +799,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     same_pos = same_pos && std::memcmp(contexts[e].cull_camera.position, contexts[0].cull_camera.position, 12) == 0;
   }
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->shared.valid = false;  // (share_pass_tests: a batch may rebuild any list)
   for (uint32_t e = 0; e < count; e++) {
     oxc_status st = ensure_capacity(ctx, ci[e].M, ci[e].N, 0, e, static_cast<hipStream_t>(hip_stream));
     if (st != OXC_OK) return st;
@@ -1479,6 +1528,8 @@ oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float n
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }
+
+uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx) { return ctx ? ctx->last_share_mode : 0u; }
 
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;

@@ -545,8 +545,11 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
 // instance: its InstCache row, mask words and pyramid texels stay in the L2 of the XCD the counter's blocks run on; measured ~1 %).
 constexpr uint32_t kTicketRun = 4;
 OXC_DEV uint32_t OXC_TICKET_STEP(uint32_t t, uint32_t K, uint32_t x) { return ((t / kTicketRun) * K + x) * kTicketRun + t % kTicketRun; }
-template <bool OCCL, bool LATE, int G>
+template <bool OCCL, bool LATE, int G, int SHARE = 0>
 OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
+  // SHARE (only with OCCL, G == 4): 1 = early call that also publishes its frustum ballots and each step's mask run, 2 = late call
+  // that takes both from the early call of the same frame (MeshletTestArgs::share)
+  static_assert(SHARE == 0 || (OCCL && G == 4 && (SHARE == 1) == !LATE), "sharing: early call writes, late call reads");
   set_half_denorm_flush();
   constexpr int kWaves = 16 / G;
   constexpr bool OCCL_OR_LATE = OCCL || LATE;  // HAS_FLAG(flags, TestOcclusion|LatePass) is "any of"
@@ -608,13 +611,42 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
     uint2 rec[G];
     uint32_t st[G];        // bit 0: still to be decided, bit 1: visible, bit 2: was_visible
     uint32_t mask_idx[G];  // bit index into the persistent visibility mask
+    // SHARE: bit 3 of st = "inside the frustum" (SHARE == 1: found by this call and published at the end of the step; SHARE == 2: read
+    // from what the early call of the frame published)
+    bool quick = false;  // SHARE == 2: nothing of this step is inside the frustum and its mask bits are one run: no record is needed
+    uint32_t fbit[G];
 #pragma unroll
-    for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
+    for (int j = 0; j < G; j++) fbit[j] = 0u;
+    if constexpr (SHARE == 2) {
+      uint64_t any = 0;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t w = group0 + j < nwords ? gptr(a.frustum_bits)[group0 + j] : 0ull;
+        any |= w;
+        fbit[j] = ((w >> lane) & 1ull) != 0ull ? 8u : 0u;
+      }
+      const uint2 info = load_global_u2(reinterpret_cast<uint64_t>(a.step_info), step);
+      quick = any == 0ull && info.y != 0u;
+      if (quick) {
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          st[j] = 0u;
+          mask_idx[j] = info.x + 64u * (uint32_t)j + (uint32_t)lane;
+          rec[j] = make_uint2(0u, 0u);
+        }
+      }
+    }
+    if (!quick) {
+#pragma unroll
+      for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
+    }
     const uint32_t next_ticket = ticket ? draw_ticket() : 0u;  // in flight behind the record loads; read at the end of the step
+    if (!quick) {
 #pragma unroll
-    for (int j = 0; j < G; j++) {
-      st[j] = ((group0 + j) * 64 + lane < N) ? 1u : 0u;
-      mask_idx[j] = 0;
+      for (int j = 0; j < G; j++) {
+        st[j] = (((group0 + j) * 64 + lane < N) ? 1u : 0u) | fbit[j];
+        mask_idx[j] = 0;
+      }
     }
     for (;;) {
       uint32_t mi_u = 0;
@@ -637,7 +669,9 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
       for (int j = 0; j < G; j++) {
         mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
-        bnd[j] = OXC_LOAD_BND(bounds, mine[j] ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
+        // (SHARE == 2: only the meshlets inside the frustum are looked at again)
+        const bool fetch = SHARE == 2 ? (mine[j] && (st[j] & 8u) != 0u) : mine[j];
+        bnd[j] = OXC_LOAD_BND(bounds, fetch ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
         mword[j] = 0xFFFFFFFFu;
         if (OCCL) {  // cull_meshlets_hiz.slang:45-51 (unconditional load: lanes of other instances re-read this instance's first word)
           // (a mask index beyond the caller's buffer -- inconsistent visibility offsets -- reads as "not visible" and is
@@ -664,7 +698,14 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
         for (int j = 0; j < G; j++) {
           const uint4 b = bnd[j];
           const bool was_visible = (mword[j] & 1u) != 0u;
-          if (!LATE && __builtin_amdgcn_ballot_w64(mine[j] && was_visible) == 0) {
+          if constexpr (SHARE == 2) {  // the early call of this frame ran the same frustum test on the same operands
+            const bool vis = mine[j] & ((st[j] & 8u) != 0u);
+            cx[j] = cy[j] = cz[j] = ex[j] = ey[j] = ez[j] = 0.0f;
+            need[j] = 0u;
+            st[j] = mine[j] ? ((vis ? 2u : 0u) | (was_visible ? 4u : 0u)) : st[j];
+            continue;
+          }
+          if (!LATE && SHARE == 0 && __builtin_amdgcn_ballot_w64(mine[j] && was_visible) == 0) {
             // early pass, and no meshlet of this group was visible last frame (cull_meshlets_hiz.slang:45-51: they all return
             // before any test): skip the decode + frustum code for the whole group.  Visibility is coherent per instance, so
             // this is most groups of a typical frame.
@@ -675,8 +716,10 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
           }
           cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
           ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
-          bool vis = mine[j] & (LATE ? true : was_visible);
-          vis = vis & test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j]);
+          const bool inside = mine[j] & test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j]);
+          // (SHARE == 1: every meshlet inside the frustum goes on to the cone test, whose result the late call reuses; bit 1 means
+          //  "visible" only after the scatter below)
+          const bool vis = inside & ((LATE || SHARE == 1) ? true : was_visible);
           const bool nc = vis & (((int32_t)b.w >> 24) != 127);  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
           need[j] = nc ? 1u : 0u;
           any_need |= __builtin_amdgcn_ballot_w64(nc);
@@ -708,9 +751,19 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
           for (int j = 0; j < G; j++) {
             slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb[j], 0u));
-            if ((vb[j] >> lane) & 1ull) strip[slot[j]] = bnd[j];
+            if ((vb[j] >> lane) & 1ull) {
+              if constexpr (SHARE == 2) {  // these passed frustum and cone in the early call: straight to the occlusion batches
+                strip[slot[j]] = make_uint4(bnd[j].x, bnd[j].y, bnd[j].z, (bnd[j].w & 0x00FFFFFFu) | (slot[j] << 24));
+                flg[slot[j]] = 1u;
+              } else {
+                strip[slot[j]] = bnd[j];
+                if constexpr (SHARE == 1) flg[slot[j]] = st[j] & 4u;  // was_visible travels with the record
+              }
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
+          uint32_t nb = SHARE == 2 ? total : 0u;  // occlusion candidates: they occupy strip[0 .. nb)
+          if constexpr (SHARE != 2) {
           ConeU cu;
 #pragma unroll
           for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
@@ -721,7 +774,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
           for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
           cu.scale_max = asf(row[kRowScale]);
-          uint32_t nb = 0;  // cone survivors so far: they occupy strip[0 .. nb)
           for (uint32_t t0 = 0; t0 < total; t0 += 64) {
             const uint32_t t = t0 + (uint32_t)lane;
             const bool act = t < total;
@@ -741,12 +793,16 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
               }
               ok = nc ? cone_ok : ok;
             }
-            const uint64_t okb = __builtin_amdgcn_ballot_w64(ok);
+            // SHARE == 1: the occlusion test is for the meshlets that were visible last frame; bit 0 of the flag = passed frustum and
+            // cone (published for the late call), bit 1 = visible so far
+            const bool okv = SHARE == 1 ? (ok && (flg[act ? t : 0u] & 4u) != 0u) : ok;
+            const uint64_t okb = __builtin_amdgcn_ballot_w64(okv);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(okb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okb, 0u));
-            if (act) flg[t] = ok ? 1u : 0u;
+            if (act) flg[t] = SHARE == 1 ? ((ok ? 1u : 0u) | (okv ? 2u : 0u)) : (ok ? 1u : 0u);
             // (nb + rank <= t, and every lane of this batch has read its record: the LDS queue of a wave is in order)
-            if (ok) strip[nb + rank] = make_uint4(b.x, b.y, b.z, (b.w & 0x00FFFFFFu) | (t << 24));  // the cutoff byte now carries the survivor's strip position
+            if (okv) strip[nb + rank] = make_uint4(b.x, b.y, b.z, (b.w & 0x00FFFFFFu) | (t << 24));  // the cutoff byte now carries the survivor's strip position
             nb += (uint32_t)__popcll((unsigned long long)okb);
+          }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (nb) {
@@ -760,13 +816,19 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
               const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
               const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
               const bool occluded = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, act);
-              if (act && occluded) flg[b.w >> 24] = 0u;
+              if (act && occluded) flg[b.w >> 24] = SHARE == 1 ? 1u : 0u;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
 #pragma unroll
           for (int j = 0; j < G; j++) {
-            if ((vb[j] >> lane) & 1ull) st[j] = flg[slot[j]] ? st[j] : (st[j] & ~2u);
+            if ((vb[j] >> lane) & 1ull) {
+              const uint32_t f = flg[slot[j]];
+              if constexpr (SHARE == 1)
+                st[j] = (st[j] & ~2u) | (f & 2u) | ((f & 1u) << 3);
+              else
+                st[j] = f ? st[j] : (st[j] & ~2u);
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip and flags are rewritten by the next round
         }
@@ -806,9 +868,11 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
     // ballots and the run is written in one go, instead of once per 64-meshlet group through update_visibility_mask (~40 VALU
     // instructions each, 13 % of a late step's instructions).  Same stores / atomics as the per-group path would issue, merged.
     bool step_run = false;
+    uint32_t run_first = 0;
     if constexpr (OCCL && G == 4) {
       if ((group0 + G) * 64u <= N) {  // (wave-uniform)
         const uint32_t d0 = readfirst_u(mask_idx[0]);
+        run_first = d0;
         uint64_t bad = 0;
 #pragma unroll
         for (int j = 0; j < G; j++) bad |= __builtin_amdgcn_ballot_w64(mask_idx[j] != d0 + 64u * (uint32_t)j + (uint32_t)lane);  // (kMaskNone lanes differ)
@@ -843,6 +907,18 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the flag row is rewritten by the next step
         }
+      }
+    }
+    if constexpr (SHARE == 1) {
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const uint64_t w = __builtin_amdgcn_ballot_w64((st[j] & 8u) != 0u);
+        if (lane == 0 && group0 + j < nwords) gptr(a.frustum_bits)[group0 + j] = w;
+      }
+      if (lane == 0) {
+        uint32_t* info = reinterpret_cast<uint32_t*>(a.step_info + step);
+        gptr(info)[0] = run_first;
+        gptr(info)[1] = step_run ? 1u : 0u;
       }
     }
     uint32_t cnt = 0;
@@ -1584,6 +1660,14 @@ __global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_c
   else
     meshlets_hiz_body<OCCL, LATE, G>(a);
 }
+// the two calls of a frame sharing the frustum test (MeshletTestArgs::share)
+template <bool LATE>
+#ifndef OXC_SHARED_LATE_WAVES
+#define OXC_SHARED_LATE_WAVES 5
+#endif
+__global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WAVES : 5) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
+  meshlets_hiz_body<true, LATE, (int)kHizGroupsPerWave, LATE ? 2 : 1>(a);
+}
 template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
   meshlets_emit_body<HIZ, LATE>(a);
@@ -1946,6 +2030,14 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
   if (hiz && grid_limit) grid = std::min(grid, grid_limit);
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
+  } else if (occl && a.share) {
+    if (a.share == 2) {
+      static const uint32_t cap = resident_grid(k_cull_meshlets_test_shared<true>, hb, num_cus);
+      hipLaunchKernelGGL((k_cull_meshlets_test_shared<true>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
+    } else {
+      static const uint32_t cap = resident_grid(k_cull_meshlets_test_shared<false>, hb, num_cus);
+      hipLaunchKernelGGL((k_cull_meshlets_test_shared<false>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
+    }
   } else if (occl && late) {
     static const uint32_t cap = resident_grid(k_cull_meshlets_test<true, true, true, kHizGroups>, hb, num_cus);
     hipLaunchKernelGGL((k_cull_meshlets_test<true, true, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);

@@ -78,6 +78,10 @@ struct CullGeometryContext {
   // extension (scheduling only): cull_triangles of this call runs on the backend's own stream beside what the caller enqueues next
   // (the next cull_geometry's meshlet stage, generate_hiz); join_triangles() before anything of the caller's reads the index list
   bool async_triangles = false;
+  // extension (caching only): set on both HiZ calls of a frame (early, then LatePass with the same camera and buffers), the late call
+  // takes the frustum + cone results from the early one instead of testing again -- the caller vouches that no input of those tests
+  // was written in between (include/oxcull.h: share_pass_tests)
+  bool share_pass_tests = false;
 };
 
 struct MainGeometryContext {
@@ -145,6 +149,7 @@ public:
     c.wide_triangle_index = context.wide_triangle_index;
     c.small_triangle_cull = context.small_triangle_cull;
     c.async_triangles = context.async_triangles;
+    c.share_pass_tests = context.share_pass_tests;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));

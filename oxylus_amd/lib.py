@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liboxcull.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 OXC_OK, OXC_INVALID_ARG, OXC_HIP_ERROR, OXC_RCCL_ERROR, OXC_OUT_OF_MEMORY = range(5)
-ABI_VERSION = 3  # OXC_ABI_VERSION of include/oxcull.h
+ABI_VERSION = 4  # OXC_ABI_VERSION of include/oxcull.h
 
 CULL_TEST_FRUSTUM = 1
 CULL_SELECT_LOD = 2
@@ -100,6 +100,8 @@ class CullGeometryContext(C.Structure):
         ("wide_triangle_index", C.c_uint32),
         ("small_triangle_cull", C.c_uint32),
         ("async_triangles", C.c_uint32),
+        ("share_pass_tests", C.c_uint32),
+        ("_reserved0", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),
@@ -265,6 +267,7 @@ EXPORTS = [
     "oxc_broadcast_hiz",
     "oxc_broadcast_hiz_levels",
     "oxc_debug_read_u32",
+    "oxc_debug_shared_tests_mode",
     "oxc_debug_project_aabb",
 ]
 
@@ -326,6 +329,8 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.oxc_debug_shared_tests_mode.argtypes = [vp]
+    lib.oxc_debug_shared_tests_mode.restype = C.c_uint32
     lib.oxc_debug_raster_stats.argtypes = [vp, vp, vp]
     lib.oxc_comm_unique_id.argtypes = [vp, vp]
     lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]

@@ -153,6 +153,7 @@ class CullGeometryContext:
     wide_triangle_index: bool = False  # extension: (id << 9) | (3t+k), meshlets of up to 128 triangles
     small_triangle_cull: bool = False  # extension (north star): also drop triangles whose screen bbox covers no pixel centre
     async_triangles: bool = False  # extension (scheduling only): the triangle stage runs on the context's own stream; RendererInstance.join_triangles
+    share_pass_tests: bool = False  # extension (caching only): the late HiZ call of a frame reuses the early call's frustum + cone results (include/oxcull.h)
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -173,6 +174,7 @@ class CullGeometryContext:
         c.wide_triangle_index = int(self.wide_triangle_index)
         c.small_triangle_cull = int(self.small_triangle_cull)
         c.async_triangles = int(self.async_triangles)
+        c.share_pass_tests = int(self.share_pass_tests)
         return c
 
 
@@ -374,6 +376,10 @@ class RendererInstance:
         out = (C.c_uint32 * 4)()
         self._check(self._lib.oxc_debug_raster_stats(self._ctx, C.cast(out, C.c_void_p), self._stream(stream)))
         return {"big": int(out[0]), "clipped": int(out[1]), "tiles": int(out[2]), "overflowed_segments": int(out[3])}
+
+    def debug_shared_tests_mode(self) -> int:
+        """What share_pass_tests did in the last cull_geometry call: 0 tested on its own, 1 early call that published, 2 late call that reused."""
+        return int(self._lib.oxc_debug_shared_tests_mode(self._ctx))
 
     def debug_project_aabb(self, mvp16, near_clip: float, boxes6: torch.Tensor) -> torch.Tensor:
         """boxes6 f32 [n, 6] = {center.xyz, extent.xyz} -> f32 [n, 7] = {min.u, min.v, min.z, max.u, max.v, max.z, valid}."""

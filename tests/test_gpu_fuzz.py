@@ -58,4 +58,8 @@ def test_random_frame_matches_checker(renderer, oracle_lib, seed):
         want = oracle_frame(cpu, cull_flags=flags, use_hiz=True, hiz=hizd, mask=mask.clone(), two_pass=two)
         got = gpu_frame(renderer, gpu, cull_flags=flags, use_hiz=True, hiz=att, mask=mask.clone(), two_pass=two)
         keys = [k for k in want.keys() if k in got]
+        # the same calls with share_pass_tests (include/oxcull.h): a cache between the early and the late call of a two-pass frame, ignored
+        # by the other modes -- the checker's bytes either way
+        shared = gpu_frame(renderer, gpu, cull_flags=flags, use_hiz=True, hiz=att, mask=mask.clone(), two_pass=two, share_pass_tests=True)
+        assert_same(want, shared, keys)
     assert_same(want, got, keys)

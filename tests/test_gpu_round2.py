@@ -42,17 +42,29 @@ def test_config3_full_size_every_output_bit_exact(renderer, oracle_lib):
     frame.meshlet_instance_visibility_mask_buffer.copy_(mask0)
     renderer.prepared_frame = frame
     renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
-    ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
-    renderer.seed_meshlet_instances(ctx, N)
-    got = {}
-    for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
-        ctx.cull_flags = flags
-        renderer.cull_geometry(ctx)
-        c = renderer.read_counters(ctx)
-        first = c.early_visible_meshlet_instances if tag == "late" else 0
-        got[tag] = (frame.visible_meshlet_instances_indices_buffer[first:first + c.cull_triangles_cmd_x].cpu(), frame.reordered_indices_buffer[:c.draw_index_count].cpu(),
-                    (c.total_visible_meshlet_instances, c.early_visible_meshlet_instances, c.late_visible_meshlet_instances, c.cull_triangles_cmd_x))
-    got_mask = frame.meshlet_instance_visibility_mask_buffer.cpu()
+    runs = {}
+    for share in (False, True):  # every call on its own / the late call reusing the early call's frustum + cone results (share_pass_tests)
+        frame.meshlet_instance_visibility_mask_buffer.copy_(mask0)
+        frame.visible_meshlet_instances_indices_buffer.zero_()
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                  share_pass_tests=share)
+        renderer.seed_meshlet_instances(ctx, N)
+        got = {}
+        for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+            ctx.cull_flags = flags
+            renderer.cull_geometry(ctx)
+            c = renderer.read_counters(ctx)
+            first = c.early_visible_meshlet_instances if tag == "late" else 0
+            got[tag] = (frame.visible_meshlet_instances_indices_buffer[first:first + c.cull_triangles_cmd_x].cpu(), frame.reordered_indices_buffer[:c.draw_index_count].cpu(),
+                        (c.total_visible_meshlet_instances, c.early_visible_meshlet_instances, c.late_visible_meshlet_instances, c.cull_triangles_cmd_x))
+        got["mask"] = frame.meshlet_instance_visibility_mask_buffer.cpu()
+        runs[share] = got
+    for tag in ("early", "late"):
+        assert runs[True][tag][2] == runs[False][tag][2], f"{tag}: counters differ with share_pass_tests"
+        assert torch.equal(runs[True][tag][0], runs[False][tag][0]) and torch.equal(runs[True][tag][1], runs[False][tag][1]), f"{tag}: lists differ with share_pass_tests"
+    assert torch.equal(runs[True]["mask"], runs[False]["mask"])
+    got, got_mask = runs[False], runs[False]["mask"]
+    del runs
     got_hiz = hiz.data.cpu()
     # ---- the checker, whole scene
     cpu = gpu.to("cpu")

@@ -57,8 +57,10 @@ def oracle_frame(scene_cpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hiz=None,
 
 
 def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hiz: ImageAttachment = None, mask=None,
-              run_cull_meshes=False, two_pass=False, with_triangles=True):
-    """Same sequence through liboxcull.so.  Returns numpy arrays in the layout of oracle_frame."""
+              run_cull_meshes=False, two_pass=False, with_triangles=True, share_pass_tests=False, before_pass=None):
+    """Same sequence through liboxcull.so.  Returns numpy arrays in the layout of oracle_frame.
+    share_pass_tests: the flag of include/oxcull.h on every call; before_pass(i, ctx): called in front of call i (tests that change
+    something between the early and the late call)."""
     frame = PreparedFrame.create(scene_gpu, with_triangles=with_triangles, expand=not run_cull_meshes)
     if mask is not None:
         frame.meshlet_instance_visibility_mask_buffer.copy_(mask.to(scene_gpu.device))
@@ -66,7 +68,7 @@ def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hi
     cam = scene_gpu.cull_camera()
     stages = L.STAGE_ALL if with_triangles else (L.STAGE_MESHES | L.STAGE_MESHLETS)
     ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=run_cull_meshes, cull_flags=cull_flags, cull_camera=cam,
-                              hiz_attachment=hiz, stages=stages)
+                              hiz_attachment=hiz, stages=stages, share_pass_tests=share_pass_tests)
     res = {}
     if not run_cull_meshes:
         renderer.seed_meshlet_instances(ctx, scene_gpu.n_meshlet_instances)
@@ -75,7 +77,10 @@ def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hi
         ctx.cull_flags = flags
         if i > 0:
             ctx.init_cull_meshes = False
+        if before_pass is not None:
+            before_pass(i, ctx)
         renderer.cull_geometry(ctx)
+        res.setdefault("share_modes", []).append(renderer.debug_shared_tests_mode())
         c = renderer.read_counters(ctx)
         late = bool(flags & L.CULL_LATE_PASS)
         tag = ("late" if late else "early") if use_hiz else None
