@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--async-triangles", action="store_true",
                     help="config3: time the main line with async_triangles = 1 (triangle stages on the context's own stream, frames pipeline); the default line is in "
                          "order on one stream and carries the pipelined figure as the nested object \"async_triangles\"")
+    ap.add_argument("--no-share-pass-tests", action="store_true",
+                    help="config3: every call runs its own frustum + cone tests; by default the two calls of a frame set share_pass_tests (include/oxcull.h): the late "
+                         "call reuses the early call's results -- same outputs; the other form is timed as a variant in scheduling_ab")
     ap.add_argument("--no-scheduling-ab", action="store_true", help="config3: skip the short timed runs of the other schedulings (profiling runs: their concurrent kernels would "
                                                                     "be averaged into the per-kernel durations of a kernel trace)")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the short timed run with the other --hiz-exchange form")
@@ -434,6 +437,9 @@ def bench_config3(args, e):
 
     frame_no = [0]
     use_async = [bool(args.async_triangles)]  # async_triangles (include/oxcull.h): triangle stages on the context's own stream, frames pipeline
+    # share_pass_tests (include/oxcull.h): both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884), so the
+    # late call takes the frustum + cone results from the early one
+    use_share = [not args.no_share_pass_tests]
 
     def run_frame(record=None):
         f = frame_no[0]
@@ -460,6 +466,7 @@ def bench_config3(args, e):
             produce_hiz(b, False)
         c = cctx[b]
         c.async_triangles = int(use_async[0])
+        c.share_pass_tests = int(use_share[0])
         c.cull_flags = L.CULL_TEST_ALL
         check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
         if record is not None:
@@ -534,26 +541,30 @@ def bench_config3(args, e):
     # stream beside this frame's cull (what N > 1 does by default); (c) both.  Every variant must leave the outputs of the in-order run.
     ab_steps = max(2, args.steps // 4)
 
-    def timed_variant(async_on, ahead_on):
-        use_async[0], use_overlap[0] = async_on, ahead_on
+    def timed_variant(async_on, ahead_on, share_on):
+        use_async[0], use_overlap[0], use_share[0] = async_on, ahead_on, share_on
         el = timed_steps(e, run_step, ab_steps, 1)
-        return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
+        return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "share_pass_tests": share_on, "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
                 "value": round(n_meshlets * world * ab_steps * inner / el, 1), "frames_timed": ab_steps * inner, "outputs_match_main_line": outputs_checksum() == sum_main}
 
-    main_async, main_ahead = use_async[0], use_overlap[0]
+    main_async, main_ahead, main_share = use_async[0], use_overlap[0], use_share[0]
     variants = []
     if not args.no_scheduling_ab:
-        variants.append(timed_variant(not main_async, main_ahead))
+        variants.append(timed_variant(main_async, main_ahead, not main_share))
+        variants.append(timed_variant(not main_async, main_ahead, main_share))
         if world == 1:
-            variants.append(timed_variant(main_async, not main_ahead))
-            variants.append(timed_variant(not main_async, not main_ahead))
-        use_async[0], use_overlap[0] = main_async, main_ahead
+            variants.append(timed_variant(main_async, not main_ahead, main_share))
+            variants.append(timed_variant(not main_async, not main_ahead, main_share))
+        use_async[0], use_overlap[0], use_share[0] = main_async, main_ahead, main_share
         with torch.cuda.stream(stream):
             run_frame()  # (back in the main line's form before the kernel profile below)
         torch.cuda.synchronize()
-    sched_ab = {"main_line": {"async_triangles": main_async, "hiz_one_frame_ahead_on_second_stream": main_ahead, "ms_per_frame": round(ms_per_frame, 6)},
+    sched_ab = {"main_line": {"async_triangles": main_async, "hiz_one_frame_ahead_on_second_stream": main_ahead, "share_pass_tests": main_share,
+                              "ms_per_frame": round(ms_per_frame, 6)},
                 "variants": variants,
-                "note": "async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "
+                "note": "share_pass_tests: the late call of a frame reads the early call's frustum + cone results (one bit per meshlet) instead of testing again -- a cache "
+                        "inside liboxcull, valid because both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884); the first variant is "
+                        "the frame with every call testing on its own.  async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "
                         "events both ways, double-buffered pyramid -- legal here because the depth image a frame's pyramid is built from is given; in the engine the "
                         "pyramid is built from the early draw's depth between the two culls of a frame (RendererInstance.cpp:842-884), which is why the main line stays in order"}
 
@@ -594,7 +605,8 @@ def bench_config3(args, e):
     # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
     rp = rocprof_kernel_us(["r03_config3_pmc.json", "r02_config3_pmc.json"])
     rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
-                "cull_meshlets_test": ["oxc::k_cull_meshlets_test<true, true, false, 4>"], "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test<true, true, true, 4>"],
+                "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
+                "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
                 "cull_meshlets_emit": ["oxc::k_cull_meshlets_emit<true, false>"], "cull_meshlets_emit_late": ["oxc::k_cull_meshlets_emit<true, true>"],
                 "cull_triangles_test": ["oxc::k_cull_triangles_test<false, false, false>"], "cull_triangles_test_late": ["oxc::k_cull_triangles_test<true, false, false>"],
                 "cull_triangles_emit": ["oxc::k_cull_triangles_emit<false, false>"], "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit<true, false>"]}
@@ -762,7 +774,7 @@ def bench_config3(args, e):
                                                          "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if xmode["top"] else "whole pyramid broadcast from rank 0"),
                                                          "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": use_overlap[0],
                                                          "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame, "hiz_exchange_ab": exchange_ab},
-            "async_triangles": bool(use_async[0]),
+            "async_triangles": bool(use_async[0]), "share_pass_tests": bool(use_share[0]),
         },
         "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
         "unpinned_gap": unpinned, "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -51,7 +51,7 @@ struct oxc_ctx {
     uint32_t* m_chunk_counts = nullptr;
     uint32_t* m_supers = nullptr;
     uint32_t* m_tickets = nullptr;
-    uint64_t* frustum_bits = nullptr;  // share_pass_tests: the early call's frustum ballots ...
+    uint64_t* camera_test_bits = nullptr;  // share_pass_tests: the early call's "passed frustum and cone" ballots ...
     uint2* step_info = nullptr;        // ... and each wave step's run of mask bits, for the late call of the same frame
     uint64_t* tri_masks = nullptr;
     uint32_t* t_chunk_counts = nullptr;
@@ -96,7 +96,7 @@ struct oxc_ctx {
   };
   static constexpr uint32_t kTriRing = 4;
   TriPending tri[kTriRing];
-  // share_pass_tests: what the last flagged early HiZ call tested, i.e. what lane[0].frustum_bits / step_info describe
+  // share_pass_tests: what the last flagged early HiZ call tested, i.e. what lane[0].camera_test_bits / step_info describe
   struct SharedTests {
     bool valid = false;
     uint32_t N = 0, n_host = 0, M = 0, flags = 0;
@@ -231,7 +231,7 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
   L->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
   L->m_tickets = reinterpret_cast<uint32_t*>(b + o_mtick);
-  L->frustum_bits = reinterpret_cast<uint64_t*>(b + o_fb);
+  L->camera_test_bits = reinterpret_cast<uint64_t*>(b + o_fb);
   L->step_info = reinterpret_cast<uint2*>(b + o_si);
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
   L->t_chunk_counts = reinterpret_cast<uint32_t*>(b + o_tcc);
@@ -682,7 +682,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       } else if (!do_meshes && ctx->shared.valid && ctx->shared.same_inputs(now)) {
         ta.share = 2u;
       }
-      ta.frustum_bits = ctx->lane[0].frustum_bits;
+      ta.camera_test_bits = ctx->lane[0].camera_test_bits;
       ta.step_info = ctx->lane[0].step_info;
     }
     ctx->last_share_mode = ta.share;

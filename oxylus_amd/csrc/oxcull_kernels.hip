@@ -547,8 +547,9 @@ constexpr uint32_t kTicketRun = 4;
 OXC_DEV uint32_t OXC_TICKET_STEP(uint32_t t, uint32_t K, uint32_t x) { return ((t / kTicketRun) * K + x) * kTicketRun + t % kTicketRun; }
 template <bool OCCL, bool LATE, int G, int SHARE = 0>
 OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
-  // SHARE (only with OCCL, G == 4): 1 = early call that also publishes its frustum ballots and each step's mask run, 2 = late call
-  // that takes both from the early call of the same frame (MeshletTestArgs::share)
+  // SHARE (only with OCCL, G == 4): 1 = early call that also runs the cone test for the meshlets that were not visible last frame and
+  // publishes the "passed frustum and cone" ballots and each step's mask run, 2 = late call that takes both from the early call of the
+  // same frame (MeshletTestArgs::share, include/oxcull.h: share_pass_tests)
   static_assert(SHARE == 0 || (OCCL && G == 4 && (SHARE == 1) == !LATE), "sharing: early call writes, late call reads");
   set_half_denorm_flush();
   constexpr int kWaves = 16 / G;
@@ -611,9 +612,9 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
     uint2 rec[G];
     uint32_t st[G];        // bit 0: still to be decided, bit 1: visible, bit 2: was_visible
     uint32_t mask_idx[G];  // bit index into the persistent visibility mask
-    // SHARE: bit 3 of st = "inside the frustum" (SHARE == 1: found by this call and published at the end of the step; SHARE == 2: read
-    // from what the early call of the frame published)
-    bool quick = false;  // SHARE == 2: nothing of this step is inside the frustum and its mask bits are one run: no record is needed
+    // SHARE: bit 3 of st = "passed the frustum and the cone test" (SHARE == 1: found by this call and published at the end of the step;
+    // SHARE == 2: read from what the early call of the frame published)
+    bool quick = false;  // SHARE == 2: nothing of this step passed the camera tests and its mask bits are one run: no record is needed
     uint32_t fbit[G];
 #pragma unroll
     for (int j = 0; j < G; j++) fbit[j] = 0u;
@@ -621,7 +622,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       uint64_t any = 0;
 #pragma unroll
       for (int j = 0; j < G; j++) {
-        const uint64_t w = group0 + j < nwords ? gptr(a.frustum_bits)[group0 + j] : 0ull;
+        const uint64_t w = group0 + j < nwords ? gptr(a.camera_test_bits)[group0 + j] : 0ull;
         any |= w;
         fbit[j] = ((w >> lane) & 1ull) != 0ull ? 8u : 0u;
       }
@@ -669,7 +670,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
       for (int j = 0; j < G; j++) {
         mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
-        // (SHARE == 2: only the meshlets inside the frustum are looked at again)
+        // (SHARE == 2: only the meshlets that passed frustum and cone in the early call are looked at again)
         const bool fetch = SHARE == 2 ? (mine[j] && (st[j] & 8u) != 0u) : mine[j];
         bnd[j] = OXC_LOAD_BND(bounds, fetch ? rec[j].y : 0u);  // other lanes read element 0 (always valid)
         mword[j] = 0xFFFFFFFFu;
@@ -698,7 +699,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
         for (int j = 0; j < G; j++) {
           const uint4 b = bnd[j];
           const bool was_visible = (mword[j] & 1u) != 0u;
-          if constexpr (SHARE == 2) {  // the early call of this frame ran the same frustum test on the same operands
+          if constexpr (SHARE == 2) {  // the early call of this frame ran the same frustum and cone tests on the same operands
             const bool vis = mine[j] & ((st[j] & 8u) != 0u);
             cx[j] = cy[j] = cz[j] = ex[j] = ey[j] = ez[j] = 0.0f;
             need[j] = 0u;
@@ -913,7 +914,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 #pragma unroll
       for (int j = 0; j < G; j++) {
         const uint64_t w = __builtin_amdgcn_ballot_w64((st[j] & 8u) != 0u);
-        if (lane == 0 && group0 + j < nwords) gptr(a.frustum_bits)[group0 + j] = w;
+        if (lane == 0 && group0 + j < nwords) gptr(a.camera_test_bits)[group0 + j] = w;
       }
       if (lane == 0) {
         uint32_t* info = reinterpret_cast<uint32_t*>(a.step_info + step);

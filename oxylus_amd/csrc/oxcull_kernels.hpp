@@ -68,10 +68,11 @@ struct MeshletTestArgs {
   uint32_t* supers;
   uint32_t* tickets;  // != null: waves take their 64*G-meshlet steps from these counters instead of a fixed stride (zeroed by prepare)
   // Two-pass sharing (oxc_cull_geometry_context::share_pass_tests): the early HiZ call leaves, per 64-meshlet group, the ballot of
-  // "inside the frustum" and, per wave step, where its run of mask bits starts; the late call of the same frame reads them instead
-  // of testing again.  share: 0 = off, 1 = write them (early call), 2 = read them (late call).
+  // "passed the frustum and the normal-cone test" (the tests that depend on the camera only) and, per wave step, where its run of mask
+  // bits starts; the late call of the same frame reads them instead of testing again.  share: 0 = off, 1 = write them (early call),
+  // 2 = read them (late call).
   uint32_t share;
-  uint64_t* frustum_bits;  // [ceil(N / 64)]
+  uint64_t* camera_test_bits;  // [ceil(N / 64)]
   uint2* step_info;        // [steps]: {first mask bit of the step, 1 if the step's 64 * G meshlets are one run of mask bits}
   const float* hiz_data;
   uint32_t hiz_level_off[13];  // float offsets of each mip

@@ -142,7 +142,8 @@ def bench_loop(args, r, dev, stream, rank, world, dist):
         hiz = ImageAttachment.hiz(W // 2, H // 2, dev)
         depth = ImageAttachment.depth(torch.zeros((H, W), dtype=torch.float32, device=dev))
         visdepth = torch.zeros((H, W), dtype=torch.int64, device=dev)
-        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=cam, hiz_attachment=hiz, stages=L.STAGE_ALL)
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=cam, hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                  share_pass_tests=True)  # early cull -> draw -> pyramid -> late cull of ONE camera: the late call reuses the early frustum + cone results
         r.seed_meshlet_instances(ctx, n_meshlets)
     from oxylus_amd.renderer import MainGeometryContext
 
@@ -492,7 +493,8 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
         frame = PreparedFrame.create(scene, with_triangles=True)
         depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))
         hiz = ImageAttachment.hiz(HW, HW, dev)
-        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                  share_pass_tests=True)  # as the main line of bench.py
         r.prepared_frame = frame
         r.seed_meshlet_instances(ctx, N)
         g = torch.Generator(device=dev).manual_seed(5)

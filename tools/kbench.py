@@ -2,7 +2,7 @@
 """tools/kbench.py -- A/B several builds of liboxcull.so on the configs[2] frame in ONE process (one scene generation).
 
   python tools/kbench.py [--libs base=oxylus_amd/liboxcull.so,x=oxylus_amd/variants/liboxcull_x.so] [--frames 60] [--meshlets N]
-  A library entry may carry settings: tag=path@ASYNC=1@OXC_ASYNC_MTEST_BLOCKS_PER_CU=3 -- ASYNC=1 sets async_triangles on every call
+  A library entry may carry settings: tag=path@ASYNC=1@SHARE=1@OXC_ASYNC_MTEST_BLOCKS_PER_CU=3 -- ASYNC=1 sets async_triangles, SHARE=1 share_pass_tests on every call
   (the frames then pipeline: triangle stages on the context's own stream), anything else goes into the environment before oxc_create.
 
 For every library: warm up, time `--frames` frames (wall, one stream), then an instrumented pass (HIP-event pair per kernel), and a
@@ -54,11 +54,13 @@ def main():
     for item in a.libs.split(","):
         tag, path = item.split("=", 1)
         path, *settings = path.split("@")
-        use_async = False
+        use_async, use_share = False, False
         for kv in settings:
             k_, v_ = kv.split("=")
             if k_ == "ASYNC":
                 use_async = v_ == "1"
+            elif k_ == "SHARE":
+                use_share = v_ == "1"
             else:
                 os.environ[k_] = v_
         r = RendererInstance(0, lib_path=os.path.join(ROOT, path) if not os.path.isabs(path) else path)
@@ -72,6 +74,8 @@ def main():
             os.environ.pop(kv.split("=")[0], None)
         cframe, cctx = frame.c(), ctx.c()
         cctx.async_triangles = int(use_async)
+        if use_share:
+            cctx.share_pass_tests = 1
         mg = L.MainGeometryContext()
         mg.struct_size = C.sizeof(L.MainGeometryContext)
         mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
