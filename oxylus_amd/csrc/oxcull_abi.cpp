@@ -99,11 +99,11 @@ struct oxc_ctx {
   // share_pass_tests: what the last flagged early HiZ call tested, i.e. what lane[0].camera_test_bits / step_info describe
   struct SharedTests {
     bool valid = false;
-    uint32_t N = 0, n_host = 0, M = 0, flags = 0;
+    uint32_t N = 0, n_host = 0, M = 0, flags = 0, mask_bits = 0;
     const void *meshlet_instances = nullptr, *mask = nullptr, *meshes = nullptr, *transforms = nullptr, *mesh_instances = nullptr, *vis = nullptr;
     oxc_cull_camera camera = {};
     bool same_inputs(const SharedTests& o) const {
-      return N == o.N && n_host == o.n_host && M == o.M && flags == o.flags && meshlet_instances == o.meshlet_instances && mask == o.mask && meshes == o.meshes &&
+      return N == o.N && n_host == o.n_host && M == o.M && flags == o.flags && mask_bits == o.mask_bits && meshlet_instances == o.meshlet_instances && mask == o.mask && meshes == o.meshes &&
              transforms == o.transforms && mesh_instances == o.mesh_instances && vis == o.vis && std::memcmp(&camera, &o.camera, sizeof camera) == 0;
     }
   };
@@ -668,6 +668,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       now.n_host = n_host;
       now.M = M;
       now.flags = c->cull_flags & ~(uint32_t)OXC_CULL_LATE_PASS;
+      now.mask_bits = ta.mask_bits;  // (the early call's "one run of mask bits" is a statement about this many bits)
       now.meshlet_instances = f->meshlet_instances_buffer.dptr;
       now.mask = f->meshlet_instance_visibility_mask_buffer.dptr;
       now.meshes = f->meshes_buffer.dptr;
