@@ -33,7 +33,7 @@ def _cameras(scene, n):
     return cams
 
 
-def _run(scene, use_hiz, n_frames, async_mode, mask0, depth, hw):
+def _run(scene, use_hiz, n_frames, async_mode, mask0, depth, hw, share=False):
     dev = scene.device
     r = RendererInstance(0)
     stream = torch.cuda.Stream(device=dev)
@@ -42,7 +42,7 @@ def _run(scene, use_hiz, n_frames, async_mode, mask0, depth, hw):
     hiz = ImageAttachment.hiz(hw, hw, dev) if use_hiz else None
     passes = [L.CULL_TEST_ALL, L.CULL_TEST_ALL | L.CULL_LATE_PASS] if use_hiz else [L.CULL_TEST_ALL]
     ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz,
-                              stages=L.STAGE_ALL, async_triangles=async_mode)
+                              stages=L.STAGE_ALL, async_triangles=async_mode, share_pass_tests=share)
     calls = []
     with torch.cuda.stream(stream):
         r.seed_meshlet_instances(ctx, scene.n_meshlet_instances)
@@ -81,7 +81,12 @@ def test_async_triangle_stage_writes_the_same_bytes(use_hiz):
     mask0 = (bits << torch.arange(32, device="cuda")).sum(1).to(torch.int32)
     want, want_final = _run(scene, use_hiz, 4, False, mask0, depth, HW)
     got, got_final = _run(scene, use_hiz, 4, True, mask0, depth, HW)
-    assert len(want) == len(got)
+    # ... and with the late call of every frame reusing the early call's frustum + cone results (share_pass_tests) on top of it
+    got2, got2_final = _run(scene, use_hiz, 4, True, mask0, depth, HW, share=True)
+    assert len(want) == len(got) == len(got2)
+    for i, (w, g_) in enumerate(zip(want, got2)):
+        assert w[0] == g_[0] and w[1] == g_[1] and np.array_equal(w[2], g_[2]), f"call {i} with share_pass_tests"
+    assert want_final[:3] == got2_final[:3] and np.array_equal(want_final[3], got2_final[3]) and np.array_equal(want_final[4], got2_final[4])
     assert sum(w[1] for w in want) > 100_000  # the frames emit triangles at all ...
     assert len({w[1] for w in want}) > 2      # ... and differ from each other
     for i, (w, g_) in enumerate(zip(want, got)):
