@@ -51,6 +51,8 @@ struct oxc_ctx {
     uint32_t* m_chunk_counts = nullptr;
     uint32_t* m_supers = nullptr;
     uint32_t* m_tickets = nullptr;
+    uint32_t* m_supers_late = nullptr;   // share_pass_tests: the accumulators of the late call, zeroed by the early call's prepare kernel
+    uint32_t* m_tickets_late = nullptr;
     uint64_t* camera_test_bits = nullptr;  // share_pass_tests: the early call's "passed frustum and cone" ballots ...
     uint2* step_info = nullptr;        // ... and each wave step's run of mask bits, for the late call of the same frame
     uint64_t* tri_masks = nullptr;
@@ -102,6 +104,11 @@ struct oxc_ctx {
     uint32_t N = 0, n_host = 0, M = 0, flags = 0, mask_bits = 0;
     const void *meshlet_instances = nullptr, *mask = nullptr, *meshes = nullptr, *transforms = nullptr, *mesh_instances = nullptr, *vis = nullptr;
     oxc_cull_camera camera = {};
+    // the early call also did the late call's prepare work (PrepareArgs::slot_late): valid for lane-0 call number `armed_for_call` only
+    uint64_t armed_for_call = ~0ull;
+    uint32_t* late_slot = nullptr;
+    uint32_t* late_t_supers = nullptr;
+    InstCache* rows = nullptr;
     bool same_inputs(const SharedTests& o) const {
       return N == o.N && n_host == o.n_host && M == o.M && flags == o.flags && mask_bits == o.mask_bits && meshlet_instances == o.meshlet_instances && mask == o.mask && meshes == o.meshes &&
              transforms == o.transforms && mesh_instances == o.mesh_instances && vis == o.vis && std::memcmp(&camera, &o.camera, sizeof camera) == 0;
@@ -203,6 +210,8 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   const uint64_t o_mcc = carve((uint64_t)m_chunks * 4);
   const uint64_t o_msup = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4 * kSuperStride);
   const uint64_t o_mtick = carve((uint64_t)kTicketCounters * 4 * kSuperStride);
+  const uint64_t o_msup_late = carve((uint64_t)cdiv(m_chunks, kChunksPerSuper) * 4 * kSuperStride);
+  const uint64_t o_mtick_late = carve((uint64_t)kTicketCounters * 4 * kSuperStride);
   const uint64_t o_fb = carve((uint64_t)cdiv(N, 64) * 8);
   const uint64_t o_si = carve((uint64_t)m_chunks * 8);
   const uint64_t o_tm = carve((uint64_t)N * 16);  // one 64-bit pass mask per visible meshlet (two in wide mode)
@@ -231,6 +240,8 @@ oxc_status ensure_capacity(oxc_ctx* ctx, uint32_t mesh_instances, uint32_t meshl
   L->m_chunk_counts = reinterpret_cast<uint32_t*>(b + o_mcc);
   L->m_supers = reinterpret_cast<uint32_t*>(b + o_msup);
   L->m_tickets = reinterpret_cast<uint32_t*>(b + o_mtick);
+  L->m_supers_late = reinterpret_cast<uint32_t*>(b + o_msup_late);
+  L->m_tickets_late = reinterpret_cast<uint32_t*>(b + o_mtick_late);
   L->camera_test_bits = reinterpret_cast<uint64_t*>(b + o_fb);
   L->step_info = reinterpret_cast<uint2*>(b + o_si);
   L->tri_masks = reinterpret_cast<uint64_t*>(b + o_tm);
@@ -492,8 +503,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   oxc_ctx::Lane& L0 = ctx->lane[0];
   const uint64_t call_no = ctx->call_seq++;
   const bool async = c->async_triangles != 0 && do_tris;
-  InstCache* const cache = (call_no & 1u) ? L0.cache_alt : L0.cache;
-  uint32_t* const t_supers = (call_no & 1u) ? L0.t_supers_alt : L0.t_supers;
+  InstCache* cache = (call_no & 1u) ? L0.cache_alt : L0.cache;
+  uint32_t* t_supers = (call_no & 1u) ? L0.t_supers_alt : L0.t_supers;
   oxc_ctx::TriPending& my_tri = ctx->tri[call_no % oxc_ctx::kTriRing];
   my_tri.valid = false;  // (the stage of call_no - kTriRing: every call since has waited for it where it mattered, and the side stream is in order)
   if (!async || do_meshes) {
@@ -534,6 +545,53 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     vis = static_cast<uint32_t*>(c->visibility_buffer.dptr);
     meshlets_cmd = static_cast<uint32_t*>(c->cull_meshlets_cmd_buffer.dptr);
   }
+  // ---- share_pass_tests (include/oxcull.h): is this the early call that publishes its frustum + cone results (1), or the late call that
+  // continues it (2)?  An early call in order on one stream (no async_triangles) also does the late call's prepare work in its own
+  // prepare kernel -- accumulators, counter slot; the instance rows are the same -- so that a late call that follows it immediately
+  // launches no prepare kernel at all.
+  uint32_t share_mode = 0;
+  bool armed_late = false, arm_late = false;
+  uint32_t* m_supers = L0.m_supers;
+  uint32_t* m_tickets = L0.m_tickets;
+  const uint32_t mask_bits = (uint32_t)std::min<uint64_t>(f->meshlet_instance_visibility_mask_buffer.bytes / 4u * 32u, 0xFFFFFFFEull);
+  if (c->use_hiz && occl && c->share_pass_tests && do_meshlets) {
+    oxc_ctx::SharedTests now;
+    now.N = N;
+    now.n_host = n_host;
+    now.M = M;
+    now.flags = c->cull_flags & ~(uint32_t)OXC_CULL_LATE_PASS;
+    now.mask_bits = mask_bits;  // (the early call's "one run of mask bits" is a statement about this many bits)
+    now.meshlet_instances = f->meshlet_instances_buffer.dptr;
+    now.mask = f->meshlet_instance_visibility_mask_buffer.dptr;
+    now.meshes = f->meshes_buffer.dptr;
+    now.transforms = f->transforms_world_buffer.dptr;
+    now.mesh_instances = f->mesh_instances_buffer.dptr;
+    now.vis = vis;
+    now.camera = c->cull_camera;
+    if (!late) {
+      share_mode = 1u;
+      arm_late = c->async_triangles == 0;
+      now.valid = true;
+      if (arm_late) {
+        now.armed_for_call = call_no + 1;
+        now.late_slot = next_slot(ctx);
+        now.late_t_supers = (call_no & 1u) ? L0.t_supers : L0.t_supers_alt;  // the other set: this call's triangle stage uses t_supers
+        now.rows = cache;
+      }
+      ctx->shared = now;
+    } else if (!do_meshes && !c->init_cull_meshes && ctx->shared.valid && ctx->shared.same_inputs(now)) {
+      share_mode = 2u;
+      if (ctx->shared.armed_for_call == call_no && c->async_triangles == 0) {
+        armed_late = true;
+        slot = ctx->shared.late_slot;
+        t_supers = ctx->shared.late_t_supers;
+        cache = ctx->shared.rows;
+        m_supers = L0.m_supers_late;
+        m_tickets = L0.m_tickets_late;
+      }
+    }
+  }
+  if (!armed_late && ctx->shared.armed_for_call <= call_no) ctx->shared.armed_for_call = ~0ull;  // (armed for this call only)
   uint32_t* tri_cmd = slot + SLOT_TRI_CMD;
   uint32_t* draw_cmd = slot + SLOT_DRAW_CMD;
   c->cull_triangles_cmd_buffer = {tri_cmd, 12};
@@ -552,9 +610,13 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.slot = slot;
   pa.vis = vis;
   pa.meshlets_cmd = meshlets_cmd;
-  pa.supers_meshlets = ctx->lane[0].m_supers;
+  pa.supers_meshlets = m_supers;
   pa.supers_tris = t_supers;
-  pa.tickets = ctx->lane[0].m_tickets;
+  pa.tickets = m_tickets;
+  pa.slot_late = arm_late ? ctx->shared.late_slot : nullptr;
+  pa.supers_meshlets_late = arm_late ? L0.m_supers_late : nullptr;
+  pa.supers_tris_late = arm_late ? ctx->shared.late_t_supers : nullptr;
+  pa.tickets_late = arm_late ? L0.m_tickets_late : nullptr;
   pa.n_supers_meshlets = cdiv(cdiv(std::max(N, 1u), 64u), kChunksPerSuper);
   pa.n_supers_tris = cdiv(t_chunks, kChunksPerSuper);
   pa.mesh_instance_count = M;
@@ -566,7 +628,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
   pa.view_cache = ctx->lane[0].view_cache;
   const uint32_t prep_threads = std::max(std::max(M * 8u, pa.n_supers_tris), 1u);  // 8 lanes per mesh instance
-  {
+  if (!armed_late) {  // (an armed late call: the early call of the frame did all of this)
     KernelTimer t(ctx, OXC_K_PREPARE, s);
     launch_prepare(pa, std::min(cdiv(prep_threads, 256), max_grid), (c->use_hpb && do_meshlets) ? views : 0u, s);
   }
@@ -629,16 +691,16 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     std::memset(&ta, 0, sizeof ta);
     ta.n_host = n_host;
     ta.n_cap = N;
-    ta.mask_bits = (uint32_t)std::min<uint64_t>(f->meshlet_instance_visibility_mask_buffer.bytes / 4u * 32u, 0xFFFFFFFEull);
+    ta.mask_bits = mask_bits;
     ta.cache = cache;
     ta.meshlet_instances = static_cast<const GpuMeshletInstance*>(f->meshlet_instances_buffer.dptr);
     ta.vis = vis;
     ta.mask = static_cast<uint32_t*>(f->meshlet_instance_visibility_mask_buffer.dptr);
     ta.bits = ctx->lane[0].bits;
     ta.chunk_counts = ctx->lane[0].m_chunk_counts;
-    ta.supers = ctx->lane[0].m_supers;
+    ta.supers = m_supers;
     if (c->use_hiz) {
-      ta.tickets = ctx->lane[0].m_tickets;  // the HiZ variants take their work dynamically (step cost varies 10x)
+      ta.tickets = m_tickets;  // the HiZ variants take their work dynamically (step cost varies 10x)
       const oxc_image& h = c->hiz_attachment;
       ta.hiz_data = static_cast<const float*>(h.dptr);
       ta.hiz_w = h.width;
@@ -662,27 +724,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
-    if (c->use_hiz && occl && c->share_pass_tests) {  // include/oxcull.h: the late call of a frame reuses the early call's frustum + cone results
-      oxc_ctx::SharedTests now;
-      now.N = N;
-      now.n_host = n_host;
-      now.M = M;
-      now.flags = c->cull_flags & ~(uint32_t)OXC_CULL_LATE_PASS;
-      now.mask_bits = ta.mask_bits;  // (the early call's "one run of mask bits" is a statement about this many bits)
-      now.meshlet_instances = f->meshlet_instances_buffer.dptr;
-      now.mask = f->meshlet_instance_visibility_mask_buffer.dptr;
-      now.meshes = f->meshes_buffer.dptr;
-      now.transforms = f->transforms_world_buffer.dptr;
-      now.mesh_instances = f->mesh_instances_buffer.dptr;
-      now.vis = vis;
-      now.camera = c->cull_camera;
-      if (!late) {
-        ta.share = 1u;
-        ctx->shared = now;
-        ctx->shared.valid = true;
-      } else if (!do_meshes && ctx->shared.valid && ctx->shared.same_inputs(now)) {
-        ta.share = 2u;
-      }
+    if (share_mode) {  // include/oxcull.h: the late call of a frame reuses the early call's frustum + cone results (decided above)
+      ta.share = share_mode;
       ta.camera_test_bits = ctx->lane[0].camera_test_bits;
       ta.step_info = ctx->lane[0].step_info;
     }
@@ -698,7 +741,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ea.count_meshlets = c->use_hiz ? 64u * kHizGroupsPerWave : 64u * kPlainGroups;  // one count per wave step: 64 * groups per wave
       ea.bits = ctx->lane[0].bits;
       ea.chunk_counts = ctx->lane[0].m_chunk_counts;
-      ea.supers = ctx->lane[0].m_supers;
+      ea.supers = m_supers;
       ea.vis = vis;
       ea.tri_cmd = tri_cmd;
       ea.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);

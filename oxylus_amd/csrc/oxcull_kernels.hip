@@ -99,6 +99,21 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
     for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i * kSuperStride] = 0;
     for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris[i * kSuperStride] = 0;
     if (a.tickets && tid < kTicketCounters) a.tickets[tid * kSuperStride] = 0;
+    if (a.slot_late) {  // (wave-uniform) the late call of this frame: its accumulators and counter slot, see PrepareArgs
+      if (tid == 0) {
+        a.slot_late[SLOT_TRI_CMD + 0] = 0;
+        a.slot_late[SLOT_TRI_CMD + 1] = 1;
+        a.slot_late[SLOT_TRI_CMD + 2] = 1;
+        a.slot_late[SLOT_DRAW_CMD + 0] = 0;
+        a.slot_late[SLOT_DRAW_CMD + 1] = 1;
+        a.slot_late[SLOT_DRAW_CMD + 2] = 0;
+        a.slot_late[SLOT_DRAW_CMD + 3] = 0;
+        a.slot_late[SLOT_DRAW_CMD + 4] = 0;
+      }
+      for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets_late[i * kSuperStride] = 0;
+      for (uint32_t i = tid; i < a.n_supers_tris; i += nthreads) a.supers_tris_late[i * kSuperStride] = 0;
+      if (tid < kTicketCounters) a.tickets_late[tid * kSuperStride] = 0;
+    }
   }
   const bool do_cull_meshes = main_view && a.do_cull_meshes;
 

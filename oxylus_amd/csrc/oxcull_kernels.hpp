@@ -23,6 +23,12 @@ struct PrepareArgs {
   uint32_t* supers_tris;
   uint32_t n_supers_meshlets, n_supers_tris;
   uint32_t* tickets;  // kTicketCounters work counters (stride kSuperStride) zeroed here for the test kernels that take work dynamically; may be null
+  // share_pass_tests, early call: the late call of the frame will reuse this call's instance rows, so everything else its prepare
+  // kernel would do is done here -- a second set of accumulators and its counter slot -- and the late call launches none.  Null: not armed.
+  uint32_t* slot_late;
+  uint32_t* supers_meshlets_late;
+  uint32_t* supers_tris_late;
+  uint32_t* tickets_late;
   uint32_t mesh_instance_count;
   uint32_t cull_flags;
   uint32_t do_cull_meshes;
@@ -210,6 +216,8 @@ inline void prepare_args_of(const BatchCore& c, PrepareArgs& pa) {
   pa.supers_meshlets = c.m_supers;
   pa.supers_tris = c.t_supers;
   pa.tickets = nullptr;  // batched elements run the plain meshlet test (fixed stride)
+  pa.slot_late = nullptr;
+  pa.supers_meshlets_late = pa.supers_tris_late = pa.tickets_late = nullptr;
   pa.n_supers_meshlets = c.n_supers_meshlets;
   pa.n_supers_tris = c.n_supers_tris;
   pa.mesh_instance_count = c.mesh_instance_count;
