@@ -537,7 +537,8 @@ oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float n
 /* Harness helper: copy n u32 from device memory (e.g. a callee-owned indirect command) to the host; synchronises the stream. */
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream);
 /* Test hook: what share_pass_tests did in the context's last oxc_cull_geometry call -- 0: the call tested on its own, 1: early call that
- * also published its results, 2: late call that reused them. */
+ * also published its results, 2: late call that reused them, 3: late call that reused them and launched no prepare kernel (the early
+ * call had done that work too: it was in order on one stream and directly in front of it). */
 uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
 
 /* Test hook: what the last oxc_draw_visbuffer on this context did with its triangles; synchronises the stream.

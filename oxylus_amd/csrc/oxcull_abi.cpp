@@ -729,7 +729,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ta.camera_test_bits = ctx->lane[0].camera_test_bits;
       ta.step_info = ctx->lane[0].step_info;
     }
-    ctx->last_share_mode = ta.share;
+    ctx->last_share_mode = armed_late ? 3u : ta.share;
     {
       {
         KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);

@@ -378,7 +378,8 @@ class RendererInstance:
         return {"big": int(out[0]), "clipped": int(out[1]), "tiles": int(out[2]), "overflowed_segments": int(out[3])}
 
     def debug_shared_tests_mode(self) -> int:
-        """What share_pass_tests did in the last cull_geometry call: 0 tested on its own, 1 early call that published, 2 late call that reused."""
+        """What share_pass_tests did in the last cull_geometry call: 0 tested on its own, 1 early call that published, 2 late call that reused,
+        3 late call that reused and needed no prepare kernel."""
         return int(self._lib.oxc_debug_shared_tests_mode(self._ctx))
 
     def debug_project_aabb(self, mvp16, near_clip: float, boxes6: torch.Tensor) -> torch.Tensor:

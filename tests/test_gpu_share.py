@@ -45,7 +45,7 @@ def test_late_call_reusing_the_early_tests_writes_the_checkers_bytes(renderer, o
     want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True)
     got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, share_pass_tests=True)
     assert_same(want, got, KEYS)
-    assert got["share_modes"] == [1, 2]  # the early call published, the late call reused
+    assert got["share_modes"] == [1, 3]  # the early call published (and prepared for both), the late call reused
     plain = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True)
     assert_same(plain, got, KEYS)
     assert plain["share_modes"] == [0, 0]
@@ -59,7 +59,7 @@ def test_with_cull_meshes_in_the_early_call(renderer, oracle_lib):
     want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True, run_cull_meshes=True)
     got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, run_cull_meshes=True, share_pass_tests=True)
     assert_same(want, got, KEYS + ["lod_index", "meshlet_instances", "cull_meshlets_cmd_x"])
-    assert 0 < want["total"] and got["share_modes"] == [1, 2]
+    assert 0 < want["total"] and got["share_modes"] == [1, 3]
 
 
 def _moved(cam):
@@ -117,5 +117,37 @@ def test_two_frames_back_to_back_keep_their_own_bits(renderer, oracle_lib):
     b0 = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, before_pass=camera_b)
     assert_same(a0, a1, KEYS)
     assert_same(b0, b1, KEYS)
-    assert a1["share_modes"] == [1, 2] and b1["share_modes"] == [1, 2]
+    assert a1["share_modes"] == [1, 3] and b1["share_modes"] == [1, 3]
     assert not np.array_equal(a0["late_visible"], b0["late_visible"])
+
+
+def test_another_call_between_the_two_still_shares_but_the_late_call_prepares_itself(renderer, oracle_lib):
+    """early (flag) -> a call of another view on the same context (seeded beforehand, so it neither re-seeds nor rebuilds a list) -> late
+    (flag): the late call still matches the early one and reuses its bits, but the accumulators the early call had armed for it are
+    no longer taken for granted -- it launches its own prepare kernel.  Bytes as without the flag."""
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    spec = SceneSpec(n_mesh_instances=200, meshlets_per_mesh=500, with_geometry=True, seed=51)
+    cpu, gpu, hiz, ohiz, mask = _setup(renderer, spec, 512, 0.3, 51)
+    other = make_scene(SceneSpec(n_mesh_instances=50, meshlets_per_mesh=300, with_geometry=True, seed=52), "cpu").to("cuda")
+    other_frame = PreparedFrame.create(other, with_triangles=True)
+    other_ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=other.cull_camera(), stages=L.STAGE_ALL)
+    renderer.prepared_frame = other_frame
+    renderer.seed_meshlet_instances(other_ctx, other.n_meshlet_instances)
+    renderer.cull_geometry(other_ctx)
+    want_other = renderer.read_counters(other_ctx).draw_index_count
+
+    def intruder(i, ctx):
+        if i == 1:
+            mine = renderer.prepared_frame
+            renderer.prepared_frame = other_frame
+            renderer.cull_geometry(other_ctx)
+            assert renderer.read_counters(other_ctx).draw_index_count == want_other
+            renderer.prepared_frame = mine
+
+    a = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, share_pass_tests=True, before_pass=intruder)
+    b = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True)
+    assert_same(b, a, KEYS)
+    assert a["share_modes"] == [1, 2]
+    want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True)
+    assert_same(want, a, KEYS)
