@@ -175,8 +175,10 @@ typedef struct oxc_cull_geometry_context {
    * since the early call: meshes / transforms / mesh instances / MeshletInstance list / meshlet bounds.  What the context can
    * check it checks -- the late call reuses the bits only if the previous flagged early call on this context had the same cull_camera
    * (all 96 bytes), the same buffers, counts and flags, and no call in between rebuilt the list (init_cull_meshes) or the scratch;
-   * otherwise it silently tests again.  (The match is made when the call is enqueued: a late call captured into a HIP graph reuses,
-   * at every replay, the bits of whatever flagged early call ran last -- replay the pair, not the late call alone.)  Only with use_hiz
+   * otherwise it silently tests again.  (The match is made when the call is enqueued: a late call captured into a HIP graph on its own
+   * reuses, at every replay, the bits of whatever flagged early call ran last -- capture the pair, or keep the scene unchanged
+   * between the replays.)  An early call that is in order on one stream (no async_triangles) also does the prepare work of the late call
+   * that follows it directly (same capture, if any), which then launches no prepare kernel.  Only with use_hiz
    * and OXC_CULL_TEST_OCCLUSION; ignored elsewhere and by oxc_cull_geometry_batch.  0 (default) = every call tests on its own. */
   uint32_t share_pass_tests;
   uint32_t _reserved0; /* must be 0 */

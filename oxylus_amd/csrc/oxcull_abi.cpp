@@ -106,6 +106,8 @@ struct oxc_ctx {
     oxc_cull_camera camera = {};
     // the early call also did the late call's prepare work (PrepareArgs::slot_late): valid for lane-0 call number `armed_for_call` only
     uint64_t armed_for_call = ~0ull;
+    unsigned long long capture_id = 0;  // the capture the arming early call was part of (0: none): an armed late call must be part of the same
+                                        // one -- replayed alone, nobody would zero its accumulators again
     uint32_t* late_slot = nullptr;
     uint32_t* late_t_supers = nullptr;
     InstCache* rows = nullptr;
@@ -155,6 +157,7 @@ oxc_status fail(oxc_ctx* ctx, oxc_status st, const char* what, hipError_t e = hi
   } while (0)
 
 bool stream_is_capturing(hipStream_t s);
+unsigned long long stream_capture_id(hipStream_t s);
 
 // Device-side ordering of a context's calls across streams (see oxc_ctx::last_stream).  Not across a capture boundary: an event
 // recorded outside a capture cannot be waited for inside it (and the reverse), so when `s` is being captured the wait for a
@@ -173,6 +176,17 @@ oxc_status order_stream(oxc_ctx* ctx, hipStream_t s) {
   ctx->last_stream = s;
   ctx->has_last_stream = true;
   return OXC_OK;
+}
+
+// 0 when `s` is not being captured, else the id of the capture it belongs to
+unsigned long long stream_capture_id(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(s, &st, &id) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return st == hipStreamCaptureStatusNone ? 0ull : (id ? id : ~0ull);
 }
 
 bool stream_is_capturing(hipStream_t s) {
@@ -574,6 +588,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       now.valid = true;
       if (arm_late) {
         now.armed_for_call = call_no + 1;
+        now.capture_id = stream_capture_id(s);
         now.late_slot = next_slot(ctx);
         now.late_t_supers = (call_no & 1u) ? L0.t_supers : L0.t_supers_alt;  // the other set: this call's triangle stage uses t_supers
         now.rows = cache;
@@ -581,7 +596,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ctx->shared = now;
     } else if (!do_meshes && !c->init_cull_meshes && ctx->shared.valid && ctx->shared.same_inputs(now)) {
       share_mode = 2u;
-      if (ctx->shared.armed_for_call == call_no && c->async_triangles == 0) {
+      if (ctx->shared.armed_for_call == call_no && c->async_triangles == 0 && ctx->shared.capture_id == stream_capture_id(s)) {
         armed_late = true;
         slot = ctx->shared.late_slot;
         t_supers = ctx->shared.late_t_supers;

@@ -151,3 +151,75 @@ def test_another_call_between_the_two_still_shares_but_the_late_call_prepares_it
     assert a["share_modes"] == [1, 2]
     want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True)
     assert_same(want, a, KEYS)
+
+
+def test_in_hip_graphs(oracle_lib):
+    """(a) The pair captured into one graph and replayed: the late call is part of the same capture as the early call that prepared for it
+    (mode 3), every replay starts from re-zeroed accumulators.  (b) Only the late call captured, after an early call outside the graph: it
+    reuses the bits (the scene does not change) but must prepare itself (mode 2) -- replayed alone, nobody else would zero its accumulators."""
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame, RendererInstance
+
+    r = RendererInstance(0)
+    spec = SceneSpec(n_mesh_instances=120, meshlets_per_mesh=400, with_geometry=True, seed=61)
+    cpu, gpu, hiz, ohiz, mask = _setup(r, spec, 256, 0.3, 61)
+    want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True)
+    frame = PreparedFrame.create(gpu, with_triangles=True)
+    r.prepared_frame = frame
+    r.reserve(gpu.n_mesh_instances, gpu.n_meshlet_instances)
+    s = torch.cuda.Stream()
+    mask_gpu = mask.cuda()
+
+    def check(ctx_e, ctx_l, what):
+        torch.cuda.synchronize()
+        ce, cl = r.read_counters(ctx_e), r.read_counters(ctx_l)
+        assert (cl.early_visible_meshlet_instances, cl.late_visible_meshlet_instances) == (want["early"], want["late"]), what
+        vis = frame.visible_meshlet_instances_indices_buffer.cpu().numpy()
+        assert np.array_equal(vis[:want["early"]], want["early_visible"]) and np.array_equal(vis[want["early"]:want["early"] + want["late"]], want["late_visible"]), what
+        assert cl.draw_index_count == len(want["late_indices"]) and ce.draw_index_count == len(want["early_indices"]), what
+        assert np.array_equal(frame.reordered_indices_buffer[:cl.draw_index_count].cpu().numpy(), want["late_indices"]), what
+        assert np.array_equal(frame.meshlet_instance_visibility_mask_buffer.cpu().numpy(), want["mask"]), what
+
+    def contexts():
+        e = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                share_pass_tests=True)
+        with torch.cuda.stream(s):
+            r.seed_meshlet_instances(e, gpu.n_meshlet_instances, stream=s)
+        l = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL | L.CULL_LATE_PASS, cull_camera=gpu.cull_camera(), hiz_attachment=hiz,
+                                stages=L.STAGE_ALL, share_pass_tests=True)
+        l._c.visibility_buffer, l._c.cull_meshlets_cmd_buffer = e._c.visibility_buffer, e._c.cull_meshlets_cmd_buffer
+        return e, l
+
+    # (a) the pair in one graph
+    e, l = contexts()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        r.cull_geometry(e, stream=s)
+        mode_e = r.debug_shared_tests_mode()
+        r.cull_geometry(l, stream=s)
+        mode_l = r.debug_shared_tests_mode()
+    assert (mode_e, mode_l) == (1, 3)
+    for rep in range(3):
+        frame.meshlet_instance_visibility_mask_buffer.copy_(mask_gpu)
+        frame.visible_meshlet_instances_indices_buffer.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        check(e, l, f"pair, replay {rep}")
+    # (b) the late call alone in a graph
+    e, l = contexts()
+    frame.meshlet_instance_visibility_mask_buffer.copy_(mask_gpu)
+    torch.cuda.synchronize()
+    r.cull_geometry(e, stream=s)
+    torch.cuda.synchronize()
+    mask_after_early = frame.meshlet_instance_visibility_mask_buffer.clone()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        r.cull_geometry(l, stream=s)
+        mode_l = r.debug_shared_tests_mode()
+    assert mode_l == 2
+    for rep in range(3):
+        frame.meshlet_instance_visibility_mask_buffer.copy_(mask_after_early)
+        torch.cuda.synchronize()
+        g2.replay()
+        check(e, l, f"late alone, replay {rep}")
+    r.close()
