@@ -254,7 +254,8 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
  * cull_meshes; the synthetic benchmark configurations start from a given list.
  * Counter buffers handed back in a context (visibility / cull_meshlets_cmd / cull_triangles_cmd /
  * draw_geometry_cmd) are callee-owned slots of a ring: a seeded pair stays valid for 4096 further seeds, a
- * per-call set for 4096 further cull_geometry / cull_terrain calls (a batched call uses one per element) on the same oxc_ctx. */
+ * per-call set for 4096 further cull_geometry / cull_terrain calls (a batched call uses one per element; an early call with
+ * share_pass_tests takes the late call's set with its own) on the same oxc_ctx. */
 oxc_status oxc_seed_meshlet_instances(oxc_ctx* ctx, oxc_cull_geometry_context* context, uint32_t total,
                                       void* hip_stream);
 

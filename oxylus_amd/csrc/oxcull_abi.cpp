@@ -540,7 +540,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     return wait_triangles(ctx, s, [&](const oxc_ctx::TriPending& tp) { return !(late && !tp.late && tp.vis == vis_now && tp.visible == visible_buf); });
   };
 
-  uint32_t* slot = next_slot(ctx);
+  uint32_t* slot = c->init_cull_meshes ? next_slot(ctx) : nullptr;  // (otherwise taken below: a late call may find its slot prepared)
   uint32_t* vis;
   uint32_t* meshlets_cmd;
   uint32_t n_host = 0;  // list length when the host knows it (oxc_seed_meshlet_instances), else 0
@@ -607,6 +607,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
   }
   if (!armed_late && ctx->shared.armed_for_call <= call_no) ctx->shared.armed_for_call = ~0ull;  // (armed for this call only)
+  if (!slot) slot = next_slot(ctx);
   uint32_t* tri_cmd = slot + SLOT_TRI_CMD;
   uint32_t* draw_cmd = slot + SLOT_DRAW_CMD;
   c->cull_triangles_cmd_buffer = {tri_cmd, 12};
