@@ -50,6 +50,41 @@ def build_mesh_lods(positions: torch.Tensor, indices: torch.Tensor, normals: Opt
         lib.oxc_mesh_build_destroy(h)
 
 
+def vertex_fetch_remap(first_use: torch.Tensor, vertex_count: int) -> torch.Tensor:
+    """meshopt_optimizeVertexFetchRemap as the reference's asset path uses it (AssetManager_GLTF.cpp:512-568): new id of every vertex =
+    its rank by first appearance in `first_use` (an index stream); vertices the stream never names keep their relative order behind
+    the used ones (the reference drops them; keeping them keeps every per-vertex stream the same length).  Returns remap[old] = new."""
+    ids = np.ascontiguousarray(first_use.detach().cpu().numpy().reshape(-1), dtype=np.int64)
+    _, first = np.unique(ids, return_index=True)
+    used_in_order = ids[np.sort(first)]
+    seen = np.zeros(vertex_count, dtype=bool)
+    seen[used_in_order] = True
+    order = np.concatenate([used_in_order, np.nonzero(~seen)[0]])  # order[new] = old
+    remap = np.empty(vertex_count, dtype=np.int64)
+    remap[order] = np.arange(vertex_count, dtype=np.int64)
+    return torch.from_numpy(remap)
+
+
+def reorder_vertices(lods: List[dict], streams: List[torch.Tensor], by: str = "meshlets"):
+    """Vertex order for the fetches of the triangle stage.  by="indices": first use in LOD 0's index buffer -- the reference's order
+    (AssetManager_GLTF.cpp:512-568 remaps before it simplifies and clusters).  by="meshlets" (default): first use in LOD 0's
+    indirect_vertex_indices, i.e. in meshlet order -- a meshlet's <= 64 vertices then sit next to each other in vertex_positions except
+    for the ones an earlier meshlet introduced, and cull_triangles' position gather (64 lanes x 8 bytes) touches a handful of cache lines
+    instead of one per grid row of the source mesh.  Same geometry, same meshlets, same bounds; only ids move.
+    Returns (lods with remapped "vidx" / "indices", [stream[order] for stream in streams])."""
+    V = int(streams[0].shape[0])
+    remap = vertex_fetch_remap(lods[0]["vidx"] if by == "meshlets" else lods[0]["indices"], V)
+    order = torch.empty(V, dtype=torch.int64)
+    order[remap] = torch.arange(V, dtype=torch.int64)
+    out = []
+    for l in lods:
+        m = dict(l)
+        m["vidx"] = remap[l["vidx"].to(torch.int64)].to(torch.int32)
+        m["indices"] = remap[l["indices"].to(torch.int64)].to(torch.int32)
+        out.append(m)
+    return out, [st[order.to(st.device)] for st in streams]
+
+
 def make_scene_from_lods(n_mesh_instances: int, lods: List[dict], bounds_per_lod: List[torch.Tensor], positions_u16x4: torch.Tensor, mesh_bounds6: torch.Tensor,
                          seed: int = 0x0A1DE5, device="cpu", **spec_kw):
     """A scene of randomly placed instances of ONE mesh with its whole LOD chain (arrays LOD-major, as the mesh blob holds them):
