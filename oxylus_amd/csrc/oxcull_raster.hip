@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void k_draw_rows(DrawArgs a) {
 
 // vs_main (visbuffer_encode.slang:24-49) for the three corners of a triangle given its three index-buffer entries: clip coordinates +
 // the encoded vis value.
-OXC_DEV void tri_clip_coords(const DrawArgs& a, const uint32_t (&idx)[3], float (&clip)[3][4], uint32_t& vis_out) {
+// first_mli: the MeshletInstance record of idx[0]'s instance when the caller has fetched it already (k_draw_setup, a step ahead).
+OXC_DEV void tri_clip_coords(const DrawArgs& a, const uint32_t (&idx)[3], float (&clip)[3][4], uint32_t& vis_out, const uint2* first_mli = nullptr) {
   const uint32_t corner_bits = a.wide ? 9u : 8u;
   const uint32_t corner_mask = (1u << corner_bits) - 1u;
   // The three indices of a triangle written by cull_triangles name the same meshlet instance, so everything up to
@@ -197,7 +198,7 @@ OXC_DEV void tri_clip_coords(const DrawArgs& a, const uint32_t (&idx)[3], float 
     const uint32_t mli_index = data >> corner_bits, corner = data & corner_mask;
     if (mli_index != cur_mli) {
       cur_mli = mli_index;
-      const uint2 mli = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli_index];
+      const uint2 mli = (k == 0 && first_mli) ? *first_mli : reinterpret_cast<const uint2*>(a.meshlet_instances)[mli_index];
       const DrawRow* row = a.rows + mli.x;
       const uint4 p0 = reinterpret_cast<const uint4*>(row)[0], p1 = reinterpret_cast<const uint4*>(row)[1];
       const float4 w0 = reinterpret_cast<const float4*>(row)[2], w1 = reinterpret_cast<const float4*>(row)[3], w2 = reinterpret_cast<const float4*>(row)[4];
@@ -325,7 +326,7 @@ OXC_DEV void tri_emit(const DrawArgs& a, const TriSetup& t, uint32_t seg) {
   walk_box(a, r, r.px0, r.py0, r.px1, r.py1);
 }
 
-__global__ __launch_bounds__(256) void k_draw_setup(DrawArgs a) {
+__global__ __launch_bounds__(256, 5) void k_draw_setup(DrawArgs a) {
   set_half_denorm_flush();
   __shared__ TriLds s_tri[4][64];
   __shared__ uint32_t s_off[4][64];
@@ -334,26 +335,40 @@ __global__ __launch_bounds__(256) void k_draw_setup(DrawArgs a) {
   uint32_t* const off = s_off[wave];
   const uint32_t tris = a.draw_cmd[0] / 3u;  // VkDrawIndexedIndirectCommand.indexCount
   const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)wave, nwaves = gridDim.x * 4u;
-  uint32_t nidx[3] = {0, 0, 0};  // the next step's index-buffer entries, fetched a step ahead
+  // The fetches of a triangle hang on each other (index -> MeshletInstance -> row -> Meshlet record -> micro index -> vertex id ->
+  // position) and the kernel waits for them most of its time: the index entries are fetched two steps ahead and the MeshletInstance
+  // record of the first corner one step ahead, which takes the first two links out of a step's own chain.
+  const uint32_t corner_bits_pf = a.wide ? 9u : 8u;
+  uint32_t nidx[3] = {0, 0, 0}, nnidx[3] = {0, 0, 0};  // the next / next but one step's index-buffer entries
+  uint2 nmli = make_uint2(0u, 0u);                       // the next step's MeshletInstance record (of its first corner)
   if (wave_id * 64u + (uint32_t)lane < tris) {
 #pragma unroll
     for (int k = 0; k < 3; k++) nidx[k] = a.indices[(wave_id * 64u + (uint32_t)lane) * 3u + (uint32_t)k];
+    nmli = reinterpret_cast<const uint2*>(a.meshlet_instances)[nidx[0] >> corner_bits_pf];
+  }
+  if ((wave_id + nwaves) * 64u + (uint32_t)lane < tris) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) nnidx[k] = a.indices[((wave_id + nwaves) * 64u + (uint32_t)lane) * 3u + (uint32_t)k];
   }
   for (uint32_t base = wave_id * 64u; base < tris; base += nwaves * 64u) {  // wave-uniform
     const uint32_t tri = base + (uint32_t)lane;
     const uint32_t idx[3] = {nidx[0], nidx[1], nidx[2]};
+    const uint2 mli0 = nmli;
     {
-      const uint32_t nt = tri + nwaves * 64u;
+#pragma unroll
+      for (int k = 0; k < 3; k++) nidx[k] = nnidx[k];
+      if (tri + nwaves * 64u < tris) nmli = reinterpret_cast<const uint2*>(a.meshlet_instances)[nidx[0] >> corner_bits_pf];
+      const uint32_t nt = tri + 2u * nwaves * 64u;
       if (nt < tris) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) nidx[k] = a.indices[nt * 3u + (uint32_t)k];
+        for (int k = 0; k < 3; k++) nnidx[k] = a.indices[nt * 3u + (uint32_t)k];
       }
     }
     uint32_t count = 0;  // box pixels this lane's triangle contributes to the wave's small-triangle pass
     if (tri < tris) {
       float clip[3][4];
       uint32_t vis;
-      tri_clip_coords(a, idx, clip, vis);
+      tri_clip_coords(a, idx, clip, vis, &mli0);
       const int cls = tri_clip_class(clip);
       TriSetup t;
       if (cls == 1) {  // rare: crosses the camera plane or the guard band -- clipped by k_draw_clipped, one thread per triangle
