@@ -275,13 +275,14 @@ def profile_kernels(e, renderers, run, n: int) -> dict:
 
 
 def kernel_source_sha16() -> str:
-    """sha256 over oxylus_amd/csrc/*.hip|*.hpp: what tools/summarize_profiles.py stamps into a committed profile."""
-    import glob
+    """sha256 over the device sources of the cull path (oxcull_kernels.hip + the three headers it is made of): what
+    tools/summarize_profiles.py stamps into a committed profile.  The other translation units (rasteriser, terrain, bounds, HPB
+    producers) do not contain a kernel of the frames this file times."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "oxylus_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "oxylus_amd", "csrc", "*.hpp"))):
-        h.update(open(f, "rb").read())
+    for f in ("oxcull_kernels.hip", "oxcull_kernels.hpp", "oxcull_device.hpp", "oxcull_types.hpp"):
+        h.update(open(os.path.join(ROOT, "oxylus_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -47,14 +47,13 @@ def pmc(dirpath):
 
 
 def kernel_source_sha16():
-    """Identifies the device code a profile belongs to: sha256 over oxylus_amd/csrc/*.hip|*.hpp (bench.py compares it with the tree it runs from)."""
-    import glob
+    """Identifies the device code a profile belongs to: sha256 over the cull path's device sources (bench.py compares it with the tree it runs from)."""
     import hashlib
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(root, "oxylus_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "oxylus_amd", "csrc", "*.hpp"))):
-        h.update(open(f, "rb").read())
+    for f in ("oxcull_kernels.hip", "oxcull_kernels.hpp", "oxcull_device.hpp", "oxcull_types.hpp"):
+        h.update(open(os.path.join(root, "oxylus_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
