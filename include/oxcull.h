@@ -427,6 +427,13 @@ oxc_status oxc_mesh_build_create(const oxc_mesh_build_desc* desc, oxc_mesh_build
 uint32_t oxc_mesh_build_lod_count(const oxc_mesh_build* build);
 oxc_status oxc_mesh_build_lod(const oxc_mesh_build* build, uint32_t lod, oxc_mesh_lod_view* out);
 void oxc_mesh_build_destroy(oxc_mesh_build* build);
+/* Replaces meshopt_optimizeVertexFetchRemap as AssetManager_GLTF.cpp:512-568 uses it (host code there too): remap_out[old vertex id] = its
+ * rank by first appearance in `stream` (count entries, each < vertex_count); vertices the stream never names follow the used ones in their
+ * old order (the reference drops them: *used_out tells how many are used).  The reference passes the raw index buffer, before it simplifies
+ * and clusters.  Passing LOD 0's indirect_vertex_indices instead orders the vertices by MESHLET: the <= 64 vertices of a meshlet then lie
+ * next to each other in vertex_positions and cull_triangles' position gather touches a handful of cache lines (measured: DESIGN.md 5).  The
+ * caller applies the remap to its vertex streams and to every LOD's indices / indirect_vertex_indices; geometry and meshlets do not change. */
+oxc_status oxc_mesh_vertex_fetch_remap(const uint32_t* stream, uint64_t count, uint32_t vertex_count, uint32_t* remap_out, uint32_t* used_out);
 
 /* ---- hierarchical page buffer producer ------------------------------------------
  * Replaces the "vsm downsample hpb" pass (Oxylus/src/Render/Passes/Shadowmaps.cpp:331-366, pipeline

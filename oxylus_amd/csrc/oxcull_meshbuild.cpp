@@ -501,4 +501,20 @@ oxc_status oxc_mesh_build_lod(const oxc_mesh_build* b, uint32_t lod, oxc_mesh_lo
 
 void oxc_mesh_build_destroy(oxc_mesh_build* b) { delete b; }
 
+oxc_status oxc_mesh_vertex_fetch_remap(const uint32_t* stream, uint64_t count, uint32_t vertex_count, uint32_t* remap_out, uint32_t* used_out) {
+  if ((!stream && count) || !remap_out) return OXC_INVALID_ARG;
+  constexpr uint32_t kUnset = 0xFFFFFFFFu;
+  for (uint32_t v = 0; v < vertex_count; v++) remap_out[v] = kUnset;
+  uint32_t next = 0;
+  for (uint64_t i = 0; i < count; i++) {
+    const uint32_t v = stream[i];
+    if (v >= vertex_count) return OXC_INVALID_ARG;
+    if (remap_out[v] == kUnset) remap_out[v] = next++;
+  }
+  if (used_out) *used_out = next;
+  for (uint32_t v = 0; v < vertex_count; v++)
+    if (remap_out[v] == kUnset) remap_out[v] = next++;
+  return OXC_OK;
+}
+
 }  // extern "C"

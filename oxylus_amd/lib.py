@@ -256,6 +256,7 @@ EXPORTS = [
     "oxc_mesh_build_lod_count",
     "oxc_mesh_build_lod",
     "oxc_mesh_build_destroy",
+    "oxc_mesh_vertex_fetch_remap",
     "oxc_generate_hpb",
     "oxc_cull_terrain",
     "oxc_draw_visbuffer",
@@ -326,6 +327,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_mesh_build_lod.argtypes = [vp, C.c_uint32, C.POINTER(MeshLodView)]
     lib.oxc_mesh_build_destroy.argtypes = [vp]
     lib.oxc_mesh_build_destroy.restype = None
+    lib.oxc_mesh_vertex_fetch_remap.argtypes = [vp, C.c_uint64, C.c_uint32, vp, vp]
     lib.oxc_generate_hpb.argtypes = [vp, Buffer, C.POINTER(ImageArrayU8), vp]
     lib.oxc_cull_terrain.argtypes = [vp, C.POINTER(TerrainContext), vp]
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]

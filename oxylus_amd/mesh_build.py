@@ -51,18 +51,17 @@ def build_mesh_lods(positions: torch.Tensor, indices: torch.Tensor, normals: Opt
 
 
 def vertex_fetch_remap(first_use: torch.Tensor, vertex_count: int) -> torch.Tensor:
-    """meshopt_optimizeVertexFetchRemap as the reference's asset path uses it (AssetManager_GLTF.cpp:512-568): new id of every vertex =
-    its rank by first appearance in `first_use` (an index stream); vertices the stream never names keep their relative order behind
-    the used ones (the reference drops them; keeping them keeps every per-vertex stream the same length).  Returns remap[old] = new."""
-    ids = np.ascontiguousarray(first_use.detach().cpu().numpy().reshape(-1), dtype=np.int64)
-    _, first = np.unique(ids, return_index=True)
-    used_in_order = ids[np.sort(first)]
-    seen = np.zeros(vertex_count, dtype=bool)
-    seen[used_in_order] = True
-    order = np.concatenate([used_in_order, np.nonzero(~seen)[0]])  # order[new] = old
-    remap = np.empty(vertex_count, dtype=np.int64)
-    remap[order] = np.arange(vertex_count, dtype=np.int64)
-    return torch.from_numpy(remap)
+    """oxc_mesh_vertex_fetch_remap (include/oxcull.h; meshopt_optimizeVertexFetchRemap as AssetManager_GLTF.cpp:512-568 uses it): new id of
+    every vertex = its rank by first appearance in `first_use` (an index stream); vertices the stream never names keep their relative order
+    behind the used ones.  Returns remap[old] = new (int64)."""
+    lib = L.load()
+    ids = np.ascontiguousarray(first_use.detach().cpu().numpy().reshape(-1), dtype=np.uint32)
+    remap = np.empty(vertex_count, dtype=np.uint32)
+    used = C.c_uint32(0)
+    st = lib.oxc_mesh_vertex_fetch_remap(ids.ctypes.data, ids.shape[0], vertex_count, remap.ctypes.data, C.byref(used))
+    if st != L.OXC_OK:
+        raise L.OxcError(st, "oxc_mesh_vertex_fetch_remap: an index >= vertex_count")
+    return torch.from_numpy(remap.astype(np.int64))
 
 
 def reorder_vertices(lods: List[dict], streams: List[torch.Tensor], by: str = "meshlets"):
