@@ -965,7 +965,7 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 // over dirty views; views a whole wave no longer needs are skipped.  Output: ballots, expanded
 // by k_cull_meshlets_emit<false,false> like the plain meshlet stage.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
+__global__ __launch_bounds__(256, 6) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   // Round 2: the view loop is the OUTER loop of a wave step.  Round 1 walked one 64-meshlet group at a time and, inside it, one
   // clipmap view at a time, so every (group, view) paid the scalar-load round trips of the view's plane / matrix row on its own --
   // 0.89 ms per 10 M meshlets, latency-bound.  Here a wave holds G groups (all loads batched, as in the plain kernel) and a view's
@@ -978,7 +978,9 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   __shared__ uint32_t s_level_off[13];
   constexpr int G = (int)kGroupsPerWave;
   constexpr uint32_t kWaves = 4;
-  __shared__ uint4 s_strip[kWaves][G * 64];
+  __shared__ uint4 s_strip[kWaves][G * 64];   // the candidates of a round (camera frustum + cone survivors), dense
+  __shared__ uint32_t s_strip2[kWaves][G * 64];  // of those, the strip positions of the ones inside the current view's frustum: the page test's lanes
+  __shared__ uint32_t s_seen[kWaves][G * 64];  // per candidate: some view's pages want it
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = min(a.vis[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
@@ -1003,6 +1005,8 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
     return t;
   };
   uint4* const strip = s_strip[wave];
+  uint32_t* const strip2 = s_strip2[wave];
+  uint32_t* const seen = s_seen[wave];
   uint32_t step = OXC_TICKET_STEP(readlane_u(draw_ticket(), 0), K, kx);
   while (step < nsteps) {
     const uint32_t group0 = step * G;
@@ -1068,73 +1072,80 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
           any_cand |= __builtin_amdgcn_ballot_w64(cand[j]);
         }
       }
-      // "visible if ANY dirty clipmap view passes frustum + page test" (:59-79); the reference's break on the first hit has no side effect
-      for (uint32_t v = 0; v < a.clipmap_count && any_cand; v++) {
-        if (a.dirty[v] == 0u) continue;  // uniform
-        uint64_t need_any = 0;
+      // "visible if ANY dirty clipmap view passes frustum + page test" (:59-79); the reference's break on the first hit has no side effect.
+      // The candidates of the round (camera frustum + cone survivors: a minority of the lanes) are compacted once through the LDS
+      // strip; every view then runs its frustum over ceil(candidates / 64) DENSE batches (round 2 ran it over the G sparse groups),
+      // compacts the strip positions of the lanes inside it and runs the page test (8 projected corners + the pyramid fetches) over
+      // those.  A candidate some view has accepted drops out.
+      if (any_cand) {
+        uint64_t cb[G];
+        uint32_t base[G + 1], slot[G];
+        base[0] = 0;
 #pragma unroll
-        for (int j = 0; j < G; j++) need_any |= __builtin_amdgcn_ballot_w64(cand[j] && !vis[j]);
-        if (need_any == 0) break;  // nobody in the wave still needs a view
-        const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
-        bool inside[G];
-        uint64_t any_inside = 0;
-        {
-          float vpl[24], vsg[18];
+        for (int j = 0; j < G; j++) {
+          cb[j] = __builtin_amdgcn_ballot_w64(cand[j]);
+          base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)cb[j]);
+        }
+        const uint32_t total = base[G];
 #pragma unroll
-          for (int k = 0; k < 24; k++) vpl[k] = asf(vrow[kRowPlanes + k]);
-#pragma unroll
-          for (int k = 0; k < 18; k++) vsg[k] = asf(vrow[kRowSigns + k]);
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            inside[j] = false;
-            if (__builtin_amdgcn_ballot_w64(cand[j] && !vis[j]) == 0) continue;  // wave-uniform
-            uint4 b = bnd[j];
-            asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-            OXC_HPB_DECODE(b);
-            inside[j] = (cand[j] && !vis[j]) & test_frustum_planes(vpl, vsg, cxj, cyj, czj, exj, eyj, ezj);
-            any_inside |= __builtin_amdgcn_ballot_w64(inside[j]);
+        for (int j = 0; j < G; j++) {
+          slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(cb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb[j], 0u));
+          if (cand[j]) {
+            strip[slot[j]] = bnd[j];
+            seen[slot[j]] = 0u;
           }
         }
-        if (any_inside) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
+        uint32_t open_count = total;  // candidates no view has accepted yet (wave-uniform)
+        for (uint32_t v = 0; v < a.clipmap_count && open_count; v++) {
+          if (a.dirty[v] == 0u) continue;  // uniform
+          const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
+          uint32_t n_in = 0;  // lanes inside this view's frustum so far: strip2[0 .. n_in)
+          {
+            float vpl[24], vsg[18];
+#pragma unroll
+            for (int k = 0; k < 24; k++) vpl[k] = asf(vrow[kRowPlanes + k]);
+#pragma unroll
+            for (int k = 0; k < 18; k++) vsg[k] = asf(vrow[kRowSigns + k]);
+            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+              const uint32_t t = t0 + (uint32_t)lane;
+              const bool act = t < total && seen[t < total ? t : 0u] == 0u;
+              const uint4 b = strip[t < total ? t : total - 1u];
+              OXC_HPB_DECODE(b);
+              const bool in = act & test_frustum_planes(vpl, vsg, cxj, cyj, czj, exj, eyj, ezj);
+              const uint64_t ib = __builtin_amdgcn_ballot_w64(in);
+              if (in) strip2[n_in + __builtin_amdgcn_mbcnt_hi((uint32_t)(ib >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ib, 0u))] = t;
+              n_in += (uint32_t)__popcll((unsigned long long)ib);
+            }
+          }
+          if (n_in == 0) continue;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           float vmvp[16];
 #pragma unroll
           for (int k = 0; k < 16; k++) vmvp[k] = asf(vrow[kRowMvp + k]);
           const oxc_virtual_clipmap* cm = a.clipmaps + v;
           const float z_near = cm->z_near;
           const int32_t pox = cm->page_offset[0], poy = cm->page_offset[1];
-          uint64_t ib[G];
-          uint32_t base[G + 1], slot[G];
-          base[0] = 0;
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            ib[j] = __builtin_amdgcn_ballot_w64(inside[j]);
-            base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)ib[j]);
-          }
-          const uint32_t total = base[G];
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(ib[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ib[j], 0u));
-            if (inside[j]) strip[slot[j]] = bnd[j];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
-          for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+          for (uint32_t t0 = 0; t0 < n_in; t0 += 64) {
             const uint32_t t = t0 + (uint32_t)lane;
-            const bool act = t < total;
-            const uint4 b = strip[act ? t : total - 1u];
+            const bool act = t < n_in;
+            const uint32_t at = strip2[act ? t : n_in - 1u];
+            const uint4 b = strip[at];
             OXC_HPB_DECODE(b);
             float sa[6];
             bool pass = true;  // projection crosses the near plane: visible (cull_meshlets_hpb.slang:70-76)
             if (project_aabb<true>(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa)) pass = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (act) strip[t].x = pass ? 1u : 0u;
+            const bool hit = act && pass;
+            if (hit) seen[at] = 1u;
+            open_count -= (uint32_t)__popcll((unsigned long long)__builtin_amdgcn_ballot_w64(hit));
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            if (inside[j]) vis[j] = strip[slot[j]].x != 0u;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is rewritten by the next view
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next view reads the flags and rewrites strip2
         }
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          if (cand[j]) vis[j] = seen[slot[j]] != 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip and flags are rewritten by the next round
       }
 #pragma unroll
       for (int j = 0; j < G; j++) st[j] = mine[j] ? ((cand[j] && vis[j]) ? 2u : 0u) : st[j];
