@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--no-share-pass-tests", action="store_true",
                     help="config3: every call runs its own frustum + cone tests; by default the two calls of a frame set share_pass_tests (include/oxcull.h): the late "
                          "call reuses the early call's results -- same outputs; the other form is timed as a variant in scheduling_ab")
+    ap.add_argument("--unordered-output", type=int, default=0, choices=[0, 1, 2],
+                    help="config3: unordered_output of include/oxcull.h on the main line (0 = ascending lists, the default; 1 = fused triangle stage; 2 = appending "
+                         "HiZ meshlet tests too); the default line carries the other forms as scheduling_ab variants, compared as sorted sets")
+    ap.add_argument("--no-tris124", action="store_true", help="config3: skip the nested run with BASELINE's stated meshlet shape (64 verts / 124 tris, wide index, 8M meshlets)")
     ap.add_argument("--no-scheduling-ab", action="store_true", help="config3: skip the short timed runs of the other schedulings (profiling runs: their concurrent kernels would "
                                                                     "be averaged into the per-kernel durations of a kernel trace)")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the short timed run with the other --hiz-exchange form")
@@ -441,6 +445,7 @@ def bench_config3(args, e):
     # share_pass_tests (include/oxcull.h): both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884), so the
     # late call takes the frustum + cone results from the early one
     use_share = [not args.no_share_pass_tests]
+    use_unord = [int(args.unordered_output)]  # unordered_output (include/oxcull.h): the reference's atomic slot allocation instead of the ordered emit
 
     def run_frame(record=None):
         f = frame_no[0]
@@ -468,6 +473,7 @@ def bench_config3(args, e):
         c = cctx[b]
         c.async_triangles = int(use_async[0])
         c.share_pass_tests = int(use_share[0])
+        c.unordered_output = use_unord[0]
         c.cull_flags = L.CULL_TEST_ALL
         check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
         if record is not None:
@@ -499,13 +505,22 @@ def bench_config3(args, e):
         if rank == 0:
             lim = min(args.cpu_prefix, M) * K  # the checker's sample: ids below `lim` (ascending lists: a prefix of each list)
             vis = frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x]
-            nv = int(torch.searchsorted(vis, torch.tensor([lim], dtype=torch.int32, device=dev)).item())
-            # packed (id << 8 | corner) values are u32: search an upper-bounded head of the list as int64
             shift = 9 if wide else 8
-            head = frame.reordered_indices_buffer[:min(out.draw_index_count, nv * (384 if wide else 192))].to(torch.int64) & 0xFFFFFFFF
-            ni = int(torch.searchsorted(head, torch.tensor([lim << shift], dtype=torch.int64, device=dev)).item())
-            snap[tag]["visible_prefix"] = vis[:nv].cpu()
-            snap[tag]["indices_prefix"] = frame.reordered_indices_buffer[:ni].cpu()
+            if use_unord[0]:  # an unordered list is compared SORTED (the ordered form's lists ascend)
+                vis = torch.sort(vis)[0]
+                allidx = torch.sort(frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64) & 0xFFFFFFFF)[0]
+                nv = int(torch.searchsorted(vis, torch.tensor([lim], dtype=torch.int32, device=dev)).item())
+                ni = int(torch.searchsorted(allidx, torch.tensor([lim << shift], dtype=torch.int64, device=dev)).item())
+                snap[tag]["visible_prefix"] = vis[:nv].cpu()
+                snap[tag]["indices_prefix"] = allidx[:ni].to(torch.int32).cpu()
+                del allidx
+            else:
+                nv = int(torch.searchsorted(vis, torch.tensor([lim], dtype=torch.int32, device=dev)).item())
+                # packed (id << 8 | corner) values are u32: search an upper-bounded head of the list as int64
+                head = frame.reordered_indices_buffer[:min(out.draw_index_count, nv * (384 if wide else 192))].to(torch.int64) & 0xFFFFFFFF
+                ni = int(torch.searchsorted(head, torch.tensor([lim << shift], dtype=torch.int64, device=dev)).item())
+                snap[tag]["visible_prefix"] = vis[:nv].cpu()
+                snap[tag]["indices_prefix"] = frame.reordered_indices_buffer[:ni].cpu()
 
     with torch.cuda.stream(stream):
         run_frame(record)
@@ -517,13 +532,18 @@ def bench_config3(args, e):
     t_early, t_late = counts["early_index_count"] // 3, counts["late_index_count"] // 3
 
     def outputs_checksum():
-        """Every output of the last frame folded into a few integers (device-side sums): what a scheduling variant must reproduce."""
+        """Every output of the last frame folded into a few integers (device-side sums): what a scheduling variant must reproduce.
+        Lists written with unordered_output are sorted first (early and late list each; the ordered form's lists ascend)."""
         torch.cuda.synchronize()
         out = L.Counters()
         check(lib.oxc_read_counters(ctxp, C.byref(cctx[(frame_no[0] - 1) % len(hiz)]), C.byref(out), sp))
-        nv = out.early_visible_meshlet_instances + out.late_visible_meshlet_instances
+        ne = out.early_visible_meshlet_instances
+        nv = ne + out.late_visible_meshlet_instances
         vis = frame.visible_meshlet_instances_indices_buffer[:nv].to(torch.int64)
         idx = frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64) & 0xFFFFFFFF
+        if use_unord[0]:
+            vis = torch.cat([torch.sort(vis[:ne])[0], torch.sort(vis[ne:])[0]])
+            idx = torch.sort(idx)[0]
         wv = torch.arange(1, 1 + vis.numel(), device=dev, dtype=torch.int64) % 1000003
         wi = torch.arange(1, 1 + idx.numel(), device=dev, dtype=torch.int64) % 1000003
         return (out.early_visible_meshlet_instances, out.late_visible_meshlet_instances, out.draw_index_count, int((vis * wv).sum().item()),
@@ -542,29 +562,36 @@ def bench_config3(args, e):
     # stream beside this frame's cull (what N > 1 does by default); (c) both.  Every variant must leave the outputs of the in-order run.
     ab_steps = max(2, args.steps // 4)
 
-    def timed_variant(async_on, ahead_on, share_on):
+    def timed_variant(async_on, ahead_on, share_on, unord=None):
         use_async[0], use_overlap[0], use_share[0] = async_on, ahead_on, share_on
+        use_unord[0] = main_unord if unord is None else unord
         el = timed_steps(e, run_step, ab_steps, 1)
-        return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "share_pass_tests": share_on, "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
+        return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "share_pass_tests": share_on, "unordered_output": use_unord[0],
+                "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
                 "value": round(n_meshlets * world * ab_steps * inner / el, 1), "frames_timed": ab_steps * inner, "outputs_match_main_line": outputs_checksum() == sum_main}
 
-    main_async, main_ahead, main_share = use_async[0], use_overlap[0], use_share[0]
+    main_async, main_ahead, main_share, main_unord = use_async[0], use_overlap[0], use_share[0], use_unord[0]
     variants = []
     if not args.no_scheduling_ab:
+        for other in (u for u in (0, 1, 2) if u != main_unord):  # the list layouts of include/oxcull.h (compared as sorted sets)
+            variants.append(timed_variant(main_async, main_ahead, main_share, other))
         variants.append(timed_variant(main_async, main_ahead, not main_share))
         variants.append(timed_variant(not main_async, main_ahead, main_share))
         if world == 1:
             variants.append(timed_variant(main_async, not main_ahead, main_share))
             variants.append(timed_variant(not main_async, not main_ahead, main_share))
-        use_async[0], use_overlap[0], use_share[0] = main_async, main_ahead, main_share
+        use_async[0], use_overlap[0], use_share[0], use_unord[0] = main_async, main_ahead, main_share, main_unord
         with torch.cuda.stream(stream):
             run_frame()  # (back in the main line's form before the kernel profile below)
         torch.cuda.synchronize()
     sched_ab = {"main_line": {"async_triangles": main_async, "hiz_one_frame_ahead_on_second_stream": main_ahead, "share_pass_tests": main_share,
-                              "ms_per_frame": round(ms_per_frame, 6)},
+                              "unordered_output": main_unord, "ms_per_frame": round(ms_per_frame, 6)},
                 "variants": variants,
-                "note": "share_pass_tests: the late call of a frame reads the early call's frustum + cone results (one bit per meshlet) instead of testing again -- a cache "
-                        "inside liboxcull, valid because both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884); the first variant is "
+                "note": "unordered_output (include/oxcull.h): 0 = ascending lists, test + ordered emit per stage; 1 = the triangle stage as ONE launch that appends behind an "
+                        "atomic_add on index_count per 256-meshlet span (cull_triangles.slang:71-88), HiZ meshlet stage unchanged; 2 = the HiZ meshlet tests append as well, one "
+                        "atomic_add pair per wave step (cull_meshlets_hiz.slang:67-78 aggregated through the ballot) -- variants of it are compared with the main line as sorted sets.  "
+                        "share_pass_tests: the late call of a frame reads the early call's frustum + cone results (one bit per meshlet) instead of testing again -- a cache "
+                        "inside liboxcull, valid because both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884); the variant that flips it is "
                         "the frame with every call testing on its own.  async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "
                         "events both ways, double-buffered pyramid -- legal here because the depth image a frame's pyramid is built from is given; in the engine the "
                         "pyramid is built from the early draw's depth between the two culls of a frame (RendererInstance.cpp:842-884), which is why the main line stays in order"}
@@ -602,9 +629,15 @@ def bench_config3(args, e):
         "cull_triangles_emit": v_early * (8.0 * H + 4.0) + 12.0 * t_early,
         "cull_triangles_emit_late": v_late * (8.0 * H + 4.0) + 12.0 * t_late,
     }
+    if main_unord:  # the fused kernel tests AND expands: no pass masks or visible ids through memory (-2 x 8 H, -4 B per visible meshlet)
+        alg["cull_triangles_test"] = v_early * tri_bytes_per_meshlet + 12.0 * t_early
+        alg["cull_triangles_test_late"] = v_late * tri_bytes_per_meshlet + 12.0 * t_late
     # the second clock: the committed rocprofv3 --kernel-trace --stats averages of the same kernels (of the build the profile was taken
     # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
-    rp = rocprof_kernel_us(["r03_config3_pmc.json", "r02_config3_pmc.json"])
+    # (the committed profiles are of the default workload: T = 64, ordered lists; any other shape has no counters of its own and says so)
+    prof_names = ["r04_config3_pmc.json", "r03_config3_pmc.json"] if (not wide and not args.small_triangle_cull and main_unord == 0 and n_meshlets == 10_000_000) else (
+        ["r04_tris124_pmc.json"] if (wide and main_unord == 0 and not args.small_triangle_cull) else [])
+    rp = rocprof_kernel_us(prof_names) if prof_names else {}
     rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
                 "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
                 "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
@@ -636,7 +669,7 @@ def bench_config3(args, e):
         dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
         dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        traffic, traffic_src, traffic_same = pmc_traffic(["r03_config3_pmc.json", "r02_config3_pmc.json"], lambda k: "k_cull_triangles_test" in k)
+        traffic, traffic_src, traffic_same = pmc_traffic(prof_names, lambda k: "k_cull_triangles_test" in k) if prof_names else (None, None, None)
         roofline = {"bound": "hbm", "kernel": "k_cull_triangles_test (early + late launch of a frame, averaged)", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_profile_is_of_this_device_code": traffic_same, "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
@@ -645,7 +678,10 @@ def bench_config3(args, e):
     stage = {"algorithmic_bytes_per_frame": round(frame_alg), "ms_per_frame": round(ms_per_frame, 6),
              "achieved_GBps": round(frame_alg / (ms_per_frame * 1e-3) / 1e9, 1), "stage_frac": round(frame_alg / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
              "sum_of_kernel_us_per_frame": round(frame_kernel_us, 1),
-             "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures, HiZ taps excluded"}
+             "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures, HiZ taps excluded.  "
+                     "With share_pass_tests the late meshlet test is still CHARGED the reference's 24.25 B per meshlet although it fetches ~14.7 (no MeshletInstance "
+                     "record and no bounds for steps nothing of which passed the camera tests): ~95 MB of the frame's algorithmic bytes, and that kernel's frac, are the "
+                     "reference's traffic, not this kernel's (SURVEY 8d defines algorithmic bytes by the reference's data flow)"}
 
     # ---- CPU checker on a bounded prefix of the SAME arrays: bit_match + cpu_baseline (rank 0, N = 1) ----
     bit_match, cpu_baseline, hiz_match, unpinned = None, None, None, None
@@ -775,13 +811,14 @@ def bench_config3(args, e):
                                                          "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if xmode["top"] else "whole pyramid broadcast from rank 0"),
                                                          "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": use_overlap[0],
                                                          "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame, "hiz_exchange_ab": exchange_ab},
-            "async_triangles": bool(use_async[0]), "share_pass_tests": bool(use_share[0]),
+            "async_triangles": bool(use_async[0]), "share_pass_tests": bool(use_share[0]), "unordered_output": main_unord,
         },
         "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
         "unpinned_gap": unpinned, "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
         "scheduling_ab": sched_ab,
     }
     # free the 25 GB of this workload before the nested one
+    r_hiz.close()
     del scene, frame, depth, hiz, mask0
     torch.cuda.empty_cache()
     return line
@@ -899,6 +936,37 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
               "hip_graph": True, "frames_timed": reps1 * copies, "seconds": round(el1, 3)}
     del g1
 
+    # ---- (c) the same single call with unordered_output = 1 (include/oxcull.h): the test kernel appends its survivors behind one atomic_add per
+    # 1024 meshlets (cull_meshlets.slang:55-70 aggregated through the ballots) and no emit kernel runs -- two launches per call instead of three
+    for s_ in st_:
+        s_.cctx.unordered_output = 1
+    with torch.cuda.stream(stream):
+        st_[0].frame.visible_meshlet_instances_indices_buffer.fill_(-1)
+        check(r, lib.oxc_cull_geometry(r._ctx, st_[0].pf, st_[0].pc, sps[0]))
+    torch.cuda.synchronize()
+    cu = L.Counters()
+    check(r, lib.oxc_read_counters(r._ctx, st_[0].pc, C.byref(cu), sps[0]))
+    unordered_match = None
+    if rank == 0:
+        got_u = torch.sort(st_[0].frame.visible_meshlet_instances_indices_buffer[: cu.cull_triangles_cmd_x])[0].cpu()
+        unordered_match = bool(cu.cull_triangles_cmd_x == c0.cull_triangles_cmd_x and torch.equal(want, got_u))
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=stream):
+        for s_ in st_:
+            check(r, lib.oxc_cull_geometry(r._ctx, s_.pf, s_.pc, sps[0]))
+
+    def replay2(_i):
+        for _ in range(reps1):
+            g2.replay()
+
+    el2 = timed_steps(e, replay2, 1, 1)
+    single_unordered = {"value": round(n_meshlets * world * reps1 * copies / el2, 1), "ms_per_frame": round(el2 * 1e3 / (reps1 * copies), 6), "frames_per_launch": 1, "streams": 1,
+                        "hip_graph": True, "unordered_output": 1, "launches_per_call": 2, "frames_timed": reps1 * copies, "seconds": round(el2, 3),
+                        "sorted_list_equals_the_checkers": unordered_match}
+    del g2
+    for s_ in st_:
+        s_.cctx.unordered_output = 0
+
     # ---- per-kernel times on one stream (>= 50 batched launches) and the roofline of the dominant kernel ----
     n_prof = max(50, min(len(groups), 96))
     kern = profile_kernels(e, renderers, run_group, n_prof)
@@ -923,6 +991,7 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
         stage_bytes = n_meshlets * (24.0 + 212.0 / K + 4.0 * visible_fraction)
         batched["stage_frac"] = round(stage_bytes / (batched["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         single["stage_frac"] = round(stage_bytes / (single["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        single_unordered["stage_frac"] = round(stage_bytes / (single_unordered["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
 
     cpu_baseline = None
     if with_cpu and rank == 0 and world == 1 and cpu_scene is not None:
@@ -953,7 +1022,8 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
     return {
         "workload": "configs[1]: 1M meshlets, one camera, frustum + cone cull + ordered compaction (cull_meshlets stage)",
         "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "copies_rotated": copies, "working_set_MB": round(copies * bytes_per_copy / 1e6, 1),
-        "visible_fraction": round(visible_fraction, 4), "bit_match": bit_match, "batched": batched, "one_call_per_frame": single, "kernels": kernels,
+        "visible_fraction": round(visible_fraction, 4), "bit_match": bit_match, "batched": batched, "one_call_per_frame": single,
+        "one_call_per_frame_unordered": single_unordered, "kernels": kernels,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
 
@@ -1031,10 +1101,26 @@ def main():
                 "data": "synthetic", "config": {"workload": res["workload"], "inner_reps": b["frames_timed"] // args.steps, **{k: res[k] for k in
                                                 ("meshlets_per_gpu", "mesh_instances", "copies_rotated", "working_set_MB", "visible_fraction")},
                                                 "frames_per_launch": b["frames_per_launch"], "streams": b["streams"]},
-                "bit_match": res["bit_match"], "batched": b, "one_call_per_frame": res["one_call_per_frame"], "kernels": res["kernels"], "roofline": res["roofline"],
+                "bit_match": res["bit_match"], "batched": b, "one_call_per_frame": res["one_call_per_frame"], "one_call_per_frame_unordered": res["one_call_per_frame_unordered"],
+                "kernels": res["kernels"], "roofline": res["roofline"],
                 "cpu_baseline": res["cpu_baseline"]}))
     else:
         line = bench_config3(args, e)
+        if e.world == 1 and not args.no_tris124 and args.tris == 64 and not args.meshlets:
+            # BASELINE's stated meshlet shape -- 64 vertices / 124 triangles -- does not fit the reference's 24 + 8 bit packed index: the same
+            # frame with the wide index extension ((id << 9) | corner, two 64-lane triangle passes, at most 2^23 ids: 8 M meshlets), a short run
+            import copy
+
+            a2 = copy.copy(args)
+            a2.tris, a2.steps, a2.warmup = 124, max(4, args.steps // 4), 1
+            a2.no_scheduling_ab, a2.no_cpu_baseline, a2.cpu_prefix, a2.unordered_output = True, True, min(args.cpu_prefix, 250), 0
+            t = bench_config3(a2, e)
+            line["tris124"] = {"workload": "the configs[2] frame with 64 vertices / 124 triangles per meshlet (BASELINE's stated shape): wide_triangle_index, "
+                                           f"{t['config']['meshlets_per_gpu']} meshlets (2^23 ids), 4096^2 HiZ", "value": t["value"], "unit": "meshlets/s",
+                               "ms_per_frame": t["config"]["ms_per_frame"], "frames_timed": t["config"]["frames_timed"], "wide_triangle_index": True,
+                               "visible_fraction": t["config"]["visible_fraction"], "triangles_per_visible_meshlet": t["config"]["triangles_per_visible_meshlet"],
+                               "bit_match": t["bit_match"], "bit_match_sample": t["bit_match_sample"], "counts": t["counts"], "roofline": t["roofline"], "stage": t["stage"],
+                               "kernels": {k: v for k, v in t["kernels"].items() if k.startswith("cull_triangles") or k.startswith("_")}}
         if e.world == 1 and not args.no_configs1:
             line["configs1"] = bench_config2(args, e, steps=8, warmup=1, with_cpu=not args.no_cpu_baseline)
         if e.world == 1 and not args.no_configs4:

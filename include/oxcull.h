@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OXC_ABI_VERSION 4u
+#define OXC_ABI_VERSION 5u
 
 typedef struct oxc_ctx oxc_ctx;
 
@@ -157,7 +157,9 @@ typedef struct oxc_cull_geometry_context {
    * (pixel centres sit at k + 0.5: an interval [lo, hi] holds one iff the two roundings differ).  Not supported by
    * the fused path of oxc_cull_geometry_batch (such elements are processed one after the other). */
   uint32_t small_triangle_cull;
-  /* Extension (scheduling only, no effect on any output byte): 1 = the triangle stage of this call (cull_triangles test + ordered
+  /* EXPERIMENTAL extension (scheduling only, no effect on any output byte; on MI355X it has not been faster than the in-order call in any
+   * measured configuration -- both stages keep the vector ALUs and the memory system busy, DESIGN.md 4c -- and exists for engines whose
+   * draw sits between the two calls): 1 = the triangle stage of this call (cull_triangles test + ordered
    * emit) is enqueued on a second stream the context owns and runs BESIDE whatever is enqueued on hip_stream next -- typically the
    * meshlet stage of the following oxc_cull_geometry call (ALU-bound, while the triangle stage is HBM-bound) and oxc_generate_hiz.
    * reordered_indices_buffer and draw_geometry_cmd_buffer of this call are complete on a stream only after
@@ -181,7 +183,21 @@ typedef struct oxc_cull_geometry_context {
    * that follows it directly (same capture, if any), which then launches no prepare kernel.  Only with use_hiz
    * and OXC_CULL_TEST_OCCLUSION; ignored elsewhere and by oxc_cull_geometry_batch.  0 (default) = every call tests on its own. */
   uint32_t share_pass_tests;
-  uint32_t _reserved0; /* must be 0 */
+  /* Extension (output ORDER only; counts and the SET of emitted ids / packed triangles are those of the ordered form, and the mask bytes
+   * are identical): how the compacted lists are laid out.  The reference allocates output slots with atomics -- one atomic_add per
+   * 64-thread workgroup in cull_meshlets.slang:55-70 and cull_triangles.slang:71-88, two per visible thread in
+   * cull_meshlets_hiz.slang:67-78 -- so its order is whatever the race gives.
+   *   0 (default) = ascending lists, deterministic: test -> ballots -> ordered emit, two launches per stage.
+   *   1 = unordered where that is the faster form on this part: the triangle stage is ONE launch (a block tests a span of 256 visible
+   *       meshlets and appends its packed indices behind one atomic_add on index_count), the plain meshlet stage (no use_hiz / use_hpb)
+   *       is one launch (one atomic_add on cull_triangles_cmd.x per 1024 meshlets); the HiZ / HPB meshlet stages keep the ordered
+   *       two-launch form (their per-wave-step appends would queue on one address: see 2).
+   *   2 = as 1, and the HiZ meshlet stage also appends by itself: one atomic_add pair per wave step (256 meshlets) with a survivor on
+   *       the early / late counter and cull_triangles_cmd.x -- the reference's literal scheme aggregated through the ballot; a single
+   *       address retires ~88 atomics per microsecond on MI355X, which is what this form measures.  share_pass_tests is ignored.
+   * Inside a block's run the ids ascend; the runs land in arrival order.  A triangle's three packed indices stay adjacent.  Sorting a
+   * list gives the bytes of the ordered form (tests/test_gpu_unordered.py).  Ignored by oxc_cull_geometry_batch's fused path. */
+  uint32_t unordered_output;
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */
@@ -225,7 +241,8 @@ oxc_status oxc_generate_hiz(oxc_ctx* ctx, const oxc_main_geometry_context* conte
 /* Replaces RendererInstance::cull_geometry (Passes/CullGeometry.cpp:61-404; kernels
  * passes/cull_meshes.slang, cull_meshlets.slang, cull_meshlets_hiz.slang, cull_triangles.slang).
  * Output lists are written in ascending order (a valid outcome of the reference's
- * atomic-ordered output, and a deterministic one). */
+ * atomic-ordered output, and a deterministic one) unless context->unordered_output asks for the
+ * reference's own atomic slot allocation. */
 oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* frame, oxc_cull_geometry_context* context,
                              void* hip_stream);
 
@@ -550,6 +567,15 @@ oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32
  * also published its results, 2: late call that reused them, 3: late call that reused them and launched no prepare kernel (the early
  * call had done that work too: it was in order on one stream and directly in front of it). */
 uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
+
+/* Harness hook: sizing / scheduling knobs of a context that the measurements and the tests move (the library itself reads no environment
+ * variable).  OXC_TUNE_ASYNC_*: resident blocks per CU the persistent kernels of the meshlet / triangle stage take while async_triangles
+ * lets the two stages share the machine (0 = no limit, the default).  OXC_TUNE_RASTER_BIG_CAPACITY: entries of oxc_draw_visbuffer's
+ * big-triangle / clip queues (default 2^22); only before the context's first draw, which allocates them -- the tests shrink it to reach
+ * the overflow paths with a small scene. */
+enum { OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU = 0, OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU = 1, OXC_TUNE_RASTER_BIG_CAPACITY = 2,
+       OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */ };
+oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value);
 
 /* Test hook: what the last oxc_draw_visbuffer on this context did with its triangles; synchronises the stream.
  * out4 = {triangles queued for the big path (pixel box beyond 8 x 8), triangles that crossed a clip plane, 64 x 64 tiles handed to

@@ -70,6 +70,7 @@ struct oxc_ctx {
   uint32_t bounds_scratch_cap = 0;
   void* raster_scratch = nullptr;  // oxc_draw_visbuffer: list of large triangles + its counter
   uint32_t raster_capacity = 0;    // entries of the big / clip lists (the tile list has twice as many)
+  uint32_t raster_capacity_request = 0;  // oxc_debug_set_tuning(OXC_TUNE_RASTER_BIG_CAPACITY): used by the first draw instead of the default
   void* raster_rows = nullptr;     // oxc_draw_visbuffer: one DrawRow per mesh instance
   uint32_t raster_rows_cap = 0;
   void* comm = nullptr;            // ncclComm_t (oxc_comm_init)
@@ -95,6 +96,9 @@ struct oxc_ctx {
     bool late = false;
     const uint32_t* vis = nullptr;  // the sequence's visibility counters (the late list starts at vis[1])
     const void* visible = nullptr;  // visible_meshlet_instances_indices_buffer it reads
+    unsigned long long capture_id = 0;  // the HIP-graph capture `done` was recorded in (0: none).  An event recorded outside a capture cannot be
+                                        // waited for inside one and the reverse (hipErrorStreamCaptureIsolation): wait_triangles only waits within
+                                        // the same capture
   };
   static constexpr uint32_t kTriRing = 4;
   TriPending tri[kTriRing];
@@ -119,9 +123,10 @@ struct oxc_ctx {
   SharedTests shared;
   uint32_t last_share_mode = 0;  // oxc_debug_shared_tests_mode
   uint64_t call_seq = 0;  // lane-0 oxc_cull_geometry calls so far: parity selects cache / t_supers
-  // resident blocks per CU of the persistent kernels while the two stages share the machine (0 = no limit); the environment
-  // variables OXC_ASYNC_MTEST_BLOCKS_PER_CU / OXC_ASYNC_TRI_BLOCKS_PER_CU, read by oxc_create, override the defaults (tuning aid)
+  // resident blocks per CU of the persistent kernels while the two stages share the machine (0 = no limit); oxc_debug_set_tuning
+  // overrides the defaults (tuning aid of tools/kbench.py)
   uint32_t async_mtest_per_cu = kAsyncMeshletBlocksPerCU, async_tri_per_cu = kAsyncTriangleBlocksPerCU;
+  uint32_t tri_blocks_per_cu = kTriangleBlocksPerCU;  // grid cap of the triangle kernels (blocks walk their chunks with a grid stride)
   // profiling (oxc_profile_begin/end)
   bool profiling = false;
   struct Rec {
@@ -164,10 +169,12 @@ unsigned long long stream_capture_id(hipStream_t s);
 // previous call on ANOTHER stream is skipped -- include/oxcull.h asks the caller to have that stream's work complete (or inside the
 // same capture through the caller's own events) before the capture begins.
 oxc_status order_stream(oxc_ctx* ctx, hipStream_t s) {
-  if (ctx->has_last_stream && ctx->last_stream != s && !stream_is_capturing(s)) {
+  // (a previous stream that is itself being captured: recording on it would add a node to THAT capture and the wait below would pull `s`
+  // into it -- the two are not ordered here either; same promise of the caller as above)
+  if (ctx->has_last_stream && ctx->last_stream != s && !stream_is_capturing(s) && !stream_is_capturing(ctx->last_stream)) {
     if (!ctx->order_event) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
-    // (the previous stream may have been destroyed by its owner since -- its work is complete then, nothing to wait for -- or be
-    // inside a capture of its own: the record fails, and the error is dropped)
+    // (the previous stream may have been destroyed by its owner since -- its work is complete then, nothing to wait for: the record
+    // fails, and the error is dropped)
     if (hipEventRecord(ctx->order_event, ctx->last_stream) == hipSuccess)
       OXC_HIP(ctx, hipStreamWaitEvent(s, ctx->order_event, 0));
     else
@@ -282,14 +289,28 @@ uint32_t* next_seed_slot(oxc_ctx* ctx) {
 
 // ---- async_triangles: what is in flight on the context's own stream ----
 // Makes `s` wait for every pending triangle stage for which `needed` says so.
+// Only within one capture (or outside any): a stage recorded outside a capture cannot be waited for inside it -- include/oxcull.h asks the
+// caller to have joined before the capture begins -- and a stage recorded INSIDE a capture that has ended is ordered by the graph itself at
+// every replay (the capture could not end before oxc_join_triangles), so from un-captured calls it is simply forgotten.
+// retire: the caller is an ordered call of the context on `s` (OXC_ORDER ran): everything the context does later is behind this wait, so
+// the entry need not be waited for again.
 template <class Pred>
-oxc_status wait_triangles(oxc_ctx* ctx, hipStream_t s, Pred needed) {
-  for (auto& tp : ctx->tri)
-    if (tp.valid && needed(tp)) OXC_HIP(ctx, hipStreamWaitEvent(s, tp.done, 0));
+oxc_status wait_triangles(oxc_ctx* ctx, hipStream_t s, Pred needed, bool retire = false) {
+  const unsigned long long cid = stream_capture_id(s);
+  for (auto& tp : ctx->tri) {
+    if (!tp.valid) continue;
+    if (tp.capture_id != cid) {
+      if (cid == 0) tp.valid = false;
+      continue;
+    }
+    if (!needed(tp)) continue;
+    OXC_HIP(ctx, hipStreamWaitEvent(s, tp.done, 0));
+    if (retire) tp.valid = false;
+  }
   return OXC_OK;
 }
 oxc_status join_triangles(oxc_ctx* ctx, hipStream_t s) {
-  return wait_triangles(ctx, s, [](const oxc_ctx::TriPending&) { return true; });
+  return wait_triangles(ctx, s, [](const oxc_ctx::TriPending&) { return true; }, true);
 }
 #define OXC_JOIN(ctx, stream)                                               \
   do {                                                                      \
@@ -359,7 +380,7 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing or < ceil(N/32)*4 bytes");
   }
   if (c->small_triangle_cull > 1u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: small_triangle_cull must be 0 or 1");
-  if (c->share_pass_tests > 1u || c->_reserved0 != 0u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: share_pass_tests must be 0 or 1, _reserved0 0");
+  if (c->share_pass_tests > 1u || c->unordered_output > 2u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: share_pass_tests must be 0 or 1, unordered_output 0, 1 or 2");
   const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
   if (c->use_hpb && do_meshlets) {
     if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
@@ -411,8 +432,6 @@ oxc_status oxc_create(int device, oxc_ctx** out) {
   }
   (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
   ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
-  if (const char* ev = std::getenv("OXC_ASYNC_MTEST_BLOCKS_PER_CU")) ctx->async_mtest_per_cu = (uint32_t)std::max(0, std::atoi(ev));
-  if (const char* ev = std::getenv("OXC_ASYNC_TRI_BLOCKS_PER_CU")) ctx->async_tri_per_cu = (uint32_t)std::max(0, std::atoi(ev));
   *out = ctx;
   return OXC_OK;
 }
@@ -526,13 +545,14 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     // MeshletInstance records a pending stage reads
     OXC_JOIN(ctx, s);
   } else if (call_no >= 2) {
-    const oxc_ctx::TriPending& old = ctx->tri[(call_no - 2) % oxc_ctx::kTriRing];
-    if (old.valid) OXC_HIP(ctx, hipStreamWaitEvent(s, old.done, 0));
+    const oxc_ctx::TriPending* old = &ctx->tri[(call_no - 2) % oxc_ctx::kTriRing];
+    oxc_status wst = wait_triangles(ctx, s, [old](const oxc_ctx::TriPending& tp) { return &tp == old; });
+    if (wst != OXC_OK) return wst;
   }
   // Two kernels only run side by side when neither fills every wave slot (tools/overlap_probe.py): with async_triangles the
   // persistent kernels of both stages take a share of the CUs' slots instead of all of them.
   const uint32_t mtest_limit = (c->async_triangles && ctx->async_mtest_per_cu) ? ctx->async_mtest_per_cu * ctx->num_cus : 0u;
-  const uint32_t tri_grid_cap = (async && ctx->async_tri_per_cu) ? ctx->async_tri_per_cu * ctx->num_cus : ctx->num_cus * 8;
+  const uint32_t tri_grid_cap = (async && ctx->async_tri_per_cu) ? ctx->async_tri_per_cu * ctx->num_cus : ctx->num_cus * ctx->tri_blocks_per_cu;
   const void* const visible_buf = f->visible_meshlet_instances_indices_buffer.dptr;
   // the meshlet emit of this call overwrites the visible list: wait for the pending stages that still read it -- all but the
   // early triangle stage of the same sequence when this is its late call (the late list starts behind the early one)
@@ -568,7 +588,10 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   uint32_t* m_supers = L0.m_supers;
   uint32_t* m_tickets = L0.m_tickets;
   const uint32_t mask_bits = (uint32_t)std::min<uint64_t>(f->meshlet_instance_visibility_mask_buffer.bytes / 4u * 32u, 0xFFFFFFFEull);
-  if (c->use_hiz && occl && c->share_pass_tests && do_meshlets) {
+  // unordered_output (include/oxcull.h): which stages append by themselves
+  const bool unord_tris = c->unordered_output != 0u && do_tris;
+  const bool unord_meshlets = do_meshlets && !c->use_hpb && ((c->unordered_output != 0u && !c->use_hiz) || (c->unordered_output == 2u && c->use_hiz));
+  if (c->use_hiz && occl && c->share_pass_tests && do_meshlets && !unord_meshlets) {
     oxc_ctx::SharedTests now;
     now.N = N;
     now.n_host = n_host;
@@ -604,7 +627,11 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
         m_supers = L0.m_supers_late;
         m_tickets = L0.m_tickets_late;
       }
+      ctx->shared.valid = false;  // the bits are consumed ONCE: a second late call, or a late call of a later frame whose early call did not
+                                  // publish, tests for itself (what the host can check of "nothing was written in between" is little enough)
     }
+  } else if (c->use_hiz && do_meshlets && !late) {
+    ctx->shared.valid = false;  // an early HiZ call without the flag starts a frame whose late call must not pick up an older frame's bits
   }
   if (!armed_late && ctx->shared.armed_for_call <= call_no) ctx->shared.armed_for_call = ~0ull;  // (armed for this call only)
   if (!slot) slot = next_slot(ctx);
@@ -640,6 +667,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.do_cull_meshes = do_meshes ? 1u : 0u;
   pa.init_vis = c->init_cull_meshes ? 1u : 0u;
   pa.seed_total = 0;
+  pa.zero_vis = (unord_meshlets && c->use_hiz) ? (late ? 2u : 3u) : 0u;  // the appending HiZ kernels add to the early / late counter
   pa.cam = c->cull_camera;
   pa.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
   pa.view_cache = ctx->lane[0].view_cache;
@@ -746,7 +774,15 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       ta.step_info = ctx->lane[0].step_info;
     }
     ctx->last_share_mode = armed_late ? 3u : ta.share;
-    {
+    if (unord_meshlets) {  // the test kernel appends: it writes the visible list (wait for the stages that still read it) and both counters
+      ta.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
+      ta.count_a = tri_cmd;
+      ta.count_b = c->use_hiz ? vis + (late ? 2 : 1) : nullptr;
+      oxc_status wst = wait_for_visible_list(vis);
+      if (wst != OXC_OK) return wst;
+      KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
+      launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, mtest_limit, s);
+    } else {
       {
         KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
         launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, mtest_limit, s);
@@ -791,6 +827,12 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.supers = t_supers;
     tt.resolution[0] = c->cull_camera.resolution[0];
     tt.resolution[1] = c->cull_camera.resolution[1];
+    tt.draw_cmd = draw_cmd;
+    tt.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
+    if (unord_tris) {  // one launch: test + expansion per span of 256 visible meshlets
+      KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
+      launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), tri_grid_cap), ts);
+    } else {
     {
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
       launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, tri_grid_cap), ts);
@@ -808,6 +850,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_EMIT_LATE : OXC_K_TRIANGLES_EMIT, ts);
       launch_tris_emit(te, late, c->wide_triangle_index != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), tri_grid_cap), ts);
     }
+    }
     if (async) {
       if (!my_tri.done) OXC_HIP(ctx, hipEventCreateWithFlags(&my_tri.done, hipEventDisableTiming));
       OXC_HIP(ctx, hipEventRecord(my_tri.done, ts));
@@ -815,6 +858,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       my_tri.late = late;
       my_tri.vis = vis;
       my_tri.visible = visible_buf;
+      my_tri.capture_id = stream_capture_id(s);  // (the side stream joined the caller's capture through the fork event)
     }
   }
   OXC_HIP(ctx, hipGetLastError());
@@ -824,6 +868,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
 oxc_status oxc_join_triangles(oxc_ctx* ctx, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);  // an ordered call of the context like any other: what it joined stays joined for the calls that follow
   return join_triangles(ctx, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -1330,7 +1375,9 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
   if (needs_hiz && (!h.dptr || h.levels == 0 || h.levels > 13 || h.width == 0 || h.height == 0)) return fail(ctx, OXC_INVALID_ARG, "cull_terrain: TestOcclusion / LatePass need hiz_attachment");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   if (total > 1024u) {  // the two-kernel form borrows the meshlet stage's ballot / count scratch (one ballot per 64, one count per 1024 patches)
-    oxc_status cst = ensure_capacity(ctx, 0, total, 0, 0, static_cast<hipStream_t>(hip_stream));
+    // emit_bits is indexed [block * 16 + wave]: 16 ballots per STARTED block of 1024 patches, so the request is rounded up to whole blocks
+    // (lane.bits holds ceil(n / 64) ballots for a request of n)
+    oxc_status cst = ensure_capacity(ctx, 0, cdiv(total, 1024u) * 1024u, 0, 0, static_cast<hipStream_t>(hip_stream));
     if (cst != OXC_OK) return cst;
   }
   OXC_ORDER(ctx, hip_stream);
@@ -1369,8 +1416,8 @@ oxc_status oxc_cull_terrain(oxc_ctx* ctx, oxc_terrain_context* c, void* hip_stre
 }
 
 // Big triangles (and clipped triangle ids) queued per draw; beyond that the producing lane rasterises the triangle itself and an
-// overflow pass re-walks the index list for the crossing triangles the id queue could not hold (both slow, both correct).  240 MB of scratch, allocated by the first draw.  OXC_RASTER_BIG_CAPACITY (read by
-// that first draw) shrinks it so that the tests can reach the overflow paths with a small scene.
+// overflow pass re-walks the index list for the crossing triangles the id queue could not hold (both slow, both correct).  240 MB of scratch, allocated by the first draw.
+// oxc_debug_set_tuning(OXC_TUNE_RASTER_BIG_CAPACITY) before that first draw shrinks it so that the tests can reach the overflow paths with a small scene.
 constexpr uint32_t kRasterBigCapacity = 1u << 22;
 
 oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const oxc_draw_context* d, void* hip_stream) {
@@ -1393,10 +1440,7 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
     if (stream_is_capturing(static_cast<hipStream_t>(hip_stream)))
       return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: the first call allocates its scratch; make one un-captured call first");
     uint32_t cap = kRasterBigCapacity;
-    if (const char* env = std::getenv("OXC_RASTER_BIG_CAPACITY")) {
-      const long v = std::atol(env);
-      if (v > 0) cap = (uint32_t)std::min<long>(std::max<long>(v, kBigSegs * 16), 1L << 24) / kBigSegs * kBigSegs;
-    }
+    if (ctx->raster_capacity_request) cap = std::min<uint32_t>(std::max<uint32_t>(ctx->raster_capacity_request, kBigSegs * 16), 1u << 24) / kBigSegs * kBigSegs;
     hipError_t e = hipMalloc(&ctx->raster_scratch, (size_t)cap * kTriSetupBytes + kRasterHeaderBytes + (size_t)cap * 4 + (size_t)cap * 2 * 8);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(raster scratch)", e);
     ctx->raster_capacity = cap;
@@ -1590,6 +1634,23 @@ oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float n
 }
 
 uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx) { return ctx ? ctx->last_share_mode : 0u; }
+
+oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
+  if (!ctx) return OXC_INVALID_ARG;
+  switch (knob) {
+    case OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU: ctx->async_mtest_per_cu = value; return OXC_OK;
+    case OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU: ctx->async_tri_per_cu = value; return OXC_OK;
+    case OXC_TUNE_TRI_BLOCKS_PER_CU:
+      if (value == 0) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the triangle grid needs at least one block per CU");
+      ctx->tri_blocks_per_cu = value;
+      return OXC_OK;
+    case OXC_TUNE_RASTER_BIG_CAPACITY:
+      if (ctx->raster_scratch) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the raster scratch is allocated by the first oxc_draw_visbuffer; set its capacity before");
+      ctx->raster_capacity_request = value;
+      return OXC_OK;
+    default: return fail(ctx, OXC_INVALID_ARG, "set_tuning: unknown knob");
+  }
+}
 
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;

@@ -94,6 +94,8 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       a.meshlets_cmd[1] = 1;
       a.meshlets_cmd[2] = 1;
     }
+    if (a.zero_vis & 1u) a.vis[1] = 0;  // the appending HiZ kernels ADD to the counters (unordered_output = 2)
+    if (a.zero_vis & 2u) a.vis[2] = 0;
   }
   if (main_view) {
     for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i * kSuperStride] = 0;
@@ -427,7 +429,7 @@ OXC_DEV kconst32p const_row(const InstCache* cache, uint32_t mi) { return (kcons
 // test kernel 28.0 -> 27.4 us per 4M meshlets, whole job +2.5 %).
 #define OXC_LOAD_MLI load_stream_u2
 #define OXC_LOAD_BND load_stream_u4
-template <int G>
+template <int G, bool UNORD = false>
 OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
   set_half_denorm_flush();
   constexpr uint32_t kWaves = kPlainBlockWaves;
@@ -533,6 +535,39 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
         }
       }
     }
+    if constexpr (UNORD) {
+      // ---- unordered_output: the block appends its survivors itself.  cull_meshlets.slang:55-70 with the workgroup's LDS slot
+      // counter replaced by the wave ballots and ONE returning atomic_add per block iteration (1024 meshlets; the reference: one per
+      // 64) on cull_triangles_cmd.x -- a single address retires ~88 atomics per microsecond on this part, so the aggregation is what
+      // keeps a 1 M-meshlet call from queueing on it.  Order inside a block's run is ascending; the runs land in arrival order.
+      __shared__ uint32_t s_cnt[2][kWaves];
+      __shared__ uint32_t s_base[2];
+      const uint32_t par = ((chunk - blockIdx.x) / gridDim.x) & 1u;  // (two sets: a wave may be one iteration ahead of the slowest reader)
+      uint64_t bits[G];
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        bits[j] = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u);
+        cnt += (uint32_t)__popcll((unsigned long long)bits[j]);
+      }
+      if (lane == 0) s_cnt[par][wave] = cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; w++) total += s_cnt[par][w];
+        s_base[par] = total ? __hip_atomic_fetch_add(gptr(a.count_a), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      }
+      __syncthreads();
+      uint32_t at = s_base[par];
+      for (int w = 0; w < wave; w++) at += s_cnt[par][w];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        if ((bits[j] >> lane) & 1ull)
+          gptr(a.out)[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bits[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits[j], 0u))] = (group0 + j) * 64 + (uint32_t)lane;
+        at += (uint32_t)__popcll((unsigned long long)bits[j]);
+      }
+    } else {
     // ---- ballots + per-WAVE survivor count (+ per-super accumulation), published by lane 0 without a
     // block barrier: a __syncthreads() here re-couples the block's waves every iteration (measured ~25 %)
     uint32_t cnt = 0;
@@ -548,6 +583,7 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
       gptr(a.chunk_counts)[wchunk] = cnt;
       if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (wchunk / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    }
   }
 }
 
@@ -560,7 +596,7 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
 // instance: its InstCache row, mask words and pyramid texels stay in the L2 of the XCD the counter's blocks run on; measured ~1 %).
 constexpr uint32_t kTicketRun = 4;
 OXC_DEV uint32_t OXC_TICKET_STEP(uint32_t t, uint32_t K, uint32_t x) { return ((t / kTicketRun) * K + x) * kTicketRun + t % kTicketRun; }
-template <bool OCCL, bool LATE, int G, int SHARE = 0>
+template <bool OCCL, bool LATE, int G, int SHARE = 0, bool UNORD = false>
 OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   // SHARE (only with OCCL, G == 4): 1 = early call that also runs the cone test for the meshlets that were not visible last frame and
   // publishes the "passed frustum and cone" ballots and each step's mask run, 2 = late call that takes both from the early call of the
@@ -613,6 +649,8 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   // this part (one counter: 520 us per launch), hence many counters: 8 -> 116 us, 32 -> 82, 256 -> 79 (fixed stride: 87), 512 -> 83;
   // two steps per ticket or drawing the ticket later in the step are worse (config 3, early pass; the late pass 113 -> 101 us).
   const uint32_t nsteps = nchunks * kWaves;
+  const uint32_t out_first = (UNORD && LATE) ? gptr(a.vis)[1] : 0u;  // the late list follows the early one (cull_meshlets_hiz.slang:73)
+  (void)out_first;
   const uint32_t K = min(kTicketCounters, gridDim.x), kx = blockIdx.x % K;  // every counter in use has at least one block drawing from it
   uint32_t* const ticket = a.tickets ? a.tickets + kx * kSuperStride : nullptr;
   auto draw_ticket = [&]() -> uint32_t {
@@ -938,8 +976,10 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       }
     }
     uint32_t cnt = 0;
+    uint64_t ebits[UNORD ? G : 1];
 #pragma unroll
     for (int j = 0; j < G; j++) {
+      if constexpr (UNORD) ebits[j] = 0ull;
       if (group0 + j >= nwords) continue;  // wave-uniform
       const bool visible = (st[j] & 2u) != 0u;
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
@@ -947,10 +987,31 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       if (OCCL && !step_run) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
       const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
       const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
-      if (lane == 0) gptr(a.bits)[group0 + j] = bits;
+      if constexpr (UNORD)
+        ebits[j] = bits;
+      else if (lane == 0)
+        gptr(a.bits)[group0 + j] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
-    if (lane == 0 && group0 < nwords) {
+    if constexpr (UNORD) {
+      // unordered_output = 2: the reference's own slot allocation (cull_meshlets_hiz.slang:67-78: an atomic_add on the early / late counter
+      // and one on cull_triangles_cmd.x per visible THREAD), aggregated to one pair per wave step through the ballots.  Every step
+      // with a survivor queues on the same two addresses (~88 atomics per microsecond each): the measured cost of the literal scheme.
+      if (cnt) {  // (wave-uniform)
+        uint32_t at = 0;
+        if (lane == 0) {
+          at = __hip_atomic_fetch_add(gptr(a.count_b), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(gptr(a.count_a), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        at = readfirst_u(at) + out_first;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          if ((ebits[j] >> lane) & 1ull)
+            gptr(a.out)[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(ebits[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ebits[j], 0u))] = (group0 + j) * 64 + (uint32_t)lane;
+          at += (uint32_t)__popcll((unsigned long long)ebits[j]);
+        }
+      }
+    } else if (lane == 0 && group0 < nwords) {
       gptr(a.chunk_counts)[step] = cnt;
       if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (step / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1243,7 +1304,12 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 // SMALL (extension, include/oxcull.h small_triangle_cull): after the two reference tests, drop a triangle whose
 // screen-space bounding box covers no pixel centre.  The screen position is computed once per vertex (lane = vertex,
 // two IEEE divisions) and fetched per corner like the clip coordinates; with SMALL off none of it is compiled in.
-template <bool LATE, bool WIDE, bool SMALL>
+// FUSED (unordered_output, include/oxcull.h): the block also expands what it tested -- per span of 256 visible meshlets (four chunks)
+// the pass masks stay in LDS, ONE returning atomic_add on DrawIndexedIndirect.index_count allocates the span's run of packed indices
+// (cull_triangles.slang:71-88 does that per 64-thread workgroup; a single address retires ~88 atomics per microsecond here, hence the
+// span), and the four waves write it the way tris_emit_body does.  No pass masks, chunk counts or visible ids go through memory and
+// no emit launch follows; the runs land in arrival order (ascending inside a span).
+template <bool LATE, bool WIDE, bool SMALL, bool FUSED = false>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
@@ -1258,11 +1324,20 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
   constexpr int kRowAhead = kIdxAhead + 2;      // scalar: LOD pointers out of the InstCache row
   typedef const uint32_t __attribute__((address_space(4))) * k32;
   __shared__ uint32_t s_red[4];
+  constexpr uint32_t kChunksPerSpan = kTriSpan / kTriChunk;  // FUSED: a block takes whole spans, chunk after chunk
+  constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
+  constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
+  __shared__ uint32_t f_off[FUSED ? kTriSpan : 1];
+  __shared__ uint64_t f_mask[FUSED ? kTriSpan * H : 1];
+  __shared__ uint32_t f_id[FUSED ? kTriSpan : 1];
+  __shared__ uint32_t f_strip[FUSED ? 4 * 192 * H : 1];
+  __shared__ uint32_t f_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
-  const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const uint32_t nchunks = FUSED ? (V + kTriSpan - 1) / kTriSpan * kChunksPerSpan : (V + kTriChunk - 1) / kTriChunk;  // (FUSED: whole spans; a chunk beyond V re-does the last slot and leaves empty masks)
+  for (uint32_t chunk = FUSED ? blockIdx.x * kChunksPerSpan : blockIdx.x; chunk < nchunks;
+       chunk = !FUSED ? chunk + gridDim.x : ((chunk % kChunksPerSpan) != kChunksPerSpan - 1u ? chunk + 1u : chunk - (kChunksPerSpan - 1u) + gridDim.x * kChunksPerSpan)) {
     // ---- lanes 0..15 fetch the MeshletInstance of this wave's 16 slots; everything that is uniform per
     // slot from there on (LOD pointers, Meshlet record, mvp) travels through scalar loads into SGPRs
     uint2 h_rec;
@@ -1382,6 +1457,64 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         cnt += (uint32_t)__popcll((unsigned long long)mask);
       }
     }
+    if constexpr (FUSED) {
+      (void)cnt;
+      const uint32_t c4 = chunk % kChunksPerSpan;
+      if (lane < S) {  // slot (chunk, j = lane, wave) sits at c4 * 64 + j * 4 + wave of the span (a slot beyond V left an empty mask)
+#pragma unroll
+        for (int h = 0; h < H; h++) f_mask[(c4 * kTriChunk + (uint32_t)lane * 4 + wave) * H + h] = (uint64_t)mlo[h] | ((uint64_t)mhi[h] << 32);
+      }
+      if (c4 != kChunksPerSpan - 1u) continue;  // (block-uniform)
+      __syncthreads();
+      // ---- the span is tested: allocate its run and expand it (tris_emit_body with the base taken from the counter itself)
+      const uint32_t slot = (chunk / kChunksPerSpan) * kTriSpan + threadIdx.x;
+      uint32_t c = 0;
+#pragma unroll
+      for (int h = 0; h < H; h++) c += (uint32_t)__popcll((unsigned long long)f_mask[threadIdx.x * H + h]);
+      const uint32_t id = slot < V ? a.visible[first + slot] : 0u;
+      const uint32_t incl = wave_incl_scan(c, lane);
+      if (lane == 63) s_red[wave] = incl;
+      __syncthreads();
+      uint32_t woff = 0;
+      for (int k = 0; k < wave; k++) woff += s_red[k];
+      f_off[threadIdx.x] = woff + incl - c;
+      f_id[threadIdx.x] = id;
+      if (threadIdx.x == 255) {
+        const uint32_t total3 = (woff + incl) * 3u;
+        f_base = total3 ? __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // DrawIndexedIndirect.index_count
+      }
+      __syncthreads();
+      const uint32_t base3 = f_base;
+      uint32_t* strip = f_strip + wave * (192 * H);
+#pragma unroll 2
+      for (int k = 0; k < 64; k++) {
+        const int sl = wave * 64 + k;
+        uint32_t before = 0;
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          const uint64_t m = f_mask[sl * H + h];
+          if ((m >> lane) & 1ull) {
+            const uint32_t rank = before + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+            const uint32_t packed = f_id[sl] << kCornerBits;
+            const uint32_t t3 = ((uint32_t)lane + 64u * (uint32_t)h) * 3u;
+            strip[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
+            strip[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
+            strip[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
+          }
+          before += (uint32_t)__popcll((unsigned long long)m);
+        }
+        const uint32_t n3 = before * 3u;
+        if (n3 == 0u) continue;  // wave-uniform
+        const uint32_t o = base3 + f_off[sl] * 3u;
+        // same wave, in-order LDS: the reads below see the writes above
+#pragma unroll
+        for (uint32_t r = 0; r < 3u * H; r++) {
+          const uint32_t i = (uint32_t)lane + 64u * r;
+          if (i < n3) a.out[o + i] = strip[i];
+        }
+      }
+      __syncthreads();  // the span's LDS rows are rewritten by the block's next span
+    } else {
     {
       const uint32_t slot = chunk * kTriChunk + (uint32_t)lane * 4 + wave;
       if (lane < S && slot < V) {
@@ -1396,6 +1529,7 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       uint32_t c = s_red[0] + s_red[1] + s_red[2] + s_red[3];
       a.chunk_counts[chunk] = c;
       if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     }
   }
 }
@@ -1480,6 +1614,11 @@ OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
     }
     __syncthreads();
   }
+#ifdef OXC_EMIT_RELEASE
+  // experiment (round 4): write the block's dirty index lines back before the kernel ends, so that the NEXT kernel (the pyramid build of
+  // the following frame) does not inherit their write-back
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1687,6 +1826,14 @@ __global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_c
   else
     meshlets_hiz_body<OCCL, LATE, G>(a);
 }
+// unordered_output: the same bodies appending their survivors themselves (MeshletTestArgs::out)
+template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
+__global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_cull_meshlets_test_unordered(MeshletTestArgs a) {
+  if constexpr (!HIZ)
+    meshlets_plain_body<G, true>(a);
+  else
+    meshlets_hiz_body<OCCL, LATE, G, 0, true>(a);
+}
 // the two calls of a frame sharing the frustum test (MeshletTestArgs::share)
 template <bool LATE>
 #ifndef OXC_SHARED_LATE_WAVES
@@ -1702,13 +1849,20 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
 #ifndef OXC_TRI_WAVES
 #define OXC_TRI_WAVES 8
 #endif
+#ifndef OXC_TRI_WIDE_WAVES
+#define OXC_TRI_WIDE_WAVES 6
+#endif
 template <bool LATE, bool WIDE, bool SMALL>
-__global__ __launch_bounds__(256, (WIDE || SMALL) ? 6 : OXC_TRI_WAVES) void k_cull_triangles_test(TriTestArgs a) {
+__global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_test(TriTestArgs a) {
   tris_test_body<LATE, WIDE, SMALL>(a);
 }
 template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
   tris_emit_body<LATE, WIDE>(a);
+}
+template <bool LATE, bool WIDE, bool SMALL>
+__global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused(TriTestArgs a) {
+  tris_test_body<LATE, WIDE, SMALL, true>(a);
 }
 
 // Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
@@ -2056,6 +2210,24 @@ static uint32_t resident_grid(K kernel, uint32_t block, uint32_t num_cus) {
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, uint32_t grid_limit, hipStream_t s) {
   constexpr uint32_t hb = 1024 / kHizGroups;
   if (hiz && grid_limit) grid = std::min(grid, grid_limit);
+  if (a.out) {  // unordered_output: the appending instantiations
+    if (!hiz) {
+      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
+    } else if (occl && late) {
+      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, true, true, kHizGroups>, hb, num_cus);
+      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, true, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
+    } else if (occl) {
+      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, true, false, kHizGroups>, hb, num_cus);
+      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, true, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
+    } else if (late) {
+      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, false, true, kHizGroups>, hb, num_cus);
+      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, false, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
+    } else {
+      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, false, false, kHizGroups>, hb, num_cus);
+      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, false, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
+    }
+    return;
+  }
   if (!hiz) {
     hipLaunchKernelGGL((k_cull_meshlets_test<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
   } else if (occl && a.share) {
@@ -2102,6 +2274,20 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_tri
     case 5: hipLaunchKernelGGL((k_cull_triangles_test<true, false, true>), g, b, 0, s, a); break;
     case 6: hipLaunchKernelGGL((k_cull_triangles_test<true, true, false>), g, b, 0, s, a); break;
     default: hipLaunchKernelGGL((k_cull_triangles_test<true, true, true>), g, b, 0, s, a); break;
+  }
+}
+void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s) {
+  dim3 g(grid), b(256);
+  const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
+  switch (v) {
+    case 0: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, false>), g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, true>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_cull_triangles_fused<false, true, false>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_cull_triangles_fused<false, true, true>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_cull_triangles_fused<true, false, false>), g, b, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_cull_triangles_fused<true, false, true>), g, b, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((k_cull_triangles_fused<true, true, false>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cull_triangles_fused<true, true, true>), g, b, 0, s, a); break;
   }
 }
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {

@@ -34,6 +34,9 @@ struct PrepareArgs {
   uint32_t do_cull_meshes;
   uint32_t init_vis;    // write vis/meshlets_cmd initial values
   uint32_t seed_total;  // initial vis.total (0 for the reference flow)
+  // unordered_output = 2 (the HiZ meshlet tests append with atomics on the visibility counters instead of an emit kernel that stores
+  // the totals): bit 0 = zero vis[1] (early count), bit 1 = zero vis[2] (late count) -- cull_meshlets_hiz.slang:67-78 adds to both
+  uint32_t zero_vis;
   oxc_cull_camera cam;
   // multi-view (use_hpb): blockIdx.y = 1 + v computes rows view_cache[v * M + mi] with
   // clipmaps[v].projection_view_mat in place of the camera matrix
@@ -78,6 +81,13 @@ struct MeshletTestArgs {
   // bits starts; the late call of the same frame reads them instead of testing again.  share: 0 = off, 1 = write them (early call),
   // 2 = read them (late call).
   uint32_t share;
+  // unordered_output (include/oxcull.h): the test kernel appends its survivors itself -- slot allocation by atomic_add as the reference
+  // does (cull_meshlets.slang:55-70, cull_meshlets_hiz.slang:67-78), aggregated per block (plain kernel) or per wave step (HiZ
+  // kernels) through the ballot -- and no emit kernel runs.  out = visible_meshlet_instances_indices, count_a = cull_triangles_cmd.x,
+  // count_b = visibility.early / .late (HiZ kernels; null for the plain kernel).  Null `out`: the ordered two-launch form.
+  uint32_t* out;
+  uint32_t* count_a;
+  uint32_t* count_b;
   uint64_t* camera_test_bits;  // [ceil(N / 64)]
   uint2* step_info;        // [steps]: {first mask bit of the step, 1 if the step's 64 * G meshlets are one run of mask bits}
   const float* hiz_data;
@@ -111,6 +121,10 @@ struct TriTestArgs {
   uint32_t* chunk_counts;
   uint32_t* supers;
   float resolution[2];  // cull_camera.resolution: read by the small-triangle variants only
+  // unordered_output: the fused kernel (test + expansion of a 256-meshlet span in one launch; slots by atomic_add on index_count, as
+  // cull_triangles.slang:71-88 does per workgroup) writes the packed indices and the draw command itself
+  uint32_t* draw_cmd;
+  uint32_t* out;  // reordered_indices
 };
 
 struct TriEmitArgs {
@@ -225,6 +239,7 @@ inline void prepare_args_of(const BatchCore& c, PrepareArgs& pa) {
   pa.do_cull_meshes = c.do_cull_meshes;
   pa.init_vis = c.init_vis;
   pa.seed_total = 0;
+  pa.zero_vis = 0;
   pa.cam = c.cam;
   pa.clipmaps = nullptr;
   pa.view_cache = c.view_cache;
@@ -249,6 +264,7 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   ta.bits = c.bits;
   ta.chunk_counts = c.m_chunk_counts;
   ta.supers = c.m_supers;
+  ta.out = ta.count_a = ta.count_b = nullptr;  // batched elements keep the ordered form
   ta.hiz_data = nullptr;
   ta.hiz_w = ta.hiz_h = ta.hiz_levels = ta.hiz_lds_first = 0;
   ta.near_clip = c.cam.near_clip;
@@ -276,6 +292,7 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   tt.supers = c.t_supers;
   tt.resolution[0] = c.cam.resolution[0];
   tt.resolution[1] = c.cam.resolution[1];
+  tt.draw_cmd = tt.out = nullptr;
   TriEmitArgs& te = e.temit;
   te.tri_masks = c.tri_masks;
   te.visible = c.visible_out;
@@ -346,10 +363,13 @@ void launch_hpb_test(const HpbTestArgs& a, uint32_t grid, hipStream_t s);
 void launch_scan_mesh_counts(const uint32_t* counts, uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* vis, uint32_t* cmd, hipStream_t s);
 void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, void* out, uint32_t grid, hipStream_t s);
 // grid_limit != 0: at most that many blocks (async_triangles: the HiZ variants leave wave slots to the triangle stage running beside them)
+// a.out != null: the unordered (appending) instantiation of the same kernel; no emit launch follows
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, uint32_t grid_limit, hipStream_t s);
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
 void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
+// unordered_output: test + expansion in one launch (a.draw_cmd / a.out set); grid in 256-meshlet spans
+void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_hiz(const HizArgs& a, uint32_t num_cus, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch
 void launch_prepare_batch(const BatchBlob& blob, BatchElem* dev, uint32_t grid, hipStream_t s);

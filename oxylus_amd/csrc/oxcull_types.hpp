@@ -115,6 +115,7 @@ constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulate
 // blocks per CU 3 / 8: 628, 3 / 5: 639, 4 / 4: 640, 3 / 4: 648, 2 / 5: 685, 2 / 6: 689, 1 / 6: 954 -- the kernels do run side by
 // side (their HIP-event times add up to 1.8x the frame) but each slows down by what the other takes: the frame is bound by HBM
 // traffic, which both stages draw on (2.4-3.7 TB/s by the meshlet tests, ~5 TB/s by the triangle stage).  Hence no limit by default.
+constexpr uint32_t kTriangleBlocksPerCU = 8;  // grid cap of the triangle test / emit / fused kernels, in blocks per CU (oxc_debug_set_tuning moves it for measurements)
 constexpr uint32_t kAsyncMeshletBlocksPerCU = 0;
 constexpr uint32_t kAsyncTriangleBlocksPerCU = 0;
 

@@ -82,6 +82,9 @@ struct CullGeometryContext {
   // takes the frustum + cone results from the early one instead of testing again -- the caller vouches that no input of those tests
   // was written in between (include/oxcull.h: share_pass_tests)
   bool share_pass_tests = false;
+  // extension (order only): 0 = ascending lists; 1 / 2 = the reference's own atomic slot allocation, aggregated per block / wave step
+  // (one launch per stage instead of test + ordered emit; include/oxcull.h: unordered_output)
+  uint32_t unordered_output = 0;
 };
 
 struct MainGeometryContext {
@@ -150,6 +153,7 @@ public:
     c.small_triangle_cull = context.small_triangle_cull;
     c.async_triangles = context.async_triangles;
     c.share_pass_tests = context.share_pass_tests;
+    c.unordered_output = context.unordered_output;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));

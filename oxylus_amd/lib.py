@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liboxcull.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 OXC_OK, OXC_INVALID_ARG, OXC_HIP_ERROR, OXC_RCCL_ERROR, OXC_OUT_OF_MEMORY = range(5)
-ABI_VERSION = 4  # OXC_ABI_VERSION of include/oxcull.h
+ABI_VERSION = 5  # OXC_ABI_VERSION of include/oxcull.h
 
 CULL_TEST_FRUSTUM = 1
 CULL_SELECT_LOD = 2
@@ -26,6 +26,8 @@ STAGE_MESHES = 1
 STAGE_MESHLETS = 2
 STAGE_TRIANGLES = 4
 STAGE_ALL = 7
+
+TUNE_ASYNC_MTEST_BLOCKS_PER_CU, TUNE_ASYNC_TRI_BLOCKS_PER_CU, TUNE_RASTER_BIG_CAPACITY, TUNE_TRI_BLOCKS_PER_CU = 0, 1, 2, 3  # oxc_debug_set_tuning knobs
 
 
 class Buffer(C.Structure):
@@ -101,7 +103,7 @@ class CullGeometryContext(C.Structure):
         ("small_triangle_cull", C.c_uint32),
         ("async_triangles", C.c_uint32),
         ("share_pass_tests", C.c_uint32),
-        ("_reserved0", C.c_uint32),
+        ("unordered_output", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),
@@ -269,6 +271,7 @@ EXPORTS = [
     "oxc_broadcast_hiz_levels",
     "oxc_debug_read_u32",
     "oxc_debug_shared_tests_mode",
+    "oxc_debug_set_tuning",
     "oxc_debug_project_aabb",
 ]
 
@@ -334,6 +337,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_debug_shared_tests_mode.argtypes = [vp]
     lib.oxc_debug_shared_tests_mode.restype = C.c_uint32
     lib.oxc_debug_raster_stats.argtypes = [vp, vp, vp]
+    lib.oxc_debug_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.oxc_comm_unique_id.argtypes = [vp, vp]
     lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     lib.oxc_comm_destroy.argtypes = [vp]

@@ -154,6 +154,7 @@ class CullGeometryContext:
     small_triangle_cull: bool = False  # extension (north star): also drop triangles whose screen bbox covers no pixel centre
     async_triangles: bool = False  # extension (scheduling only): the triangle stage runs on the context's own stream; RendererInstance.join_triangles
     share_pass_tests: bool = False  # extension (caching only): the late HiZ call of a frame reuses the early call's frustum + cone results (include/oxcull.h)
+    unordered_output: int = 0  # extension (order only): 0 ascending lists, 1 / 2 the reference's atomic slot allocation (include/oxcull.h)
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -175,6 +176,7 @@ class CullGeometryContext:
         c.small_triangle_cull = int(self.small_triangle_cull)
         c.async_triangles = int(self.async_triangles)
         c.share_pass_tests = int(self.share_pass_tests)
+        c.unordered_output = int(self.unordered_output)
         return c
 
 
@@ -376,6 +378,10 @@ class RendererInstance:
         out = (C.c_uint32 * 4)()
         self._check(self._lib.oxc_debug_raster_stats(self._ctx, C.cast(out, C.c_void_p), self._stream(stream)))
         return {"big": int(out[0]), "clipped": int(out[1]), "tiles": int(out[2]), "overflowed_segments": int(out[3])}
+
+    def debug_set_tuning(self, knob: int, value: int):
+        """Harness knobs (L.TUNE_*): async stage grid caps, the raster queues' capacity (before the first draw)."""
+        self._check(self._lib.oxc_debug_set_tuning(self._ctx, knob, value))
 
     def debug_shared_tests_mode(self) -> int:
         """What share_pass_tests did in the last cull_geometry call: 0 tested on its own, 1 early call that published, 2 late call that reused,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(lib, name), f"liboxcull.so does not export {name}"
-    assert lib.oxc_abi_version() == L.ABI_VERSION == 4
+    assert lib.oxc_abi_version() == L.ABI_VERSION == 5
 
 
 def test_struct_sizes_match_reference_layouts():

@@ -121,3 +121,85 @@ def test_in_order_call_after_async_calls_joins_by_itself(renderer):
     renderer.cull_geometry(ctx)
     c = renderer.read_counters(ctx)  # joins
     assert c.draw_index_count == c0.draw_index_count and torch.equal(frame.reordered_indices_buffer[:c.draw_index_count], want)
+
+
+def test_async_pair_captured_into_a_hip_graph_after_an_eager_async_warm_up(oracle_lib):
+    """Round-3 advisor finding: the pending-stage bookkeeping did not know about stream capture.  An eager async call (needed before any
+    capture: scratch is allocated un-captured) left a pending entry whose event was recorded OUTSIDE the capture; the first captured call
+    then waited for it -> hipErrorStreamCaptureIsolation, capture invalidated.  Now: eager async warm-up (joined), then the async early +
+    late pair and the join captured into one graph, replayed three times; afterwards un-captured async calls again (their bookkeeping must
+    not wait for events recorded inside the finished capture).  Every replay leaves the bytes of the in-order frame."""
+    from util import gpu_frame, oracle_frame, oracle_hiz
+
+    r = RendererInstance(0)
+    spec = SceneSpec(n_mesh_instances=120, meshlets_per_mesh=400, with_geometry=True, seed=61)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    hw = 256
+    depth = make_depth(2 * hw, 2 * hw, 48, seed=61, device="cuda")
+    hiz = ImageAttachment.hiz(hw, hw, "cuda")
+    r.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
+    want_hiz, levels, offs = oracle_hiz(depth.cpu(), hw, hw)
+    n = cpu.n_meshlet_instances
+    g = torch.Generator().manual_seed(61)
+    bits = (torch.rand(((n + 31) // 32, 32), generator=g) < 0.3).to(torch.int64)
+    mask = (bits << torch.arange(32)).sum(1).to(torch.int32)
+    want = oracle_frame(cpu, use_hiz=True, hiz={"data": want_hiz, "w": hw, "h": hw, "levels": levels, "offs": offs}, mask=mask, two_pass=True)
+    frame = PreparedFrame.create(gpu, with_triangles=True)
+    r.prepared_frame = frame
+    r.reserve(gpu.n_mesh_instances, n)
+    s = torch.cuda.Stream()
+    mask_gpu = mask.cuda()
+
+    def contexts():
+        e = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                async_triangles=True)
+        with torch.cuda.stream(s):
+            r.seed_meshlet_instances(e, n, stream=s)
+        l = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL | L.CULL_LATE_PASS, cull_camera=gpu.cull_camera(), hiz_attachment=hiz,
+                                stages=L.STAGE_ALL, async_triangles=True)
+        l._c.visibility_buffer, l._c.cull_meshlets_cmd_buffer = e._c.visibility_buffer, e._c.cull_meshlets_cmd_buffer
+        return e, l
+
+    def check(ctx_e, ctx_l, what):
+        torch.cuda.synchronize()
+        ce, cl = r.read_counters(ctx_e), r.read_counters(ctx_l)
+        assert (cl.early_visible_meshlet_instances, cl.late_visible_meshlet_instances) == (want["early"], want["late"]), what
+        vis = frame.visible_meshlet_instances_indices_buffer.cpu().numpy()
+        assert np.array_equal(vis[:want["early"]], want["early_visible"]) and np.array_equal(vis[want["early"]:want["early"] + want["late"]], want["late_visible"]), what
+        assert cl.draw_index_count == len(want["late_indices"]) and ce.draw_index_count == len(want["early_indices"]), what
+        assert np.array_equal(frame.reordered_indices_buffer[:cl.draw_index_count].cpu().numpy(), want["late_indices"]), what
+        assert np.array_equal(frame.meshlet_instance_visibility_mask_buffer.cpu().numpy(), want["mask"]), what
+
+    # eager async warm-up, joined on the stream and complete on the host before the capture begins (include/oxcull.h)
+    e, l = contexts()
+    frame.meshlet_instance_visibility_mask_buffer.copy_(mask_gpu)
+    torch.cuda.synchronize()
+    r.cull_geometry(e, stream=s)
+    r.cull_geometry(l, stream=s)
+    r.join_triangles(stream=s)
+    check(e, l, "eager async warm-up")
+    # the pair + the join in one graph
+    e, l = contexts()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        r.cull_geometry(e, stream=s)
+        r.cull_geometry(l, stream=s)
+        r.join_triangles(stream=s)
+    for rep in range(3):
+        frame.meshlet_instance_visibility_mask_buffer.copy_(mask_gpu)
+        frame.visible_meshlet_instances_indices_buffer.zero_()
+        frame.reordered_indices_buffer.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        check(e, l, f"captured async pair, replay {rep}")
+    # ... and un-captured async calls afterwards
+    e2, l2 = contexts()
+    frame.meshlet_instance_visibility_mask_buffer.copy_(mask_gpu)
+    torch.cuda.synchronize()
+    r.cull_geometry(e2, stream=s)
+    r.cull_geometry(l2, stream=s)
+    r.join_triangles(stream=s)
+    check(e2, l2, "eager async after the capture")
+    r.close()

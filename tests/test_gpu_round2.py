@@ -63,6 +63,27 @@ def test_config3_full_size_every_output_bit_exact(renderer, oracle_lib):
         assert runs[True][tag][2] == runs[False][tag][2], f"{tag}: counters differ with share_pass_tests"
         assert torch.equal(runs[True][tag][0], runs[False][tag][0]) and torch.equal(runs[True][tag][1], runs[False][tag][1]), f"{tag}: lists differ with share_pass_tests"
     assert torch.equal(runs[True]["mask"], runs[False]["mask"])
+    # ... and unordered_output (the reference's atomic slot allocation; 1: fused triangle stage, 2: appending HiZ meshlet tests too): same
+    # counters, same mask, and every list SORTED is the ordered list (which is compared with the checker below)
+    for mode in (1, 2):
+        frame.meshlet_instance_visibility_mask_buffer.copy_(mask0)
+        frame.visible_meshlet_instances_indices_buffer.zero_()
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                  share_pass_tests=True, unordered_output=mode)
+        renderer.seed_meshlet_instances(ctx, N)
+        for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+            ctx.cull_flags = flags
+            renderer.cull_geometry(ctx)
+            c = renderer.read_counters(ctx)
+            first = c.early_visible_meshlet_instances if tag == "late" else 0
+            assert (c.total_visible_meshlet_instances, c.early_visible_meshlet_instances, c.late_visible_meshlet_instances, c.cull_triangles_cmd_x) == runs[False][tag][2], (mode, tag)
+            assert c.draw_index_count == runs[False][tag][1].numel(), (mode, tag)
+            vis = torch.sort(frame.visible_meshlet_instances_indices_buffer[first:first + c.cull_triangles_cmd_x])[0].cpu()
+            assert torch.equal(vis, runs[False][tag][0]), f"unordered_output = {mode}, {tag}: visible set differs"
+            idx = torch.sort(frame.reordered_indices_buffer[:c.draw_index_count].to(torch.int64) & 0xFFFFFFFF)[0].to(torch.int32).cpu()
+            assert torch.equal(idx, runs[False][tag][1]), f"unordered_output = {mode}, {tag}: packed index set differs"
+            del vis, idx
+        assert torch.equal(frame.meshlet_instance_visibility_mask_buffer.cpu(), runs[False]["mask"]), f"unordered_output = {mode}: mask differs"
     got, got_mask = runs[False], runs[False]["mask"]
     del runs
     got_hiz = hiz.data.cpu()

@@ -259,15 +259,17 @@ def test_gpu_draw_with_the_camera_inside_the_geometry(renderer, oracle_lib, dept
 
 
 @pytest.mark.gpu
-def test_gpu_draw_when_the_big_list_overflows(oracle_lib, monkeypatch):
-    """A context whose big list holds 8192 triangles (OXC_RASTER_BIG_CAPACITY, read by the first draw) and a scene with far more
+def test_gpu_draw_when_the_big_list_overflows(oracle_lib):
+    """A context whose big list holds 8192 triangles (oxc_debug_set_tuning before the first draw) and a scene with far more
     triangles whose pixel boxes exceed 8 x 8: segments fill up and the setup lanes walk the excess themselves -- slow, and still
     the same image."""
     import oracle
     from oxylus_amd.renderer import RendererInstance
 
-    monkeypatch.setenv("OXC_RASTER_BIG_CAPACITY", "8192")
+    from oxylus_amd import lib as L
+
     r = RendererInstance(0)
+    r.debug_set_tuning(L.TUNE_RASTER_BIG_CAPACITY, 8192)
     try:
         cpu = make_scene(SceneSpec(n_mesh_instances=60, meshlets_per_mesh=50, seed=12, scene_depth=12.0), "cpu")
         cam = cpu.cull_camera()
@@ -284,14 +286,16 @@ def test_gpu_draw_when_the_big_list_overflows(oracle_lib, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_gpu_draw_when_the_clip_queue_overflows(oracle_lib, monkeypatch):
+def test_gpu_draw_when_the_clip_queue_overflows(oracle_lib):
     """The id queue of the triangles that cross a clip plane holds 4096 entries here; the camera sits inside a scene in which more
     than that cross: the overflow pass walks the index list again and clips what the queue could not record -- same image."""
     import oracle
     from oxylus_amd.renderer import RendererInstance
 
-    monkeypatch.setenv("OXC_RASTER_BIG_CAPACITY", "4096")
+    from oxylus_amd import lib as L
+
     r = RendererInstance(0)
+    r.debug_set_tuning(L.TUNE_RASTER_BIG_CAPACITY, 4096)
     try:
         cpu = make_scene(SceneSpec(n_mesh_instances=160, meshlets_per_mesh=40, seed=19, scene_depth=0.5), "cpu")
         cam = cpu.cull_camera()

@@ -57,18 +57,20 @@ def oracle_frame(scene_cpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hiz=None,
 
 
 def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hiz: ImageAttachment = None, mask=None,
-              run_cull_meshes=False, two_pass=False, with_triangles=True, share_pass_tests=False, before_pass=None):
+              run_cull_meshes=False, two_pass=False, with_triangles=True, share_pass_tests=False, before_pass=None, unordered_output=0,
+              wide_triangle_index=False, small_triangle_cull=False, max_tris=64):
     """Same sequence through liboxcull.so.  Returns numpy arrays in the layout of oracle_frame.
     share_pass_tests: the flag of include/oxcull.h on every call; before_pass(i, ctx): called in front of call i (tests that change
     something between the early and the late call)."""
-    frame = PreparedFrame.create(scene_gpu, with_triangles=with_triangles, expand=not run_cull_meshes)
+    frame = PreparedFrame.create(scene_gpu, with_triangles=with_triangles, expand=not run_cull_meshes, max_tris=max_tris)
     if mask is not None:
         frame.meshlet_instance_visibility_mask_buffer.copy_(mask.to(scene_gpu.device))
     renderer.prepared_frame = frame
     cam = scene_gpu.cull_camera()
     stages = L.STAGE_ALL if with_triangles else (L.STAGE_MESHES | L.STAGE_MESHLETS)
     ctx = CullGeometryContext(use_hiz=use_hiz, init_cull_meshes=run_cull_meshes, cull_flags=cull_flags, cull_camera=cam,
-                              hiz_attachment=hiz, stages=stages, share_pass_tests=share_pass_tests)
+                              hiz_attachment=hiz, stages=stages, share_pass_tests=share_pass_tests, unordered_output=unordered_output,
+                              wide_triangle_index=wide_triangle_index, small_triangle_cull=small_triangle_cull)
     res = {}
     if not run_cull_meshes:
         renderer.seed_meshlet_instances(ctx, scene_gpu.n_meshlet_instances)
@@ -104,6 +106,23 @@ def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hi
     res["lod_index"] = scene_gpu.mesh_instances[:, 1].cpu().numpy().copy()
     res["mask"] = frame.meshlet_instance_visibility_mask_buffer.cpu().numpy().copy()
     return res
+
+
+def sorted_lists(res: dict) -> dict:
+    """unordered_output: the lists of a frame as ascending u32 arrays -- what the ordered form emits (packed indices ascend with
+    (meshlet instance, triangle, corner), so sorting the whole index list restores the ordered bytes)."""
+    out = dict(res)
+    for k, v in res.items():
+        if isinstance(v, np.ndarray) and (k.endswith("visible") or k.endswith("indices")):
+            out[k] = np.sort(v.view(np.uint32)).view(v.dtype)
+    return out
+
+
+def assert_triangles_adjacent(indices: np.ndarray, corner_bits: int = 8):
+    """A packed index list is a sequence of triangles: (id << bits) | 3t, | 3t + 1, | 3t + 2 next to each other, whatever the order."""
+    u = indices.view(np.uint32).reshape(-1, 3)
+    assert np.all(u[:, 1] == u[:, 0] + 1) and np.all(u[:, 2] == u[:, 0] + 2), "a triangle's three packed indices are not adjacent"
+    assert np.all((u[:, 0] & ((1 << corner_bits) - 1)) % 3 == 0)
 
 
 def assert_same(a: dict, b: dict, keys):

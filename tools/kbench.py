@@ -2,8 +2,8 @@
 """tools/kbench.py -- A/B several builds of liboxcull.so on the configs[2] frame in ONE process (one scene generation).
 
   python tools/kbench.py [--libs base=oxylus_amd/liboxcull.so,x=oxylus_amd/variants/liboxcull_x.so] [--frames 60] [--meshlets N]
-  A library entry may carry settings: tag=path@ASYNC=1@SHARE=1@OXC_ASYNC_MTEST_BLOCKS_PER_CU=3 -- ASYNC=1 sets async_triangles, SHARE=1 share_pass_tests on every call
-  (the frames then pipeline: triangle stages on the context's own stream), anything else goes into the environment before oxc_create.
+  A library entry may carry settings: tag=path@ASYNC=1@SHARE=1@UNORD=1@TUNE0=3 -- ASYNC=1 sets async_triangles, SHARE=1 share_pass_tests, UNORD=n
+  unordered_output on every call (lists are then compared as sorted sets), TUNEk=v calls oxc_debug_set_tuning(k, v).
 
 For every library: warm up, time `--frames` frames (wall, one stream), then an instrumented pass (HIP-event pair per kernel), and a
 checksum of every output of one frame (visible lists, packed indices, mask, pyramid) -- variants must agree with the first library
@@ -30,17 +30,21 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--meshlets", type=int, default=10_000_000)
     ap.add_argument("--out", default="")
+    ap.add_argument("--tris", type=int, default=64, help="triangles per meshlet; > 64: wide_triangle_index (at most 8M meshlets)")
     ap.add_argument("--coherent-mask", action="store_true", help="prior-visibility mask = the previous frame's result instead of random p = 0.3")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     stream = torch.cuda.Stream(device=dev)
     K, HW = 1000, 4096
+    wide = a.tris > 64
+    if wide:
+        a.meshlets = min(a.meshlets, 8_000_000)
     M = a.meshlets // K
     N = M * K
     with torch.cuda.stream(stream):
-        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2), dev)
-        frame = PreparedFrame.create(scene, with_triangles=True)
+        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2, tris_per_meshlet=a.tris), dev)
+        frame = PreparedFrame.create(scene, with_triangles=True, max_tris=128 if wide else 64)
         depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))
         hiz = ImageAttachment.hiz(HW, HW, dev)
         g = torch.Generator(device=dev).manual_seed(5)
@@ -54,26 +58,32 @@ def main():
     for item in a.libs.split(","):
         tag, path = item.split("=", 1)
         path, *settings = path.split("@")
-        use_async, use_share = False, False
+        use_async, use_share, unord, tunes = False, False, 0, []
         for kv in settings:
             k_, v_ = kv.split("=")
             if k_ == "ASYNC":
                 use_async = v_ == "1"
             elif k_ == "SHARE":
                 use_share = v_ == "1"
+            elif k_ == "UNORD":
+                unord = int(v_)
+            elif k_.startswith("TUNE"):
+                tunes.append((int(k_[4:]), int(v_)))
             else:
-                os.environ[k_] = v_
+                raise SystemExit(f"unknown setting {kv}")
         r = RendererInstance(0, lib_path=os.path.join(ROOT, path) if not os.path.isabs(path) else path)
+        for knob, val in tunes:
+            r.debug_set_tuning(knob, val)
         lib, ctxp, sp = r._lib, r._ctx, C.c_void_p(stream.cuda_stream)
         r.reserve(M, N)
         r.prepared_frame = frame
-        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
+        ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                                  wide_triangle_index=wide)
         with torch.cuda.stream(stream):
             r.seed_meshlet_instances(ctx, N)
-        for kv in settings:  # (read by oxc_create only)
-            os.environ.pop(kv.split("=")[0], None)
         cframe, cctx = frame.c(), ctx.c()
         cctx.async_triangles = int(use_async)
+        cctx.unordered_output = unord
         if use_share:
             cctx.share_pass_tests = 1
         mg = L.MainGeometryContext()
@@ -98,7 +108,9 @@ def main():
                     check(lib.oxc_read_counters(ctxp, C.byref(cctx), C.byref(out), sp))
                     first = out.early_visible_meshlet_instances if flags & L.CULL_LATE_PASS else 0
                     vis = frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x].to(torch.int64)
-                    idx = frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64)
+                    idx = frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64) & 0xFFFFFFFF
+                    if unord:  # the ordered form's lists ascend: sorted, an unordered list must be those bytes
+                        vis, idx = torch.sort(vis)[0], torch.sort(idx)[0]
                     w = torch.arange(1, 1 + vis.numel(), device=dev, dtype=torch.int64)
                     sums.append((out.cull_triangles_cmd_x, out.draw_index_count, int((vis * (w % 1000003)).sum().item()),
                                  int((idx * (torch.arange(1, 1 + idx.numel(), device=dev, dtype=torch.int64) % 1000003)).sum().item())))
