@@ -831,7 +831,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     if (unord_tris) {  // one launch: test + expansion per span of 256 visible meshlets
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
-      launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), tri_grid_cap), ts);
+      launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap), ts);
     } else {
     {
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);

@@ -1318,24 +1318,30 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 #define OXC_TRI_IDX_AHEAD 2  // measured on config 3 (us per launch): 2/1 -> 123, 3/2 -> 125 (SGPR spills), 6 waves/SIMD with 3/2 or 4/3 -> 139-143; the loop version: 160
 #define OXC_TRI_POS_AHEAD 1
 #endif
-  constexpr int kPosAhead = OXC_TRI_POS_AHEAD;  // position gathers (need the vertex ids) run this many slots ahead of the decision
-  constexpr int kIdxAhead = OXC_TRI_IDX_AHEAD;  // vertex / micro index loads
+#ifndef OXC_TRI_WIDE_IDX_AHEAD
+#define OXC_TRI_WIDE_IDX_AHEAD OXC_TRI_IDX_AHEAD
+#define OXC_TRI_WIDE_POS_AHEAD OXC_TRI_POS_AHEAD
+#endif
+  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;  // position gathers (need the vertex ids) run this many slots ahead of the decision
+  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;  // vertex / micro index loads
   constexpr int kRecAhead = kIdxAhead + 1;      // scalar: Meshlet record
   constexpr int kRowAhead = kIdxAhead + 2;      // scalar: LOD pointers out of the InstCache row
   typedef const uint32_t __attribute__((address_space(4))) * k32;
   __shared__ uint32_t s_red[4];
-  constexpr uint32_t kChunksPerSpan = kTriSpan / kTriChunk;  // FUSED: a block takes whole spans, chunk after chunk
+  constexpr uint32_t kFSpan = kFusedTriSpan;                // FUSED: visible meshlets per span = per atomic_add (64, 128 or 256)
+  constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;    // a block takes whole spans, chunk after chunk
+  static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
   constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
   constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
-  __shared__ uint32_t f_off[FUSED ? kTriSpan : 1];
-  __shared__ uint64_t f_mask[FUSED ? kTriSpan * H : 1];
-  __shared__ uint32_t f_id[FUSED ? kTriSpan : 1];
+  __shared__ uint32_t f_off[FUSED ? kFSpan : 1];
+  __shared__ uint64_t f_mask[FUSED ? kFSpan * H : 1];
+  __shared__ uint32_t f_id[FUSED ? kFSpan : 1];
   __shared__ uint32_t f_strip[FUSED ? 4 * 192 * H : 1];
   __shared__ uint32_t f_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
-  const uint32_t nchunks = FUSED ? (V + kTriSpan - 1) / kTriSpan * kChunksPerSpan : (V + kTriChunk - 1) / kTriChunk;  // (FUSED: whole spans; a chunk beyond V re-does the last slot and leaves empty masks)
+  const uint32_t nchunks = FUSED ? (V + kFSpan - 1) / kFSpan * kChunksPerSpan : (V + kTriChunk - 1) / kTriChunk;  // (FUSED: whole spans; a chunk beyond V re-does the last slot and leaves empty masks)
   for (uint32_t chunk = FUSED ? blockIdx.x * kChunksPerSpan : blockIdx.x; chunk < nchunks;
        chunk = !FUSED ? chunk + gridDim.x : ((chunk % kChunksPerSpan) != kChunksPerSpan - 1u ? chunk + 1u : chunk - (kChunksPerSpan - 1u) + gridDim.x * kChunksPerSpan)) {
     // ---- lanes 0..15 fetch the MeshletInstance of this wave's 16 slots; everything that is uniform per
@@ -1467,18 +1473,21 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       if (c4 != kChunksPerSpan - 1u) continue;  // (block-uniform)
       __syncthreads();
       // ---- the span is tested: allocate its run and expand it (tris_emit_body with the base taken from the counter itself)
-      const uint32_t slot = (chunk / kChunksPerSpan) * kTriSpan + threadIdx.x;
+      const uint32_t slot = (chunk / kChunksPerSpan) * kFSpan + threadIdx.x;
+      const bool in_span = threadIdx.x < kFSpan;
       uint32_t c = 0;
 #pragma unroll
-      for (int h = 0; h < H; h++) c += (uint32_t)__popcll((unsigned long long)f_mask[threadIdx.x * H + h]);
-      const uint32_t id = slot < V ? a.visible[first + slot] : 0u;
+      for (int h = 0; h < H; h++) c += in_span ? (uint32_t)__popcll((unsigned long long)f_mask[(in_span ? threadIdx.x : 0u) * H + h]) : 0u;
+      const uint32_t id = (in_span && slot < V) ? a.visible[first + slot] : 0u;
       const uint32_t incl = wave_incl_scan(c, lane);
       if (lane == 63) s_red[wave] = incl;
       __syncthreads();
       uint32_t woff = 0;
       for (int k = 0; k < wave; k++) woff += s_red[k];
-      f_off[threadIdx.x] = woff + incl - c;
-      f_id[threadIdx.x] = id;
+      if (in_span) {
+        f_off[threadIdx.x] = woff + incl - c;
+        f_id[threadIdx.x] = id;
+      }
       if (threadIdx.x == 255) {
         const uint32_t total3 = (woff + incl) * 3u;
         f_base = total3 ? __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // DrawIndexedIndirect.index_count
@@ -1487,8 +1496,8 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       const uint32_t base3 = f_base;
       uint32_t* strip = f_strip + wave * (192 * H);
 #pragma unroll 2
-      for (int k = 0; k < 64; k++) {
-        const int sl = wave * 64 + k;
+      for (int k = 0; k < (int)(kFSpan / 4); k++) {
+        const int sl = wave * (int)(kFSpan / 4) + k;
         uint32_t before = 0;
 #pragma unroll
         for (int h = 0; h < H; h++) {
@@ -1654,7 +1663,14 @@ __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     float4 v = make_float4(m[r][0], m[r][1], m[r][2], m[r][3]);
+#ifdef OXC_HIZ_NT_STORE
+    {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(mip0 + (size_t)(y0 + r) * W + x0));
+    }
+#else
     *reinterpret_cast<float4*>(mip0 + (size_t)(y0 + r) * W + x0) = v;
+#endif
   }
   if (a.levels <= 1) return;
   // mip 1: 2x2 per thread
@@ -1850,7 +1866,7 @@ __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
 #define OXC_TRI_WAVES 8
 #endif
 #ifndef OXC_TRI_WIDE_WAVES
-#define OXC_TRI_WIDE_WAVES 6
+#define OXC_TRI_WIDE_WAVES 4  // (waves per SIMD of the WIDE instantiations: at 6 the 80-VGPR budget spills 25-36 VGPRs to scratch -- 113 / 234 us per launch on the 8 M x 124-triangle frame; 5: 99 / 211; 4: 90 / 185; 3: the same)
 #endif
 template <bool LATE, bool WIDE, bool SMALL>
 __global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_test(TriTestArgs a) {

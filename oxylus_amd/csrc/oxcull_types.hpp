@@ -103,6 +103,10 @@ constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block 
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
 constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel
+#ifndef OXC_FUSED_SPAN
+#define OXC_FUSED_SPAN 128  // (configs[2] frame with unordered_output = 1, us: 256 -> 573, 128 -> 562, 64 -> 562)
+#endif
+constexpr uint32_t kFusedTriSpan = OXC_FUSED_SPAN;  // ... and of the fused (unordered_output) kernel: visible meshlets per atomic_add on index_count
 #ifndef OXC_HIZ_LDS_TEXELS
 #define OXC_HIZ_LDS_TEXELS 384
 #endif

@@ -24,6 +24,10 @@ def shard_scene(scene: Scene, rank: int, world: int) -> Tuple[Scene, int]:
     Shard-local ids: mesh_instance_index and visibility offsets are rebased to the shard."""
     a, b = shard_ranges(scene.n_mesh_instances, world)[rank]
     K = scene.spec.meshlets_per_mesh
+    if scene.spec.share_meshes == 0:  # one mesh per instance: the rank holds ONLY its range of every array (SURVEY 8e)
+        first_meshlet = int((scene.meshlet_instances[:, 0] < a).sum().item())
+        return scene.slice(a, b), first_meshlet
+    # shared meshes: instances of any range may reference any mesh -- the (small) mesh table and its geometry stay whole
     kw = {}
     for name in ("bounds", "meshlets", "micro", "vidx", "positions", "lods", "meshes", "transforms"):
         kw[name] = getattr(scene, name).clone()

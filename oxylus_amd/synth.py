@@ -162,6 +162,48 @@ class Scene:
                   camera=self.camera, n_meshes=m, lod_meshlet_counts=self.lod_meshlet_counts, _lod_tables=tables)
         return s.bind()
 
+    def slice(self, a: int, b: int, device=None) -> "Scene":
+        """The sub-scene of mesh instances [a, b) with ONLY what they reference (a rank's bounds and geometry live on that rank
+        alone), shard-local indices: mesh / transform indices, MeshletInstance records and visibility offsets are rebased to the range.
+        Needs one mesh per instance (share_meshes == 0): the blob arrays are mesh-major, so the range is one run of every array."""
+        assert self.spec.share_meshes == 0 and 0 <= a < b <= self.n_mesh_instances
+        device = torch.device(device) if device is not None else self.device
+        L, K, t = self.spec.lod_count, self.spec.meshlets_per_mesh, self._lod_tables
+        mi = self.mesh_instances[a:b]
+        idx = torch.arange(a, b, dtype=mi.dtype, device=mi.device)
+        assert torch.equal(mi[:, 0], idx) and torch.equal(mi[:, 3], idx), "one mesh and one transform per instance, in instance order"
+
+        def run(table, per, total):
+            lo = int(table[a * per].item())
+            hi = int(total) if b == self.n_meshes else int(table[b * per].item())
+            return lo, hi
+
+        m0, m1 = run(t["meshlet_start"], L, self.bounds.shape[0])
+        if self.spec.with_geometry:
+            v0, v1 = run(t["vidx_start"], L, self.vidx.shape[0])
+            c0, c1 = run(t["micro_start"], L, self.micro.shape[0])
+            p0, p1 = run(t["mesh_vertex_start"], 1, self.positions.shape[0])
+        else:
+            (v0, v1), (c0, c1), (p0, p1) = (0, self.vidx.shape[0]), (0, self.micro.shape[0]), (0, self.positions.shape[0])
+        cp = lambda x: x.to(device).contiguous().clone()  # noqa: E731
+        tables = {"meshlet_start": t["meshlet_start"][a * L: b * L] - m0, "vidx_start": t["vidx_start"][a * L: b * L] - v0,
+                  "micro_start": t["micro_start"][a * L: b * L] - c0, "mesh_vertex_start": t["mesh_vertex_start"][a:b] - p0}
+        mesh_instances = cp(mi)
+        first_bit = int(mi[0, 4].item())
+        mesh_instances[:, 0] -= a
+        mesh_instances[:, 3] -= a
+        mesh_instances[:, 4] -= first_bit  # visibility offsets: the shard's mask starts at its own bit 0
+        lo_rec = int((self.meshlet_instances[:, 0] < a).sum().item())
+        hi_rec = int((self.meshlet_instances[:, 0] < b).sum().item())
+        mli = cp(self.meshlet_instances[lo_rec:hi_rec])
+        mli[:, 0] -= a
+        spec = SceneSpec(**{**self.spec.__dict__, "n_mesh_instances": b - a})
+        s = Scene(spec=spec, device=device, bounds=cp(self.bounds[m0:m1]), meshlets=cp(self.meshlets[m0:m1]), micro=cp(self.micro[c0:c1]), vidx=cp(self.vidx[v0:v1]),
+                  positions=cp(self.positions[p0:p1]), lods=cp(self.lods[a * L: b * L]), meshes=cp(self.meshes[a:b]), transforms=cp(self.transforms[a:b]),
+                  mesh_instances=mesh_instances, meshlet_instances=mli, camera=self.camera, n_meshes=b - a, lod_meshlet_counts=self.lod_meshlet_counts,
+                  _lod_tables=tables)
+        return s.bind()
+
     def algorithmic_bytes_meshlet_stage(self, visible_fraction: float) -> float:
         """8 B MeshletInstance + 16 B MeshletBounds read, 4*v B written, per-mesh
         tables (20+64+64+64 B) amortised over K meshlets."""
