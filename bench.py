@@ -73,9 +73,11 @@ def parse():
     ap.add_argument("--no-share-pass-tests", action="store_true",
                     help="config3: every call runs its own frustum + cone tests; by default the two calls of a frame set share_pass_tests (include/oxcull.h): the late "
                          "call reuses the early call's results -- same outputs; the other form is timed as a variant in scheduling_ab")
-    ap.add_argument("--unordered-output", type=int, default=0, choices=[0, 1, 2],
-                    help="config3: unordered_output of include/oxcull.h on the main line (0 = ascending lists, the default; 1 = fused triangle stage; 2 = appending "
-                         "HiZ meshlet tests too); the default line carries the other forms as scheduling_ab variants, compared as sorted sets")
+    ap.add_argument("--unordered-output", type=int, default=1, choices=[0, 1, 2],
+                    help="config3: unordered_output of include/oxcull.h on the main line.  Default 1 -- SURVEY 7: \"benchmark the unordered one, parity-test the ordered one "
+                         "(and the unordered one after sort)\": the triangle stage is one launch that allocates its output slots with an atomic_add, like the reference; "
+                         "0 = ascending lists (the library's default), 2 = appending HiZ meshlet tests too.  The other forms are timed as scheduling_ab variants; "
+                         "bit_match compares unordered lists sorted")
     ap.add_argument("--no-tris124", action="store_true", help="config3: skip the nested run with BASELINE's stated meshlet shape (64 verts / 124 tris, wide index, 8M meshlets)")
     ap.add_argument("--no-scheduling-ab", action="store_true", help="config3: skip the short timed runs of the other schedulings (profiling runs: their concurrent kernels would "
                                                                     "be averaged into the per-kernel durations of a kernel trace)")
@@ -565,6 +567,8 @@ def bench_config3(args, e):
     def timed_variant(async_on, ahead_on, share_on, unord=None):
         use_async[0], use_overlap[0], use_share[0] = async_on, ahead_on, share_on
         use_unord[0] = main_unord if unord is None else unord
+        if rank == 0 and os.environ.get("OXC_BENCH_TRACE"):
+            print(f"[bench]   variant async={async_on} ahead={ahead_on} share={share_on} unordered={use_unord[0]}", file=sys.stderr, flush=True)
         el = timed_steps(e, run_step, ab_steps, 1)
         return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "share_pass_tests": share_on, "unordered_output": use_unord[0],
                 "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
@@ -610,6 +614,8 @@ def bench_config3(args, e):
         torch.cuda.synchronize()
 
     # ---- per-kernel times (>= 50 launches each) and rooflines: algorithmic bytes of SURVEY 8d ----
+    if rank == 0 and os.environ.get("OXC_BENCH_TRACE"):
+        print("[bench]   kernel profile", file=sys.stderr, flush=True)
     n_prof = max(50, min(inner, 96))
     renderers = [r, r_hiz]
     kern = profile_kernels(e, renderers, lambda i: run_frame(), n_prof)
@@ -635,14 +641,14 @@ def bench_config3(args, e):
     # the second clock: the committed rocprofv3 --kernel-trace --stats averages of the same kernels (of the build the profile was taken
     # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
     # (the committed profiles are of the default workload: T = 64, ordered lists; any other shape has no counters of its own and says so)
-    prof_names = ["r04_config3_pmc.json", "r03_config3_pmc.json"] if (not wide and not args.small_triangle_cull and main_unord == 0 and n_meshlets == 10_000_000) else (
-        ["r04_tris124_pmc.json"] if (wide and main_unord == 0 and not args.small_triangle_cull) else [])
+    prof_names = ["r04_config3_pmc.json"] if (not wide and not args.small_triangle_cull and main_unord == 1 and main_share and n_meshlets == 10_000_000) else []
     rp = rocprof_kernel_us(prof_names) if prof_names else {}
     rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
                 "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
                 "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
                 "cull_meshlets_emit": ["oxc::k_cull_meshlets_emit<true, false>"], "cull_meshlets_emit_late": ["oxc::k_cull_meshlets_emit<true, true>"],
-                "cull_triangles_test": ["oxc::k_cull_triangles_test<false, false, false>"], "cull_triangles_test_late": ["oxc::k_cull_triangles_test<true, false, false>"],
+                "cull_triangles_test": ["oxc::k_cull_triangles_fused<false, false, false>" if main_unord else "oxc::k_cull_triangles_test<false, false, false>"],
+                "cull_triangles_test_late": ["oxc::k_cull_triangles_fused<true, false, false>" if main_unord else "oxc::k_cull_triangles_test<true, false, false>"],
                 "cull_triangles_emit": ["oxc::k_cull_triangles_emit<false, false>"], "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit<true, false>"]}
     kernels, frame_alg, frame_kernel_us = {}, 0.0, 0.0
     for name, k in kern.items():
@@ -669,8 +675,10 @@ def bench_config3(args, e):
         dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
         dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        traffic, traffic_src, traffic_same = pmc_traffic(prof_names, lambda k: "k_cull_triangles_test" in k) if prof_names else (None, None, None)
-        roofline = {"bound": "hbm", "kernel": "k_cull_triangles_test (early + late launch of a frame, averaged)", "achieved": round(achieved, 1),
+        dom_name = "k_cull_triangles_fused" if main_unord else "k_cull_triangles_test"
+        traffic, traffic_src, traffic_same = pmc_traffic(prof_names, lambda k: dom_name in k) if prof_names else (None, None, None)
+        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + ("; test + expansion in one launch: 988 B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
+                    "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_profile_is_of_this_device_code": traffic_same, "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
                     "launches_averaged": sum(k["launches"] for k in tt), "measured_stream_read_GBps": round(stream_gbps, 1),
@@ -684,7 +692,9 @@ def bench_config3(args, e):
                      "reference's traffic, not this kernel's (SURVEY 8d defines algorithmic bytes by the reference's data flow)"}
 
     # ---- CPU checker on a bounded prefix of the SAME arrays: bit_match + cpu_baseline (rank 0, N = 1) ----
-    bit_match, cpu_baseline, hiz_match, unpinned = None, None, None, None
+    bit_match, cpu_baseline, hiz_match, unpinned, bit_detail = None, None, None, None, None
+    if rank == 0 and os.environ.get("OXC_BENCH_TRACE"):
+        print("[bench]   checker", file=sys.stderr, flush=True)
     if rank == 0:
         import oracle  # checker only
 
@@ -719,8 +729,16 @@ def bench_config3(args, e):
         t_c0 = time.perf_counter()
         want, mask_want = cpu_sequence()
         t_seq = time.perf_counter() - t_c0
-        bit_match = bool(all(torch.equal(want[t][0], snap[t]["visible_prefix"]) and torch.equal(want[t][1], snap[t]["indices_prefix"]) for t in ("early", "late"))
-                         and torch.equal(mask_want, mask_after))
+        bit_detail = {f"{t}_{what}": bool(want[t][i].numel() == snap[t][key].numel() and torch.equal(want[t][i], snap[t][key]))
+                      for t in ("early", "late") for i, what, key in ((0, "visible", "visible_prefix"), (1, "indices", "indices_prefix"))}
+        nbits = m0 * K  # (the sample's mask bits: whole words, and the low bits of the word it shares with the next instance)
+        mw, ma = mask_want.clone(), mask_after.clone()
+        if nbits % 32:
+            keep = (1 << (nbits % 32)) - 1
+            mw[-1] &= keep
+            ma[-1] &= keep
+        bit_detail["mask"] = bool(torch.equal(mw, ma))
+        bit_match = all(bit_detail.values())
         if not args.no_cpu_baseline:
             # What no oracle can pin (the reference is compiled fast-math and ships no vectors): on the same sample, how many decisions
             # change under fused multiply-adds / reciprocal divisions, and how many triangles are ill-conditioned at all.
@@ -801,7 +819,8 @@ def bench_config3(args, e):
         "ms_per_step": round(elapsed * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": ("configs[2]: 10M meshlets + 4096^2 prior-frame HiZ (13 mips, built from an 8192^2 depth): HiZ build + early/late occlusion cull + "
-                         "per-triangle cull + ordered compaction into the indirect-draw buffers" if world == 1 else
+                         "per-triangle cull + compaction into the indirect-draw buffers (" + ("unordered_output = 1: slots allocated by atomic_add as in the reference, lists "
+                         "compared sorted" if main_unord else "ascending lists") + ")" if world == 1 else
                          f"configs[3]: {n_meshlets * world} meshlets sharded {world} ways by contiguous range (the configs[2] pipeline per rank): rank 0 builds the "
                          "4096^2 pyramid and broadcasts it over RCCL/xGMI, per-rank counters all-gathered every frame, shard-local ids and outputs"),
             "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris, "verts_per_meshlet": 64,
@@ -813,7 +832,7 @@ def bench_config3(args, e):
                                                          "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame, "hiz_exchange_ab": exchange_ab},
             "async_triangles": bool(use_async[0]), "share_pass_tests": bool(use_share[0]), "unordered_output": main_unord,
         },
-        "bit_match": bit_match, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
+        "bit_match": bit_match, "bit_match_detail": bit_detail if rank == 0 else None, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",
         "unpinned_gap": unpinned, "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
         "scheduling_ab": sched_ab,
     }
@@ -1105,6 +1124,11 @@ def main():
                 "kernels": res["kernels"], "roofline": res["roofline"],
                 "cpu_baseline": res["cpu_baseline"]}))
     else:
+        def stage_note(what):  # progress on stderr: which part of the default line is running (a fault names no kernel)
+            if e.rank == 0:
+                print(f"[bench] {what}", file=sys.stderr, flush=True)
+
+        stage_note("configs[2] main line")
         line = bench_config3(args, e)
         if e.world == 1 and not args.no_tris124 and args.tris == 64 and not args.meshlets:
             # BASELINE's stated meshlet shape -- 64 vertices / 124 triangles -- does not fit the reference's 24 + 8 bit packed index: the same
@@ -1113,25 +1137,29 @@ def main():
 
             a2 = copy.copy(args)
             a2.tris, a2.steps, a2.warmup = 124, max(4, args.steps // 4), 1
-            a2.no_scheduling_ab, a2.no_cpu_baseline, a2.cpu_prefix, a2.unordered_output = True, True, min(args.cpu_prefix, 250), 0
+            a2.no_scheduling_ab, a2.no_cpu_baseline, a2.cpu_prefix = True, True, min(args.cpu_prefix, 250)
+            stage_note("tris124")
             t = bench_config3(a2, e)
             line["tris124"] = {"workload": "the configs[2] frame with 64 vertices / 124 triangles per meshlet (BASELINE's stated shape): wide_triangle_index, "
                                            f"{t['config']['meshlets_per_gpu']} meshlets (2^23 ids), 4096^2 HiZ", "value": t["value"], "unit": "meshlets/s",
                                "ms_per_frame": t["config"]["ms_per_frame"], "frames_timed": t["config"]["frames_timed"], "wide_triangle_index": True,
                                "visible_fraction": t["config"]["visible_fraction"], "triangles_per_visible_meshlet": t["config"]["triangles_per_visible_meshlet"],
-                               "bit_match": t["bit_match"], "bit_match_sample": t["bit_match_sample"], "counts": t["counts"], "roofline": t["roofline"], "stage": t["stage"],
+                               "bit_match": t["bit_match"], "bit_match_detail": t["bit_match_detail"], "bit_match_sample": t["bit_match_sample"], "counts": t["counts"], "roofline": t["roofline"], "stage": t["stage"],
                                "kernels": {k: v for k, v in t["kernels"].items() if k.startswith("cull_triangles") or k.startswith("_")}}
         if e.world == 1 and not args.no_configs1:
+            stage_note("configs1")
             line["configs1"] = bench_config2(args, e, steps=8, warmup=1, with_cpu=not args.no_cpu_baseline)
         if e.world == 1 and not args.no_configs4:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_aux
 
+            stage_note("configs4")
             line["configs4"] = bench_aux.bench_config5(args, e.r, e.dev, e.stream, e.rank, e.world, e.dist, nested=True)
         if e.world == 1 and not args.no_real_geometry:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_aux
 
+            stage_note("real_geometry")
             line["real_geometry"] = bench_aux.bench_real_geometry(args, e.r, e.dev, e.stream, e.rank)
         if e.rank == 0:
             print(json.dumps(line))

@@ -348,10 +348,15 @@ OXC_DEV void expand_body(const ExpandArgs& a) {
     if (off >= a.cap) continue;
     cnt = min(cnt, a.cap - off);
     for (uint32_t k = lane; k < cnt; k += 64) {
+#ifdef OXC_EXPAND_NT
+      typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store(u2v{mi, k}, reinterpret_cast<u2v*>(out + off + k));
+#else
       GpuMeshletInstance r;
       r.mesh_instance_index = mi;
       r.meshlet_index = k;
       out[off + k] = r;
+#endif
     }
   }
 }
@@ -1276,6 +1281,82 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Expansion of a wave's consecutive slots (64-bit pass masks + meshlet-instance ids, both in LDS) into the packed index list
+// (visbuffer.slang:13-14, cull_triangles.slang:82-88).  The slots' indices are contiguous in the output, so they are staged in
+// rank order in a per-wave LDS run of kEmitRun dwords, laid out so that LDS index = global dword index (mod 4), and flushed as
+// 16-byte stores per lane -- 1 KiB per wave instruction, whole 128-byte lines -- with at most three single dwords at either end.
+// Round 3 stored every slot on its own (64 lanes x 4 bytes, 1.5 instructions per slot, lines shared between instructions): as `nt`
+// stores those took twice as long, and as default-policy stores they left ~420 MB of dirty index lines per frame in L2 / the Infinity
+// Cache, whose write-back the NEXT kernels paid (the pyramid build 69 -> 48 us and the triangle tests 90 / 164 -> 67 / 151 us with
+// the lines gone, configs[2] frame).  Whole-line `nt` stores get both.  Same bytes at the same addresses as the per-slot form.
+// ------------------------------------------------------------------------------------------
+#ifndef OXC_EMIT_RUN
+#define OXC_EMIT_RUN 1024
+#endif
+#ifndef OXC_EMIT_WIDE_NT
+#define OXC_EMIT_WIDE_NT 1
+#endif
+constexpr uint32_t kEmitRun = OXC_EMIT_RUN;  // dwords a wave stages between flushes (>= 384 + 3: one WIDE slot)
+template <int H, uint32_t kCornerBits>
+OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int first_slot, int nslots, uint32_t g0, uint32_t* __restrict__ out, uint32_t* run, int lane) {
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
+  uint32_t pad = (uint32_t)((reinterpret_cast<uint64_t>(out + g0) >> 2) & 3u);  // the run's first dword inside its 16-byte granule
+  uint32_t filled = 0;
+  auto flush = [&]() {
+    // run[pad, pad + filled) -> out[g0, g0 + filled)
+    const uint32_t head = min((4u - pad) & 3u, filled);
+    if ((uint32_t)lane < head) out[g0 + (uint32_t)lane] = run[pad + (uint32_t)lane];
+    const uint32_t nch = (filled - head) >> 2;
+    const uint32_t* src = run + pad + head;  // 16-byte aligned in LDS (pad + head == 0 or 4 whenever nch > 0)
+    uint32_t* dst = out + g0 + head;
+    for (uint32_t c = (uint32_t)lane; c < nch; c += 64u) {
+      const u4v v = *reinterpret_cast<const u4v*>(src + 4u * c);
+      if (OXC_EMIT_WIDE_NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(dst + 4u * c));
+      else
+        *reinterpret_cast<u4v*>(dst + 4u * c) = v;
+    }
+    const uint32_t done = head + 4u * nch, tail = filled - done;
+    if ((uint32_t)lane < tail) out[g0 + done + (uint32_t)lane] = run[pad + done + (uint32_t)lane];
+    g0 += filled;
+    pad = (pad + filled) & 3u;
+    filled = 0;
+  };
+#pragma unroll 2
+  for (int k = 0; k < nslots; k++) {
+    const int s = first_slot + k;
+    uint32_t cnt = 0;
+    uint64_t m[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      m[h] = masks[s * H + h];
+      cnt += (uint32_t)__popcll((unsigned long long)m[h]);
+    }
+    const uint32_t n3 = cnt * 3u;
+    if (n3 == 0u) continue;                      // (wave-uniform)
+    if (filled + n3 > kEmitRun) flush();         // (wave-uniform; same wave, in-order LDS: the flush has read the run before it is rewritten)
+    uint32_t* at = run + pad + filled;
+    uint32_t before = 0;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      if ((m[h] >> lane) & 1ull) {
+        const uint32_t rank = before + (uint32_t)__popcll((unsigned long long)(m[h] & ((1ull << lane) - 1ull)));
+        const uint32_t packed = ids[s] << kCornerBits;
+        const uint32_t t3 = ((uint32_t)lane + 64u * (uint32_t)h) * 3u;
+        at[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
+        at[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
+        at[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
+      }
+      before += (uint32_t)__popcll((unsigned long long)m[h]);
+    }
+    filled += n3;
+  }
+  if (filled) flush();
+}
+
 // ------------------------------------------------------------------------------------------
 // Triangle stage, test kernel (passes/cull_triangles.slang:27-90).  One wave per visible
 // meshlet.  Each vertex is fetched, decoded and transformed once (lane = vertex) instead of
@@ -1332,11 +1413,10 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
   constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;    // a block takes whole spans, chunk after chunk
   static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
   constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
-  constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
   __shared__ uint32_t f_off[FUSED ? kFSpan : 1];
   __shared__ uint64_t f_mask[FUSED ? kFSpan * H : 1];
   __shared__ uint32_t f_id[FUSED ? kFSpan : 1];
-  __shared__ uint32_t f_strip[FUSED ? 4 * 192 * H : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t f_run[FUSED ? 4 * (kEmitRun + 8u) : 4];
   __shared__ uint32_t f_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
@@ -1493,35 +1573,8 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         f_base = total3 ? __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // DrawIndexedIndirect.index_count
       }
       __syncthreads();
-      const uint32_t base3 = f_base;
-      uint32_t* strip = f_strip + wave * (192 * H);
-#pragma unroll 2
-      for (int k = 0; k < (int)(kFSpan / 4); k++) {
-        const int sl = wave * (int)(kFSpan / 4) + k;
-        uint32_t before = 0;
-#pragma unroll
-        for (int h = 0; h < H; h++) {
-          const uint64_t m = f_mask[sl * H + h];
-          if ((m >> lane) & 1ull) {
-            const uint32_t rank = before + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-            const uint32_t packed = f_id[sl] << kCornerBits;
-            const uint32_t t3 = ((uint32_t)lane + 64u * (uint32_t)h) * 3u;
-            strip[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
-            strip[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
-            strip[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
-          }
-          before += (uint32_t)__popcll((unsigned long long)m);
-        }
-        const uint32_t n3 = before * 3u;
-        if (n3 == 0u) continue;  // wave-uniform
-        const uint32_t o = base3 + f_off[sl] * 3u;
-        // same wave, in-order LDS: the reads below see the writes above
-#pragma unroll
-        for (uint32_t r = 0; r < 3u * H; r++) {
-          const uint32_t i = (uint32_t)lane + 64u * r;
-          if (i < n3) a.out[o + i] = strip[i];
-        }
-      }
+      expand_slots_wide<H, kCornerBits>(f_mask, f_id, wave * (int)(kFSpan / 4), (int)(kFSpan / 4), f_base + f_off[wave * (kFSpan / 4)] * 3u, a.out,
+                                        f_run + wave * (kEmitRun + 8u), lane);
       __syncthreads();  // the span's LDS rows are rewritten by the block's next span
     } else {
     {
@@ -1551,13 +1604,13 @@ template <bool LATE, bool WIDE>
 OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
   constexpr int H = WIDE ? 2 : 1;
   constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;  // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
-  constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_off[256];
   __shared__ uint64_t s_mask[256 * H];
   __shared__ uint32_t s_id[256];
-  __shared__ uint32_t s_strip[4 * 192 * H];
+  __shared__ __attribute__((aligned(16))) uint32_t s_run[4 * (kEmitRun + 8u)];
+  static_assert(kEmitRun >= 384u + 3u && kEmitRun % 4u == 0u, "a run holds at least one WIDE slot; rows stay 16-byte aligned");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;
@@ -1588,39 +1641,8 @@ OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
       a.draw_cmd[0] = (base + woff + incl) * 3u;  // DrawIndexedIndirect.index_count
     }
     __syncthreads();
-    // each wave expands 64 slots.  A slot's packed indices are first laid out in rank order in a
-    // per-wave LDS strip, then written as contiguous 256-byte wave stores (a direct store would be
-    // three stride-12 scatters per slot: store-issue bound, profiles/r01_config3_pmc.json).
-    uint32_t* strip = s_strip + wave * (192 * H);
-#pragma unroll 2
-    for (int k = 0; k < 64; k++) {
-      const int s = wave * 64 + k;
-      uint32_t n3 = 0, before = 0;
-#pragma unroll
-      for (int h = 0; h < H; h++) {
-        const uint64_t m = s_mask[s * H + h];
-        if ((m >> lane) & 1ull) {
-          const uint32_t rank = before + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-          const uint32_t packed = s_id[s] << kCornerBits;
-          const uint32_t t3 = ((uint32_t)lane + 64u * (uint32_t)h) * 3u;
-          strip[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
-          strip[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
-          strip[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
-        }
-        before += (uint32_t)__popcll((unsigned long long)m);
-      }
-      n3 = before * 3u;
-      if (n3 == 0u) continue;  // wave-uniform
-      const uint32_t o = (base + s_off[s]) * 3u;
-      // same wave, in-order LDS: the reads below see the writes above
-      // (dwordx4 stores of the 16-byte aligned body were measured slower, 44 -> 53 us, and `nt` stores much slower,
-      // 44 -> 82-98 us, although they leave the caches clean for the next kernels: hiz 80 -> 57 us, net loss)
-#pragma unroll
-      for (uint32_t r = 0; r < 3u * H; r++) {
-        const uint32_t i = (uint32_t)lane + 64u * r;
-        if (i < n3) a.out[o + i] = strip[i];
-      }
-    }
+    // each wave expands its 64 slots: one contiguous run of the index list (expand_slots_wide above)
+    expand_slots_wide<H, kCornerBits>(s_mask, s_id, wave * 64, 64, (base + s_off[wave * 64]) * 3u, a.out, s_run + wave * (kEmitRun + 8u), lane);
     __syncthreads();
   }
 #ifdef OXC_EMIT_RELEASE
@@ -1644,9 +1666,16 @@ OXC_DEV float hiz_point_sample(const float* __restrict__ depth, uint32_t dw, uin
   int32_t sy = cvt_i32_sat(floorf(vv * (float)dh));
   sx = min(max(sx, 0), (int32_t)dw - 1);
   sy = min(max(sy, 0), (int32_t)dh - 1);
+#ifdef OXC_HIZ_NT_LOAD
+  return __builtin_nontemporal_load(depth + (size_t)sy * dw + sx);
+#else
   return depth[(size_t)sy * dw + sx];  // (`nt` here was measured slower: 80 -> 84 us for the 8192^2 -> 4096^2 build)
+#endif
 }
 
+#ifndef OXC_HIZ_NT_STORE
+#define OXC_HIZ_NT_STORE 1
+#endif
 __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
   __shared__ float s_a[16 * 16];
   __shared__ float s_b[8 * 8];
@@ -1663,14 +1692,17 @@ __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     float4 v = make_float4(m[r][0], m[r][1], m[r][2], m[r][3]);
-#ifdef OXC_HIZ_NT_STORE
+    // `nt`: mip 0 is 3/4 of the pyramid (64 MB at 4096^2) and nothing reads it back soon -- the meshlet tests sample a few texels of
+    // it per candidate.  Written with the default policy its lines sat in L2 / the Infinity Cache and their write-back was paid by
+    // the kernels that followed (configs[2] frame, us: k_hiz_tile 74.6 -> 62.3, triangle tests 80.7 / 160.2 -> 79.1 / 153.2, frame
+    // 565 -> 544; byte-identical).  OXC_HIZ_NT_STORE: 0 = none, 1 = mip 0, 2 = mips 0 and 1.
     {
       typedef float f4v __attribute__((ext_vector_type(4)));
-      __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(mip0 + (size_t)(y0 + r) * W + x0));
+      if (OXC_HIZ_NT_STORE >= 1)
+        __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(mip0 + (size_t)(y0 + r) * W + x0));
+      else
+        *reinterpret_cast<float4*>(mip0 + (size_t)(y0 + r) * W + x0) = v;
     }
-#else
-    *reinterpret_cast<float4*>(mip0 + (size_t)(y0 + r) * W + x0) = v;
-#endif
   }
   if (a.levels <= 1) return;
   // mip 1: 2x2 per thread
@@ -1684,8 +1716,13 @@ __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
     float* mip1 = a.hiz + a.level_off[1];
     const uint32_t w1 = W >> 1;
 #pragma unroll
-    for (int r = 0; r < 2; r++)
-      *reinterpret_cast<float2*>(mip1 + (size_t)((y0 >> 1) + r) * w1 + (x0 >> 1)) = make_float2(q[r][0], q[r][1]);
+    for (int r = 0; r < 2; r++) {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      if (OXC_HIZ_NT_STORE >= 2)
+        __builtin_nontemporal_store(f2v{q[r][0], q[r][1]}, reinterpret_cast<f2v*>(mip1 + (size_t)((y0 >> 1) + r) * w1 + (x0 >> 1)));
+      else
+        *reinterpret_cast<float2*>(mip1 + (size_t)((y0 >> 1) + r) * w1 + (x0 >> 1)) = make_float2(q[r][0], q[r][1]);
+    }
   }
   if (a.levels <= 2) return;
   // mip 2: one per thread
