@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--copies", type=int, default=0, help="config2: independent scene copies rotated through (default: >= 1.1 GB)")
     ap.add_argument("--streams", type=int, default=3, help="config2: independent batches in flight (contexts on their own HIP streams)")
     ap.add_argument("--batch", type=int, default=16, help="config2 / config5: frames (views) per oxc_cull_geometry_batch call (max 16)")
+    ap.add_argument("--explicit-lists", action="store_true", help="config5: write the per-view MeshletInstance records (the reference's cull_meshes output) on the main line; "
+                                                                   "by default they stay implicit {first, count} runs (include/oxcull.h: implicit_meshlet_instances) and the explicit form is timed as a variant")
     ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement")
     ap.add_argument("--no-configs4", action="store_true", help="config3: skip the nested configs[4] measurement (10M meshlets x 16 views)")
     ap.add_argument("--no-real-geometry", action="store_true", help="config3: skip the nested run of the same frame over instanced real meshes (clusteriser-built)")

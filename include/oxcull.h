@@ -198,6 +198,17 @@ typedef struct oxc_cull_geometry_context {
    * Inside a block's run the ids ascend; the runs land in arrival order.  A triangle's three packed indices stay adjacent.  Sorting a
    * list gives the bytes of the ordered form (tests/test_gpu_unordered.py).  Ignored by oxc_cull_geometry_batch's fused path. */
   uint32_t unordered_output;
+  /* Extension (configs[4]: many views of one scene): 1 = cull_meshes leaves this view's MeshletInstance list IMPLICIT instead of writing
+   * one 8-byte record per meshlet and view (466 MB per 16 cascade views of a 10 M-meshlet scene, a third of the call): record i of the
+   * view is {mesh instance m, meshlet i - first[m]} for first[m] <= i < first[m] + count[m], with {first[m], count[m]} written to
+   * meshlet_instance_runs_buffer (u32[2 * mesh_instance_count]; count 0 = the view's cull_meshes dropped the instance) -- "emit runs,
+   * expand in the consumer".  visible_meshlet_instances_indices, the counters and lod_index are exactly those of the explicit form;
+   * expanding the runs gives the explicit list byte for byte (tests/test_gpu_round2.py).  Only oxc_cull_geometry_batch's multi-view path
+   * has no reader of the records (its meshlet test walks the instances' bounds directly), so only there is the flag accepted: every
+   * element must set it, stages must not include OXC_STAGE_TRIANGLES; any other call with the flag returns OXC_INVALID_ARG.  The
+   * runs buffer alone (flag 0) is also filled by that path when given. */
+  uint32_t implicit_meshlet_instances;
+  uint32_t _reserved1; /* must be 0 */
   /* in/out: produced when init_cull_meshes, consumed (and updated) by later calls of the
    * sequence, exactly like the reference's hoisted context (RendererInstance.cpp:793-800). */
   oxc_buffer visibility_buffer;        /* GPU::MeshletInstanceVisibility {total, early, late} */
@@ -205,6 +216,8 @@ typedef struct oxc_cull_geometry_context {
   /* out: fresh per call (CullGeometry.cpp:125-127, 380-382) */
   oxc_buffer cull_triangles_cmd_buffer; /* VkDispatchIndirectCommand {#visible meshlets, 1, 1} */
   oxc_buffer draw_geometry_cmd_buffer;  /* VkDrawIndexedIndirectCommand {indexCount, 1, 0, 0, 0} */
+  /* out, optional, caller-owned: {first, count} of every mesh instance in this view's MeshletInstance list (see implicit_meshlet_instances) */
+  oxc_buffer meshlet_instance_runs_buffer;
 } oxc_cull_geometry_context;
 
 /* MainGeometryContext fields used by generate_hiz (RendererInstance.hpp:199-216). */
@@ -544,6 +557,10 @@ oxc_status oxc_comm_destroy(oxc_ctx* ctx);
  * (visibility_buffer), index_count (draw_geometry_cmd)} -- into counts4_dptr (device, u32[4]) on the stream: the input of
  * oxc_exchange_counts, without a host round trip.  Usable on one GPU as well. */
 oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* context, void* counts4_dptr, void* hip_stream);
+/* The same for the `count` (<= 16) contexts of one oxc_cull_geometry_batch call in ONE launch: counts4_dptr[i][4] = element i's
+ * {emitted, visibility.total (the length of the view's MeshletInstance list), late, index_count} -- configs[4] sharded over ranks all-gathers
+ * these per view. */
+oxc_status oxc_pack_counters_batch(oxc_ctx* ctx, uint32_t count, const oxc_cull_geometry_context* contexts, void* counts4_dptr, void* hip_stream);
 /* all-gather of 4 u32 per rank: counts4_dptr (this rank's {emitted, early, late, index_count}) -> all_counts_dptr[world][4] */
 oxc_status oxc_exchange_counts(oxc_ctx* ctx, const void* counts4_dptr, void* all_counts_dptr, void* hip_stream);
 /* broadcast of every level of `hiz` from rank `root` (in place) */

@@ -381,6 +381,11 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
   }
   if (c->small_triangle_cull > 1u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: small_triangle_cull must be 0 or 1");
   if (c->share_pass_tests > 1u || c->unordered_output > 2u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: share_pass_tests must be 0 or 1, unordered_output 0, 1 or 2");
+  if (c->implicit_meshlet_instances > 1u || c->_reserved1 != 0u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: implicit_meshlet_instances must be 0 or 1, _reserved1 0");
+  if (c->meshlet_instance_runs_buffer.dptr && c->meshlet_instance_runs_buffer.bytes < (uint64_t)M * 8u)
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshlet_instance_runs_buffer < 8 bytes per mesh instance");
+  if (c->implicit_meshlet_instances && (!c->meshlet_instance_runs_buffer.dptr || do_tris || !do_meshes))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: implicit_meshlet_instances needs meshlet_instance_runs_buffer, cull_meshes in the call and no triangle stage");
   const uint32_t views = c->use_hpb ? c->vsm_clipmap_count : 0u;
   if (c->use_hpb && do_meshlets) {
     if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
@@ -522,6 +527,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   }
   const uint32_t M = ci.M, N = ci.N, views = ci.views;
   const bool do_meshes = ci.do_meshes, do_meshlets = ci.do_meshlets, do_tris = ci.do_tris, occl = ci.occl, late = ci.late;
+  if (c->implicit_meshlet_instances)
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry: implicit_meshlet_instances is accepted by oxc_cull_geometry_batch's multi-view path only (this call's meshlet test reads the records)");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   oxc_status st = ensure_capacity(ctx, M, N, views, 0, s);
@@ -903,6 +910,12 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
                 frames[e].transforms_world_buffer.dptr == frames[0].transforms_world_buffer.dptr && contexts[e].cull_flags == contexts[0].cull_flags;
     same_pos = same_pos && std::memcmp(contexts[e].cull_camera.position, contexts[0].cull_camera.position, 12) == 0;
   }
+  // implicit_meshlet_instances: all elements or none, and only where nothing reads the records -- the multi-view meshlet stage
+  uint32_t n_implicit = 0;
+  for (uint32_t e = 0; e < count; e++) n_implicit += contexts[e].implicit_meshlet_instances ? 1u : 0u;
+  if (n_implicit && (n_implicit != count || !multiview || ci[0].do_tris))
+    return fail(ctx, OXC_INVALID_ARG, "cull_geometry_batch: implicit_meshlet_instances must be set on every element of a multi-view batch (same scene, cull_meshes in every element, no triangle stage)");
+  const bool implicit_lists = n_implicit != 0;
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   ctx->shared.valid = false;  // (share_pass_tests: a batch may rebuild any list)
   for (uint32_t e = 0; e < count; e++) {
@@ -1016,8 +1029,10 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       KernelTimer t(ctx, OXC_K_MESHES_SCAN, s);
       launch_scan_batch(ctx->batch_dev, count, s);
     }
-    KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
-    launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, cap), s);
+    if (!implicit_lists) {  // (implicit: the records have no reader in this call; the runs are written by k_mv_group)
+      KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
+      launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, cap), s);
+    }
   }
   if (do_meshlets && multiview) {
     const uint32_t Mv = ci[0].M;
@@ -1090,6 +1105,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       w.supers = reinterpret_cast<uint32_t*>(mb + o_sup[e]);
       w.scan_total = reinterpret_cast<uint32_t*>(mb + o_vtot[e]);
       w.out = static_cast<uint32_t*>(frames[e].visible_meshlet_instances_indices_buffer.dptr);
+      w.runs = static_cast<uint32_t*>(contexts[e].meshlet_instance_runs_buffer.dptr);
       w.tri_cmd = cores[e].slot + SLOT_TRI_CMD;
       w.n_cap = ci[e].N;
       w.n_supers = cdiv(vchunks_max[e], kChunksPerSuper);
@@ -1581,6 +1597,26 @@ oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, v
   OXC_JOIN(ctx, hip_stream);
   launch_pack_counters(static_cast<const uint32_t*>(c->visibility_buffer.dptr), static_cast<const uint32_t*>(c->cull_triangles_cmd_buffer.dptr),
                        static_cast<const uint32_t*>(c->draw_geometry_cmd_buffer.dptr), static_cast<uint32_t*>(counts4_dptr), static_cast<hipStream_t>(hip_stream));
+  OXC_HIP(ctx, hipGetLastError());
+  return OXC_OK;
+}
+
+oxc_status oxc_pack_counters_batch(oxc_ctx* ctx, uint32_t count, const oxc_cull_geometry_context* cs, void* counts4_dptr, void* hip_stream) {
+  if (!ctx) return OXC_INVALID_ARG;
+  if (!cs || !counts4_dptr || count == 0 || count > kMaxBatch) return fail(ctx, OXC_INVALID_ARG, "pack_counters_batch: 1..16 contexts and an output buffer");
+  PackBlob b;
+  std::memset(&b, 0, sizeof b);
+  b.count = count;
+  for (uint32_t e = 0; e < count; e++) {
+    if (cs[e].struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "pack_counters_batch: bad context struct");
+    b.vis[e] = static_cast<const uint32_t*>(cs[e].visibility_buffer.dptr);
+    b.tri_cmd[e] = static_cast<const uint32_t*>(cs[e].cull_triangles_cmd_buffer.dptr);
+    b.draw_cmd[e] = static_cast<const uint32_t*>(cs[e].draw_geometry_cmd_buffer.dptr);
+  }
+  OXC_HIP(ctx, hipSetDevice(ctx->device));
+  OXC_ORDER(ctx, hip_stream);
+  OXC_JOIN(ctx, hip_stream);
+  launch_pack_counters_batch(b, static_cast<uint32_t*>(counts4_dptr), static_cast<hipStream_t>(hip_stream));
   OXC_HIP(ctx, hipGetLastError());
   return OXC_OK;
 }

@@ -2002,6 +2002,10 @@ __global__ __launch_bounds__(256) void k_mv_group(MvArgs a, MvBlob blob) {
       kb = row->bounds;
       kt = row->transform_index;
       w.vchunks[mi] = (cnt + kMvChunk - 1) / kMvChunk;
+      if (w.runs) {  // the view's list as runs (implicit_meshlet_instances): record i = {mi, i - first} for first <= i < first + count
+        w.runs[2 * mi] = cnt ? off : 0u;
+        w.runs[2 * mi + 1] = cnt;
+      }
     }
     uint32_t same = 0;  // views of this instance with my key
 #pragma unroll
@@ -2373,6 +2377,17 @@ void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s) { hipLaunch
 void launch_pack_counters(const uint32_t* vis, const uint32_t* tri_cmd, const uint32_t* draw_cmd, uint32_t* out4, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_counters, dim3(1), dim3(64), 0, s, vis, tri_cmd, draw_cmd, out4);
 }
+__global__ __launch_bounds__(64) void k_pack_counters_batch(PackBlob b, uint32_t* out4) {
+  const uint32_t e = threadIdx.x;
+  if (e < b.count) {
+    const uint32_t *vis = b.vis[e], *tri = b.tri_cmd[e], *draw = b.draw_cmd[e];
+    out4[e * 4 + 0] = tri ? tri[0] : 0u;
+    out4[e * 4 + 1] = vis ? vis[0] : 0u;  // (a batched element is a plain call: visibility.total = the length of its MeshletInstance list)
+    out4[e * 4 + 2] = vis ? vis[2] : 0u;
+    out4[e * 4 + 3] = draw ? draw[0] : 0u;
+  }
+}
+void launch_pack_counters_batch(const PackBlob& blob, uint32_t* out4, hipStream_t s) { hipLaunchKernelGGL(k_pack_counters_batch, dim3(1), dim3(64), 0, s, blob, out4); }
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s) {
   hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(p), bytes / 16, sink);
 }

@@ -321,6 +321,7 @@ struct MvView {
   uint32_t* supers;              // per 64 chunks (stride kSuperStride)
   uint32_t* scan_total;          // [2] number of chunks of this view
   uint32_t* out;                 // visible_meshlet_instances_indices of this view
+  uint32_t* runs;                // [M][2] optional: {first, count} of the instance in this view's (possibly implicit) MeshletInstance list
   uint32_t* tri_cmd;
   uint32_t n_cap;                // the view's list capacity
   uint32_t n_supers;
@@ -381,6 +382,13 @@ void launch_tris_test_batch(const BatchElem* dev, uint32_t count, uint32_t grid,
 void launch_tris_emit_batch(const BatchElem* dev, uint32_t count, uint32_t grid, hipStream_t s);
 void launch_seed_slot(uint32_t* slot, uint32_t total, hipStream_t s);
 void launch_pack_counters(const uint32_t* vis, const uint32_t* tri_cmd, const uint32_t* draw_cmd, uint32_t* out4, hipStream_t s);
+struct PackBlob {  // one element per context of a batched call (null pointers read as 0)
+  const uint32_t* vis[kMaxBatch];
+  const uint32_t* tri_cmd[kMaxBatch];
+  const uint32_t* draw_cmd[kMaxBatch];
+  uint32_t count;
+};
+void launch_pack_counters_batch(const PackBlob& blob, uint32_t* out4, hipStream_t s);
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, uint32_t grid, hipStream_t s);
 void launch_debug_decode_bounds(const void* bounds, uint32_t n, float* out10, hipStream_t s);
 struct DebugProjectArgs {

@@ -85,6 +85,10 @@ struct CullGeometryContext {
   // extension (order only): 0 = ascending lists; 1 / 2 = the reference's own atomic slot allocation, aggregated per block / wave step
   // (one launch per stage instead of test + ordered emit; include/oxcull.h: unordered_output)
   uint32_t unordered_output = 0;
+  // extension (oxc_cull_geometry_batch's multi-view path only): cull_meshes leaves the MeshletInstance list implicit and writes
+  // {first, count} per mesh instance here instead (include/oxcull.h: implicit_meshlet_instances)
+  bool implicit_meshlet_instances = false;
+  Buffer meshlet_instance_runs_buffer = {};
 };
 
 struct MainGeometryContext {
@@ -154,6 +158,8 @@ public:
     c.async_triangles = context.async_triangles;
     c.share_pass_tests = context.share_pass_tests;
     c.unordered_output = context.unordered_output;
+    c.implicit_meshlet_instances = context.implicit_meshlet_instances;
+    c.meshlet_instance_runs_buffer = context.meshlet_instance_runs_buffer;
     c.visibility_buffer = context.visibility_buffer;
     c.cull_meshlets_cmd_buffer = context.cull_meshlets_cmd_buffer;
     check(oxc_cull_geometry(ctx_, &f, &c, stream_));

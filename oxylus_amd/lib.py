@@ -104,10 +104,13 @@ class CullGeometryContext(C.Structure):
         ("async_triangles", C.c_uint32),
         ("share_pass_tests", C.c_uint32),
         ("unordered_output", C.c_uint32),
+        ("implicit_meshlet_instances", C.c_uint32),
+        ("_reserved1", C.c_uint32),
         ("visibility_buffer", Buffer),
         ("cull_meshlets_cmd_buffer", Buffer),
         ("cull_triangles_cmd_buffer", Buffer),
         ("draw_geometry_cmd_buffer", Buffer),
+        ("meshlet_instance_runs_buffer", Buffer),
     ]
 
 
@@ -266,6 +269,7 @@ EXPORTS = [
     "oxc_comm_init",
     "oxc_comm_destroy",
     "oxc_pack_counters",
+    "oxc_pack_counters_batch",
     "oxc_exchange_counts",
     "oxc_broadcast_hiz",
     "oxc_broadcast_hiz_levels",
@@ -342,6 +346,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     lib.oxc_comm_destroy.argtypes = [vp]
     lib.oxc_pack_counters.argtypes = [vp, C.POINTER(CullGeometryContext), vp, vp]
+    lib.oxc_pack_counters_batch.argtypes = [vp, C.c_uint32, C.POINTER(CullGeometryContext), vp, vp]
     lib.oxc_exchange_counts.argtypes = [vp, vp, vp, vp]
     lib.oxc_broadcast_hiz.argtypes = [vp, C.POINTER(Image), C.c_uint64, C.c_uint32, vp]
     lib.oxc_broadcast_hiz_levels.argtypes = [vp, C.POINTER(Image), C.c_uint32, C.c_uint64, C.c_uint32, vp]

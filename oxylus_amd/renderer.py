@@ -155,6 +155,8 @@ class CullGeometryContext:
     async_triangles: bool = False  # extension (scheduling only): the triangle stage runs on the context's own stream; RendererInstance.join_triangles
     share_pass_tests: bool = False  # extension (caching only): the late HiZ call of a frame reuses the early call's frustum + cone results (include/oxcull.h)
     unordered_output: int = 0  # extension (order only): 0 ascending lists, 1 / 2 the reference's atomic slot allocation (include/oxcull.h)
+    implicit_meshlet_instances: bool = False  # extension (multi-view batch only): the MeshletInstance list stays implicit, runs in meshlet_instance_runs_buffer
+    meshlet_instance_runs_buffer: Optional[torch.Tensor] = None  # int32 [M, 2] {first, count} per mesh instance (out)
     stages: int = 0
     _c: L.CullGeometryContext = field(default_factory=L.CullGeometryContext)
 
@@ -177,6 +179,8 @@ class CullGeometryContext:
         c.async_triangles = int(self.async_triangles)
         c.share_pass_tests = int(self.share_pass_tests)
         c.unordered_output = int(self.unordered_output)
+        c.implicit_meshlet_instances = int(self.implicit_meshlet_instances)
+        c.meshlet_instance_runs_buffer = _buf(self.meshlet_instance_runs_buffer)
         return c
 
 

@@ -245,6 +245,94 @@ def test_multiview_batch_equals_single_calls(renderer, oracle_lib, views, move_c
     assert nonempty >= 2
 
 
+@pytest.mark.parametrize("views,cap_frac", [(5, 1.0), (16, 1.0), (7, 0.4)], ids=["5-views", "16-views", "7-views-short-lists"])
+def test_multiview_batch_with_implicit_meshlet_instance_lists(renderer, oracle_lib, views, cap_frac):
+    """implicit_meshlet_instances (include/oxcull.h): the per-view MeshletInstance records are not written -- {first, count} runs per mesh
+    instance are -- and nothing else changes: counters, lod_index and visible lists are those of the explicit batch, the record buffers
+    stay untouched, and expanding the runs gives the explicit list byte for byte.  Also: the runs buffer alone (flag off), and the calls
+    that must refuse the flag."""
+    import dataclasses
+
+    gpu = make_scene(SceneSpec(n_mesh_instances=700, meshlets_per_mesh=150, lod_count=3, seed=0x0A1DE5 + 9, with_geometry=False), "cuda")
+    M = gpu.n_mesh_instances
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+    cams = _cascade_cameras(gpu, views)
+    for v, cam in enumerate(cams):
+        cam.position[0], cam.position[1], cam.position[2] = 3.0 * v, -2.0 * v, -60.0 + 11.0 * v
+    cap = max(64, int(gpu.n_meshlet_instances * cap_frac))
+
+    def frame_of(e):
+        f = PreparedFrame.create(gpu if e == 0 else dataclasses.replace(gpu, mesh_instances=gpu.mesh_instances.clone()), with_triangles=False, expand=False)
+        f.meshlet_instances_buffer.fill_(-7)
+        if cap_frac < 1.0:
+            f.max_meshlet_instance_count = cap
+        return f
+
+    def run(implicit, with_runs):
+        frames = [frame_of(e) for e in range(views)]
+        runs = [torch.full((M, 2), -1, dtype=torch.int32, device="cuda") if with_runs else None for _ in range(views)]
+        ctxs = [CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cam, stages=L.STAGE_MESHES | L.STAGE_MESHLETS,
+                                    implicit_meshlet_instances=implicit, meshlet_instance_runs_buffer=runs[v]) for v, cam in enumerate(cams)]
+        renderer.cull_geometry_batch(frames, ctxs)
+        return frames, ctxs, runs, [renderer.read_counters(c) for c in ctxs]
+
+    f0, c0, _, n0 = run(False, False)
+    f1, c1, r1, n1 = run(True, True)
+    f2, c2, r2, n2 = run(False, True)
+    total = 0
+    for v in range(views):
+        a, b = n0[v], n1[v]
+        assert (a.total_visible_meshlet_instances, a.cull_triangles_cmd_x, a.cull_meshlets_cmd_x) == (b.total_visible_meshlet_instances, b.cull_triangles_cmd_x, b.cull_meshlets_cmd_x), f"view {v}"
+        n, e = a.total_visible_meshlet_instances, a.cull_triangles_cmd_x
+        total += n
+        assert torch.equal(f0[v].visible_meshlet_instances_indices_buffer[:e], f1[v].visible_meshlet_instances_indices_buffer[:e]), f"view {v}: visible list"
+        assert torch.equal(f0[v].scene.mesh_instances[:, 1], f1[v].scene.mesh_instances[:, 1]), f"view {v}: lod_index"
+        assert int((f1[v].meshlet_instances_buffer != -7).sum()) == 0, f"view {v}: records were written although the list is implicit"
+        # the runs, expanded, ARE the explicit list
+        first, count = r1[v][:, 0].long(), r1[v][:, 1].long()
+        assert int(count.sum()) == n and torch.equal(r1[v], r2[v])
+        inst = torch.repeat_interleave(torch.arange(M, device="cuda"), count)
+        start = torch.repeat_interleave(first, count)
+        want = torch.stack([inst, torch.arange(n, device="cuda") - start], 1).to(torch.int32)
+        kept = count > 0
+        assert torch.equal(first[kept], (torch.cumsum(count, 0) - count)[kept]), f"view {v}: runs are not the list's prefix sums"
+        assert torch.equal(want, f0[v].meshlet_instances_buffer[:n]), f"view {v}: expanded runs differ from the explicit list"
+        assert torch.equal(f2[v].meshlet_instances_buffer[:n], f0[v].meshlet_instances_buffer[:n])
+    assert total > 10_000
+    # refused: a single call, a batch in which only some elements set it, a batch with the triangle stage
+    renderer.prepared_frame = frame_of(1)
+    bad = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cams[0], stages=L.STAGE_MESHES | L.STAGE_MESHLETS, implicit_meshlet_instances=True,
+                              meshlet_instance_runs_buffer=torch.zeros((M, 2), dtype=torch.int32, device="cuda"))
+    with pytest.raises(L.OxcError) as ei:
+        renderer.cull_geometry(bad)
+    assert ei.value.status == L.OXC_INVALID_ARG
+    frames = [frame_of(e) for e in range(2)]
+    mixed = [CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=cams[v], stages=L.STAGE_MESHES | L.STAGE_MESHLETS, implicit_meshlet_instances=(v == 0),
+                                 meshlet_instance_runs_buffer=torch.zeros((M, 2), dtype=torch.int32, device="cuda")) for v in range(2)]
+    with pytest.raises(L.OxcError) as ei:
+        renderer.cull_geometry_batch(frames, mixed)
+    assert ei.value.status == L.OXC_INVALID_ARG
+
+
+def test_pack_counters_batch_matches_read_counters(renderer, oracle_lib):
+    import ctypes as C
+    import dataclasses
+
+    gpu = make_scene(SceneSpec(n_mesh_instances=300, meshlets_per_mesh=120, lod_count=2, seed=0x0A1DE5 + 12, with_geometry=False), "cuda")
+    cams = _cascade_cameras(gpu, 6)
+    frames = [PreparedFrame.create(gpu if e == 0 else dataclasses.replace(gpu, mesh_instances=gpu.mesh_instances.clone()), with_triangles=False, expand=False) for e in range(6)]
+    ctxs = [CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD, cull_camera=cam, stages=L.STAGE_MESHES | L.STAGE_MESHLETS) for cam in cams]
+    renderer.cull_geometry_batch(frames, ctxs)
+    cc = (L.CullGeometryContext * 6)(*[c._c for c in ctxs])
+    out = torch.full((6, 4), -1, dtype=torch.int32, device="cuda")
+    renderer._check(renderer._lib.oxc_pack_counters_batch(renderer._ctx, 6, cc, C.c_void_p(out.data_ptr()), renderer._stream(None)))
+    torch.cuda.synchronize()
+    for v in range(6):
+        cnt = renderer.read_counters(ctxs[v])
+        assert out[v].tolist() == [cnt.cull_triangles_cmd_x, cnt.total_visible_meshlet_instances, cnt.late_visible_meshlet_instances, cnt.draw_index_count]
+    assert int(out[:, 0].sum()) > 0
+
+
 def test_multiview_batch_with_the_triangle_stage(renderer, oracle_lib):
     """Three views of one scene with every stage: the per-view triangle kernels consume the visible lists the multi-view meshlet stage
     wrote; packed indices and draw commands must equal those of single calls."""

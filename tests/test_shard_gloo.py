@@ -91,6 +91,70 @@ def test_two_rank_shards_union_equals_single(tmp_path, oracle_lib, top):
     assert r[0]["hiz_sum"] == r[1]["hiz_sum"] == float(hz.double().sum())
 
 
+def _worker_views(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from oxylus_amd import lib as L
+    from oxylus_amd.shard import exchange_counts, exclusive_offsets, shard_scene
+    from oxylus_amd.synth import SceneSpec, make_scene, virtual_shadow_matrices
+
+    scene = make_scene(SceneSpec(n_mesh_instances=23, meshlets_per_mesh=80, lod_count=2, seed=78, with_geometry=False), "cpu")
+    shard, _ = shard_scene(scene, rank, world)
+    mats, _, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], [0.3, -1.0, 0.2], 500.0, 2.0, 4)
+    flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
+    local, lists = [], []
+    for v in range(4):  # configs[4]: every view runs cull_meshes (frustum + LOD select) + cull_meshlets over the rank's range
+        s = shard.clone()
+        cam = s.cull_camera()
+        for k in range(16):
+            cam.projection_view[k] = float(mats[v][k])
+        cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
+        cam.near_clip = zn
+        mli, _ = oracle.cull_meshes(s, cam, flags)
+        vis = oracle.cull_meshlets(s, cam, mli)
+        local += [vis.numel(), mli.shape[0]]
+        lists.append(vis.numpy())
+    allc = exchange_counts(torch.tensor(local, dtype=torch.int32))  # [world, views * 2]: {visible, processed} per view
+    offs = exclusive_offsets(allc)
+    # a view's global MeshletInstance list is the concatenation of the ranks' lists (contiguous instance ranges): local id + the lists before it
+    np.savez(os.path.join(out_dir, f"views{rank}.npz"), counts=allc.numpy(), **{f"v{v}": lists[v].astype(np.int64) + int(offs[rank, 2 * v + 1]) for v in range(4)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_multiview_shards_union_equals_single(tmp_path, oracle_lib):
+    """configs[4] sharded: contiguous instance ranges per rank, per-view {visible, processed} counts all-gathered,
+    union of the per-view visible lists (ids rebased by the gathered list lengths) == the single-process result of every view."""
+    import oracle
+    from oxylus_amd import lib as L
+    from oxylus_amd.synth import SceneSpec, make_scene, virtual_shadow_matrices
+
+    world = 2
+    mp.spawn(_worker_views, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    scene = make_scene(SceneSpec(n_mesh_instances=23, meshlets_per_mesh=80, lod_count=2, seed=78, with_geometry=False), "cpu")
+    mats, _, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], [0.3, -1.0, 0.2], 500.0, 2.0, 4)
+    r = [np.load(os.path.join(str(tmp_path), f"views{k}.npz")) for k in range(world)]
+    assert np.array_equal(r[0]["counts"], r[1]["counts"])
+    seen = 0
+    for v in range(4):
+        s = scene.clone()
+        cam = s.cull_camera()
+        for k in range(16):
+            cam.projection_view[k] = float(mats[v][k])
+        cam.position[0], cam.position[1], cam.position[2] = 0.0, 0.0, -60.0
+        cam.near_clip = zn
+        mli, _ = oracle.cull_meshes(s, cam, L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD)
+        vis = oracle.cull_meshlets(s, cam, mli)
+        assert int(r[0]["counts"][:, 2 * v].sum()) == vis.numel() and int(r[0]["counts"][:, 2 * v + 1].sum()) == mli.shape[0], f"view {v}: gathered counts"
+        assert np.array_equal(np.concatenate([r[0][f"v{v}"], r[1][f"v{v}"]]), vis.numpy().astype(np.int64)), f"view {v}: union of the shard lists"
+        seen += vis.numel()
+    assert seen > 30  # (the small cascades see little of a 23-instance scene; the wide ones most of it)
+
+
 def test_shard_ranges_cover_and_disjoint():
     from oxylus_amd.shard import shard_ranges
 

@@ -284,10 +284,13 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
     """--workload config5 = BASELINE configs[4]: 10M meshlets x `--views` orthographic cascade views (Shadowmaps.cpp:9-63
     generalised: doubling extents around the camera), per-view cull_meshes (frustum + LOD select, cull_meshes.slang:35-57) +
     cull_meshlets, up to 16 views per oxc_cull_geometry_batch call.  `value` counts the meshlets the meshlet stage actually
-    PROCESSED (per view: the list cull_meshes produced), not candidates x views.  nested=True: return the result (bench.py hangs
-    it into the driver's default line as "configs4") instead of printing it."""
+    PROCESSED (per view: the length of the list cull_meshes produced), not candidates x views.
+    Main line: implicit_meshlet_instances = 1 (include/oxcull.h) -- the per-view MeshletInstance lists stay {first, count} runs per mesh
+    instance, nothing in this call reads the 8-byte records; the explicit form (records written: 466 MB per step) is timed as a variant and
+    must give the same visible lists.  N > 1: every rank culls its own contiguous range of mesh instances (weak scaling: 10M meshlets per
+    rank, generated per rank) and the per-view {visible, processed} counts are all-gathered every step (RCCL); `value` comes from the
+    gathered sums.  nested=True: return the result (bench.py hangs it into the driver's default line as "configs4")."""
     import dataclasses
-    import os
 
     from oxylus_amd.synth import virtual_shadow_matrices
 
@@ -303,10 +306,13 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         base = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=False, lod_count=3, seed=0x0A1DE5 + 4 + rank), dev)
         r.reserve(M, n_meshlets)
         mats, _, zn = virtual_shadow_matrices([0.0, 0.0, -60.0], [0.3, -1.0, 0.2], 500.0, 2.0, views)
-        lanes = []  # one set of outputs (and one mesh_instances copy: cull_meshes writes lod_index per view) per batch element
+        lanes, runs = [], []  # one set of outputs (and one mesh_instances copy: cull_meshes writes lod_index per view) per batch element
         for e in range(min(vb, views)):
             sc = base if e == 0 else dataclasses.replace(base, mesh_instances=base.mesh_instances.clone())
             lanes.append(PreparedFrame.create(sc, with_triangles=False, expand=False))
+            runs.append(torch.zeros((M, 2), dtype=torch.int32, device=dev))
+        gathered = torch.zeros((world, min(vb, views), 4), dtype=torch.int32, device=dev) if world > 1 else None
+        mine = torch.zeros((min(vb, views), 4), dtype=torch.int32, device=dev)
 
     def camera_of(scene, v):
         cam = scene.cull_camera()
@@ -316,54 +322,115 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         cam.near_clip = zn
         return cam
 
-    groups = []
-    for v0 in range(0, views, vb):
-        n = min(vb, views - v0)
-        cf = (L.PreparedFrame * n)(*[lanes[e].c() for e in range(n)])
-        cc = (L.CullGeometryContext * n)()
-        for e in range(n):
-            ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=camera_of(base, v0 + e), stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
-            C.memmove(C.byref(cc[e]), C.byref(ctx.c()), C.sizeof(L.CullGeometryContext))
-        groups.append((n, cf, cc))
+    def make_groups(implicit):
+        groups = []
+        for v0 in range(0, views, vb):
+            n = min(vb, views - v0)
+            cf = (L.PreparedFrame * n)(*[lanes[e].c() for e in range(n)])
+            cc = (L.CullGeometryContext * n)()
+            for e in range(n):
+                ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=flags, cull_camera=camera_of(base, v0 + e), stages=L.STAGE_MESHES | L.STAGE_MESHLETS,
+                                          implicit_meshlet_instances=implicit and n > 1, meshlet_instance_runs_buffer=runs[e] if n > 1 else None)
+                C.memmove(C.byref(cc[e]), C.byref(ctx.c()), C.sizeof(L.CullGeometryContext))
+            groups.append((n, cf, cc))
+        return groups
+
+    implicit_main = not getattr(args, "explicit_lists", False)
+    groups = make_groups(implicit_main)
 
     def check(st):
         if st != L.OXC_OK:
             raise RuntimeError(lib.oxc_last_error(ctxp).decode())
 
-    def one():
-        for n, cf, cc in groups:
+    def one(gs=None):
+        for n, cf, cc in (gs or groups):
             check(lib.oxc_cull_geometry(ctxp, cf, cc, sp) if n == 1 else lib.oxc_cull_geometry_batch(ctxp, n, cf, cc, sp))
+            if world > 1:  # the north star's exchange: per-view counts to every rank, packed on the device (one launch), all-gathered on the stream
+                check(lib.oxc_pack_counters_batch(ctxp, n, cc, C.c_void_p(mine.data_ptr()), sp))
+                dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+
+    def timed(gs, k):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(k):
+                one(gs)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    def read_lists(gs):
+        per_view, lists = [], []
+        for gi, (n, cf, cc) in enumerate(gs):  # the last step's counters are still in the slots of each element
+            for e in range(n):
+                out = L.Counters()
+                check(lib.oxc_read_counters(ctxp, C.byref(cc[e]), C.byref(out), sp))
+                per_view.append((out.total_visible_meshlet_instances, out.cull_triangles_cmd_x))
+                if gi == len(gs) - 1 or len(gs) == 1:  # lists of the views whose lanes were not overwritten by a later group
+                    lists.append((gi * vb + e, lanes[e].visible_meshlet_instances_indices_buffer[:out.cull_triangles_cmd_x].cpu()))
+        return per_view, lists
 
     with torch.cuda.stream(stream):
         for _ in range(warmup):
             one()
     torch.cuda.synchronize()
-    per_view, got_lists = [], []
-    for gi, (n, cf, cc) in enumerate(groups):  # the last step's counters are still in the slots of each element
-        for e in range(n):
-            out = L.Counters()
-            check(lib.oxc_read_counters(ctxp, C.byref(cc[e]), C.byref(out), sp))
-            per_view.append((out.total_visible_meshlet_instances, out.cull_triangles_cmd_x))
-            if gi == len(groups) - 1 or len(groups) == 1:  # lists of the views whose lanes were not overwritten by a later group
-                got_lists.append((gi * vb + e, lanes[e].visible_meshlet_instances_indices_buffer[:out.cull_triangles_cmd_x].cpu()))
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        for _ in range(steps):
-            one()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    per_view, got_lists = read_lists(groups)
+    dt = timed(groups, steps)
     processed = sum(t for t, _ in per_view)
     visible = sum(v for _, v in per_view)
+    world_processed, world_visible = processed * world, visible * world
+    counts_source = "this rank's counters (N = 1)"
+    if world > 1 and len(groups) == 1:  # the gathered counters of the last step -- every rank's, every view's -- are what `value` is computed from
+        torch.cuda.synchronize()
+        g = gathered.cpu()
+        world_visible, world_processed = int(g[:, :, 0].sum()), int(g[:, :, 1].sum())
+        counts_source = "sum over ranks and views of the all-gathered {visible, processed} counters of the last step"
+    elif world > 1:
+        counts_source = "rank-local counters x world (more than one call per step: the gather buffer holds the last call's views only)" 
 
-    # ---- per-kernel times (HIP-event pair per launch) and rooflines: SURVEY 8d per meshlet-view, the per-view list included ----
+    # ---- what the one-pass design moves (per step, this rank): every bounds record once per GROUP of views that kept its instance at the same LOD ----
+    unique_meshlets, steps_256, view_chunks, kept_rows = None, None, None, None
+    if len(groups) == 1 and groups[0][0] > 1:
+        torch.cuda.synchronize()
+        keys, cnts = [], []
+        for e in range(groups[0][0]):
+            cnt = runs[e][:, 1].long()
+            lod = lanes[e].scene.mesh_instances[:, 1].long()
+            kept = cnt > 0
+            keys.append((torch.arange(M, device=dev) * 8 + lod)[kept])
+            cnts.append(cnt[kept])
+        allk, allc = torch.cat(keys), torch.cat(cnts)
+        uniq, inv = torch.unique(allk, return_inverse=True)
+        cu = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev)
+        cu[inv] = allc  # (a group's count is a function of its key: the LOD's meshlet count, or what the list capacity left of it)
+        unique_meshlets, steps_256 = int(cu.sum()), int(((cu + 255) // 256).sum())
+        view_chunks, kept_rows = int(((allc + 255) // 256).sum()), int(allk.numel())
+
+    # ---- the explicit form (records written) as a variant: same visible lists ----
+    variant = None
+    if implicit_main and groups[0][0] > 1:
+        g2 = make_groups(False)
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                one(g2)
+        pv2, lists2 = read_lists(g2)
+        dt2 = timed(g2, max(4, steps // 4))
+        variant = {"implicit_meshlet_instances": 0, "ms_per_step": round(dt2 / max(4, steps // 4) * 1e3, 6),
+                   "outputs_match_main_line": bool(pv2 == per_view and all(torch.equal(a[1], b[1]) for a, b in zip(lists2, got_lists))),
+                   "note": "the per-view MeshletInstance records written as the reference's cull_meshes does (8 B per processed meshlet-view)"}
+        with torch.cuda.stream(stream):
+            one()  # back to the main form for the kernel profile
+        torch.cuda.synchronize()
+
+    # ---- per-kernel times (HIP-event pair per launch) and rooflines ----
     n_prof = 30
     r.profile_begin()
     with torch.cuda.stream(stream):
@@ -375,12 +442,17 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         # cull_meshes: 212 B of tables per mesh instance and view read, one 384 B row + count written
         "prepare_instances": views * M * (212 + 384 + 4),
         "meshes_scan": views * M * 8,
-        # the per-view MeshletInstance list is an OUTPUT of cull_meshes (8 B per processed meshlet-view written) ...
-        "meshes_expand": processed * 8.0,
-        # ... and the meshlet test reads it back with the 16 B bounds record: the reference's 24.2 B per meshlet
-        "cull_meshlets_test": processed * (24.0 + 212.0 / K),
         "cull_meshlets_emit": processed / 8.0 + 4.0 * visible,
     }
+    if not implicit_main:
+        alg["meshes_expand"] = processed * 8.0  # the explicit per-view lists: 8 B per processed meshlet-view written
+    if unique_meshlets is not None:
+        # the one-pass meshlet test (k_mv_test): 16 B bounds per UNIQUE meshlet (once per group of views, not once per view) + 8 B step record
+        # per 256-meshlet chunk + the 384 B instance row of every (view, instance) kept + per view chunk 4 ballots, a count and an id base (40 B)
+        alg["cull_meshlets_test"] = 16.0 * unique_meshlets + 8.0 * steps_256 + 384.0 * kept_rows + 40.0 * view_chunks
+        alg["multiview_setup"] = views * M * 16.0 + 8.0 * steps_256 + (8.0 * views * M)  # groups + counts read, step list and runs written
+    else:
+        alg["cull_meshlets_test"] = processed * (24.0 + 212.0 / K)  # per-view kernels: the reference's 24.2 B per processed meshlet-view
     kernels, step_alg, step_kernel_us = {}, 0.0, 0.0
     for name, k in prof["kernels"].items():
         per_step_us = k["total_ms"] / n_prof * 1e3
@@ -397,9 +469,20 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
     roofline = None
     if "cull_meshlets_test" in kernels:
         kt = kernels["cull_meshlets_test"]
-        roofline = {"bound": "hbm", "kernel": "meshlet test of all views (launches of one step summed)", "achieved": kt["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": kt["frac"], "traffic": None, "algorithmic_bytes_per_step": kt["algorithmic_bytes_per_step"], "kernel_us_per_step": kt["us_per_step"],
-                    "note": "24.2 B per processed meshlet-view (8 B list record + 16 B bounds + 212 / K B of per-instance tables, SURVEY 8d a9); HIP-event time"}
+        traffic, tsrc = None, None
+        try:  # HBM bytes of k_mv_test from the committed PMC profile of this workload (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_config5_pmc.json")))
+            for kn, cs in pm.get("pmc", {}).items():
+                if "k_mv_test" in kn and "hbm_read_bytes_corrected" in cs:
+                    traffic, tsrc = round(cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0)), "profiles/r04_config5_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)"
+        except (OSError, ValueError):
+            pass
+        roofline = {"bound": "hbm", "kernel": "k_mv_test: the one-pass multi-view meshlet test (launches of one step summed)", "achieved": kt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": kt["frac"], "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_step": kt["algorithmic_bytes_per_step"],
+                    "kernel_us_per_step": kt["us_per_step"], "unique_meshlets_per_step": unique_meshlets, "processed_meshlet_views_per_step": processed,
+                    "note": "algorithmic bytes of the ONE-PASS design: a bounds record is loaded once per group of views that kept its instance at the same LOD (16 B per unique "
+                            "meshlet), not once per view -- the reference's per-view kernels would move 24.2 B per processed meshlet-view, "
+                            f"{round(processed * (24.0 + 212.0 / K))} B per step; the kernel does the tests of all views on those bytes, i.e. it is bound by VALU issue, not by HBM"}
     ms_per_step = dt / steps * 1e3
     stage = {"algorithmic_bytes_per_step": round(step_alg), "ms_per_step": round(ms_per_step, 6), "achieved_GBps": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1),
              "stage_frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "sum_of_kernel_us_per_step": round(step_kernel_us, 1)}
@@ -427,15 +510,19 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
                         "sample": f"one pass over all {views} views of the same arrays: oracle cull_meshes (one thread) + cull_meshlets (static range split over {cores} "
                                   f"pthreads) per view, {t_views:.2f} s for {processed} processed meshlet-views"}
     res = {
-        "metric": "meshlets/s culled (meshlets the meshlet stage processed, summed over views)", "value": round(processed * world * steps / dt, 1),
+        "metric": "meshlets/s culled (meshlets the meshlet stage processed, summed over views)", "value": round(world_processed * steps / dt, 1),
         "unit": "meshlets/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[4]: {n_meshlets} LOD-0 meshlets x {views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets",
+        "config": {"workload": f"configs[4]: {n_meshlets} LOD-0 meshlets x {views} orthographic cascade views, per-view cull_meshes (frustum + LOD select) + cull_meshlets"
+                               + ("" if world == 1 else f", the mesh-instance range sharded {world} ways (contiguous ranges, one per rank), per-view counts all-gathered every step"),
                    "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "views": views, "views_per_call": vb, "calls_per_step": launches_per_step,
+                   "implicit_meshlet_instances": int(implicit_main and groups[0][0] > 1),
                    "candidate_meshlet_views_per_step": n_meshlets * views, "processed_meshlet_views_per_step": processed,
+                   "world_processed_meshlet_views_per_step": world_processed, "world_visible_per_step": world_visible, "value_counts_from": counts_source,
+                   "counts_all_gather_bytes_per_rank_per_step": (16 * min(vb, views) * len(groups)) if world > 1 else 0,
                    "per_view_processed": [t for t, _ in per_view], "per_view_visible": [v for _, v in per_view]},
         "bit_match": bit_match, "bit_match_sample": f"per-view list lengths and visible counts of all {views} views; the visible lists of views {[v for v, _ in got_lists][:1]}..{[v for v, _ in got_lists][-1:]} byte for byte",
-        "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
+        "explicit_lists_variant": variant, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
     if nested:
         del base, lanes
         torch.cuda.empty_cache()
