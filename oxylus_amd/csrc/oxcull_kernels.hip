@@ -348,15 +348,12 @@ OXC_DEV void expand_body(const ExpandArgs& a) {
     if (off >= a.cap) continue;
     cnt = min(cnt, a.cap - off);
     for (uint32_t k = lane; k < cnt; k += 64) {
-#ifdef OXC_EXPAND_NT
-      typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-      __builtin_nontemporal_store(u2v{mi, k}, reinterpret_cast<u2v*>(out + off + k));
-#else
+      // (`nt` stores here were measured on configs[4], 466 MB of records per step: this kernel 86 -> 120 us, the kernels after it 20 us
+      //  faster in total -- a net loss; the records that nobody reads are better not written at all: implicit_meshlet_instances)
       GpuMeshletInstance r;
       r.mesh_instance_index = mi;
       r.meshlet_index = k;
       out[off + k] = r;
-#endif
     }
   }
 }
@@ -1645,11 +1642,6 @@ OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
     expand_slots_wide<H, kCornerBits>(s_mask, s_id, wave * 64, 64, (base + s_off[wave * 64]) * 3u, a.out, s_run + wave * (kEmitRun + 8u), lane);
     __syncthreads();
   }
-#ifdef OXC_EMIT_RELEASE
-  // experiment (round 4): write the block's dirty index lines back before the kernel ends, so that the NEXT kernel (the pyramid build of
-  // the following frame) does not inherit their write-back
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1666,11 +1658,7 @@ OXC_DEV float hiz_point_sample(const float* __restrict__ depth, uint32_t dw, uin
   int32_t sy = cvt_i32_sat(floorf(vv * (float)dh));
   sx = min(max(sx, 0), (int32_t)dw - 1);
   sy = min(max(sy, 0), (int32_t)dh - 1);
-#ifdef OXC_HIZ_NT_LOAD
-  return __builtin_nontemporal_load(depth + (size_t)sy * dw + sx);
-#else
-  return depth[(size_t)sy * dw + sx];  // (`nt` here was measured slower: 80 -> 84 us for the 8192^2 -> 4096^2 build)
-#endif
+  return depth[(size_t)sy * dw + sx];  // (`nt` LOADS here are slower: 80 -> 84 us in round 1, 46 -> 71 us with the nt stores of round 4)
 }
 
 #ifndef OXC_HIZ_NT_STORE

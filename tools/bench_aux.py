@@ -347,7 +347,13 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
             check(lib.oxc_cull_geometry(ctxp, cf, cc, sp) if n == 1 else lib.oxc_cull_geometry_batch(ctxp, n, cf, cc, sp))
             if world > 1:  # the north star's exchange: per-view counts to every rank, packed on the device (one launch), all-gathered on the stream
                 check(lib.oxc_pack_counters_batch(ctxp, n, cc, C.c_void_p(mine.data_ptr()), sp))
-                dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+                if os.environ.get("OXC_BENCH_DEBUG_BACKEND"):  # gloo has no device all-gather: stage through the host (development aid on a one-GPU box, not a measurement)
+                    stream.synchronize()
+                    host = torch.zeros(gathered.numel(), dtype=torch.int32)
+                    dist.all_gather_into_tensor(host, mine.cpu().view(-1))
+                    gathered.view(-1).copy_(host)
+                else:
+                    dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
 
     def timed(gs, k):
         torch.cuda.synchronize()
@@ -362,7 +368,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
             dist.barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([dt], device="cpu" if os.environ.get("OXC_BENCH_DEBUG_BACKEND") else dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt
@@ -597,6 +603,8 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
         mask = frame.meshlet_instance_visibility_mask_buffer
     torch.cuda.synchronize()
     cframe, cctx = frame.c(), ctx.c()
+    unord = int(getattr(args, "unordered_output", 0))  # as the main line of bench.py (benchmark the unordered form, compare it sorted)
+    cctx.unordered_output = unord
     mg = L.MainGeometryContext()
     mg.struct_size = C.sizeof(L.MainGeometryContext)
     mg.depth_attachment, mg.hiz_attachment = depth.c(), hiz.c()
@@ -613,9 +621,12 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
                 out = L.Counters()
                 check(lib.oxc_read_counters(ctxp, C.byref(cctx), C.byref(out), sp))
                 first = out.early_visible_meshlet_instances if tag == "late" else 0
-                snap[tag] = {"emitted": out.cull_triangles_cmd_x, "index_count": out.draw_index_count, "first": first,
-                             "visible": frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x].clone(),
-                             "indices": frame.reordered_indices_buffer[:out.draw_index_count].clone()}
+                vis_l = frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x].clone()
+                idx_l = frame.reordered_indices_buffer[:out.draw_index_count].clone()
+                if unord:  # the ordered form's lists ascend: an unordered list is compared sorted
+                    vis_l = torch.sort(vis_l)[0]
+                    idx_l = torch.sort(idx_l.to(torch.int64) & 0xFFFFFFFF)[0].to(torch.int32)
+                snap[tag] = {"emitted": out.cull_triangles_cmd_x, "index_count": out.draw_index_count, "first": first, "visible": vis_l, "indices": idx_l}
 
     with torch.cuda.stream(stream):
         one(record=True)
@@ -699,6 +710,7 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
                             "meshlets": "first use in LOD 0's meshlet order (oxylus_amd.mesh_build.reorder_vertices): a meshlet's position gather touches ~6 instead of ~10 cache lines; "
                                         "measured on this scene: 0.96 -> 0.81 ms per frame, triangle tests 182 / 383 -> 125 / 290 us"}.get(vertex_order, vertex_order),
            "meshlets": N, "mesh_instances": M, "meshes": fill, "asset_build_seconds": round(t_build, 2), "ms_per_frame": round(ms_per_frame, 6),
+           "share_pass_tests": True, "unordered_output": unord,
            "value": round(N / (ms_per_frame * 1e-3), 1), "unit": "meshlets/s", "frames_timed": frames,
            "visible_fraction": round((v_e + v_l) / N, 4), "triangles_per_visible_meshlet": round((t_e + t_l) / max(1, v_e + v_l), 2),
            "counts": {"early": v_e, "late": v_l, "early_triangles": t_e, "late_triangles": t_l}, "kernels_avg_us": kernels, "bit_match": bit_match, "unpinned_gap": unpinned}
