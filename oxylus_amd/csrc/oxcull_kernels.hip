@@ -1022,414 +1022,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// share_pass_tests kernels, round 4: occlusion batches filled ACROSS wave steps (meshlets_run_body).
-// The occlusion test (8 projected corners, 24 exact quotients, the pyramid taps: ~380 VALU passes per 64-lane batch) is most of what these
-// two kernels execute, and meshlets_hiz_body runs it per wave step on whatever the step left: ~20 candidates in the early call (31 % of
-// the lanes), ~66 in the late one (1.55 batches at 66 %).  Here a wave's work item is R consecutive steps; the candidates of a step are
-// appended to a per-wave LDS queue (every record tagged with the sub-step, group and lane it came from), a batch runs as soon as 64 are
-// queued -- of ONE mesh instance: its projection_view * world sits in SGPRs -- and what is left is flushed when the instance changes
-// or the item ends.  A batch's result is a cleared bit in a 64-bit word per (sub-step, group) in LDS; a step is FINISHED (mask words,
-// emit ballots, counts) from those words once every one of its candidates has been through a batch -- for the usual step, whose 256
-// mask bits are one run, after the item's last flush; a step whose mask bits are scattered flushes at once and finishes per lane as
-// before.  Same tests on the same operands, same stores: byte-identical outputs, fewer and fuller batches.
-// ------------------------------------------------------------------------------------------
-#ifndef OXC_SHARED_RUN
-#define OXC_SHARED_RUN 2
-#endif
-template <bool LATE, int R>
-OXC_DEV void meshlets_run_body(const MeshletTestArgs& a) {
-  constexpr int G = 4, kWaves = 4;
-  constexpr uint32_t kPend = 64u + (uint32_t)G * 64u;  // < 64 entries wait for company; a round adds at most G * 64
-  static_assert(R == 1 || R == 2 || R == 4, "steps per work item");
-  set_half_denorm_flush();
-  __shared__ uint32_t s_level_off[13];
-  __shared__ uint32_t s_lds_off[13];
-  __shared__ float s_hiz_top[kHizLdsTexels];
-  __shared__ uint4 s_strip[kWaves][kPend];
-  __shared__ uint32_t s_flags[kWaves][G * 64];
-  __shared__ uint32_t s_occ[kWaves][R][G][2];  // per sub-step and group: a CLEARED bit = that lane's meshlet is occluded
-  __shared__ uint32_t s_pre[kWaves][R][G][2];  // ... a set bit = visible unless occluded (passed the camera tests [and was visible last frame])
-  __shared__ uint32_t s_was[kWaves][R][G][2];  // ... visible last frame
-  __shared__ uint32_t s_run0[kWaves][R];       // first mask bit of a sub-step whose mask bits are one run
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
-  const uint32_t nwords = (N + 63u) / 64u;
-  const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
-  if (threadIdx.x < 13) {
-    s_level_off[threadIdx.x] = a.hiz_level_off[threadIdx.x];
-    s_lds_off[threadIdx.x] = a.hiz_lds_off[threadIdx.x];
-  }
-  for (uint32_t k = a.hiz_lds_first; k < a.hiz_levels; k++) {  // the top of the pyramid, once per block
-    const uint32_t n = mip_dim(a.hiz_w, k) * mip_dim(a.hiz_h, k);
-    const float* src = a.hiz_data + a.hiz_level_off[k];
-    float* dst = s_hiz_top + a.hiz_lds_off[k];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-  }
-  __syncthreads();
-  HizView hiz;
-  hiz.data = a.hiz_data;
-  hiz.width = a.hiz_w;
-  hiz.height = a.hiz_h;
-  hiz.levels = a.hiz_levels;
-  hiz.lds = s_hiz_top;
-  hiz.lds_off = s_lds_off;
-  hiz.lds_first = a.hiz_lds_first;
-  hiz.inv_width = exact_reciprocal_or_zero(a.hiz_w);
-  hiz.inv_height = exact_reciprocal_or_zero(a.hiz_h);
-  const uint64_t mlis = reinterpret_cast<uint64_t>(a.meshlet_instances);
-  const uint32_t last_index = N ? N - 1u : 0u;
-  const float camx = a.cam_pos[0], camy = a.cam_pos[1], camz = a.cam_pos[2];
-  (void)camx, (void)camy, (void)camz;
-
-  const uint32_t nsteps = nchunks * kWaves;
-  const uint32_t nitems = (nsteps + (uint32_t)R - 1u) / (uint32_t)R;
-  constexpr uint32_t kItemRun = kTicketRun / R >= 1 ? kTicketRun / R : 1;  // consecutive tickets of a counter = consecutive items (as OXC_TICKET_STEP)
-  const uint32_t K = min(kTicketCounters, gridDim.x), kx = blockIdx.x % K;
-  uint32_t* const ticket = a.tickets ? a.tickets + kx * kSuperStride : nullptr;
-  auto draw_ticket = [&]() -> uint32_t {
-    uint32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-  };
-  auto item_of = [&](uint32_t t) -> uint32_t { return ((t / kItemRun) * K + kx) * kItemRun + t % kItemRun; };
-  uint4* const strip = s_strip[wave];
-  uint32_t* const flg = s_flags[wave];
-
-  // ---- the occlusion queue of this wave: strip[0, pending), all of mesh instance pend_row
-  uint32_t pending = 0;
-  uint32_t pend_mi = 0xFFFFFFFFu;
-  kconst32p pend_row = const_row(a.cache, 0);
-  auto occlusion_batch = [&](const float* mvp, uint32_t first, uint32_t count) {  // entries strip[first, first + count), count <= 64
-    const bool act = (uint32_t)lane < count;
-    const uint4 b = strip[first + (act ? (uint32_t)lane : 0u)];
-    const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
-    const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-    const bool occluded = aabb_occluded(mvp, a.near_clip, qx, qy, qz, rx, ry, rz, hiz, s_level_off, act);
-    if (act && occluded) {
-      const uint32_t tag = b.y >> 16;  // (sub-step << 8) | (group << 6) | lane
-      __hip_atomic_fetch_and(&s_occ[wave][tag >> 8][(tag >> 6) & 3u][(tag >> 5) & 1u], ~(1u << (tag & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  };
-  // batches are taken from the tail (no entry moves); keep = 63: whole batches only, keep = 0: everything
-  auto drain = [&](kconst32p row, uint32_t keep) {
-    if (pending <= keep) return;
-    float mvp[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) mvp[k] = asf(row[kRowMvp + k]);
-    while (pending > keep) {
-      const uint32_t n = min(pending, 64u);
-      occlusion_batch(mvp, pending - n, n);
-      pending -= n;
-    }
-  };
-  auto flush_full = [&](kconst32p row) { drain(row, 63u); };
-  auto flush_all = [&](kconst32p row) {
-    drain(row, 0u);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // results are in the words; the strip may be rewritten
-  };
-
-  uint32_t item = blockIdx.x * kWaves + wave;
-  if (ticket) item = item_of(readlane_u(draw_ticket(), 0));
-  while (item < nitems) {
-    uint32_t next_ticket = 0u;
-    uint32_t fast_mask = 0u;  // sub-steps that are finished from the words after the item's last flush (wave-uniform)
-#pragma nounroll
-    for (int s = 0; s < R; s++) {  // (a real loop: R copies of this body do not fit the instruction cache -- R = 2 unrolled: 130 / 107 us against 98 / 102)
-      const uint32_t step = item * (uint32_t)R + (uint32_t)s;
-      if (step >= nsteps) continue;  // (wave-uniform)
-      const uint32_t group0 = step * G;
-      if (lane < 2 * G) (&s_occ[wave][s][0][0])[lane] = 0xFFFFFFFFu;
-      uint2 rec[G];
-      uint32_t st[G];        // bit 0: still to be decided, bit 1: visible unless occluded, bit 2: was_visible, bit 3: passed frustum and cone
-      uint32_t mask_idx[G];
-      uint32_t fbit[G];
-      bool quick = false;
-#pragma unroll
-      for (int j = 0; j < G; j++) fbit[j] = 0u;
-      if constexpr (LATE) {
-        uint64_t any = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint64_t w = group0 + j < nwords ? gptr(a.camera_test_bits)[group0 + j] : 0ull;
-          any |= w;
-          fbit[j] = ((w >> lane) & 1ull) != 0ull ? 8u : 0u;
-        }
-        const uint2 info = load_global_u2(reinterpret_cast<uint64_t>(a.step_info), step);
-        quick = any == 0ull && info.y != 0u;
-        if (quick) {
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            st[j] = 0u;
-            mask_idx[j] = info.x + 64u * (uint32_t)j + (uint32_t)lane;
-            rec[j] = make_uint2(0u, 0u);
-          }
-        }
-      }
-      if (!quick) {
-#pragma unroll
-        for (int j = 0; j < G; j++) rec[j] = OXC_LOAD_MLI(mlis, min((group0 + j) * 64 + lane, last_index));
-      }
-      if (s == 0 && ticket) next_ticket = draw_ticket();  // in flight behind the record loads; read at the end of the item
-      if (!quick) {
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          st[j] = (((group0 + j) * 64 + lane < N) ? 1u : 0u) | fbit[j];
-          mask_idx[j] = 0;
-        }
-      }
-      for (;;) {
-        uint32_t mi_u = 0;
-        bool found = false;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint64_t p = __builtin_amdgcn_ballot_w64((st[j] & 1u) != 0u);
-          if (!found && p) {
-            mi_u = readlane_u(rec[j].x, __ffsll((unsigned long long)p) - 1);
-            found = true;
-          }
-        }
-        if (!found) break;
-        if (pending && mi_u != pend_mi) flush_all(pend_row);  // (wave-uniform) another instance: what waits is tested with ITS matrix
-        const kconst32p row = const_row(a.cache, mi_u);
-        const uint64_t bounds = (uint64_t)row[kRowBounds] | ((uint64_t)row[kRowBounds + 1] << 32);
-        const uint32_t vis_offset = row[kRowVisOffset];
-        uint4 bnd[G];
-        bool mine[G];
-        uint32_t mword[G];
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          mine[j] = (st[j] & 1u) != 0u && rec[j].x == mi_u;
-          const bool fetch = LATE ? (mine[j] && (st[j] & 8u) != 0u) : mine[j];
-          bnd[j] = OXC_LOAD_BND(bounds, fetch ? rec[j].y : 0u);
-          uint32_t mi_bit = vis_offset + (mine[j] ? rec[j].y : 0u);
-          const bool in_mask = mi_bit < a.mask_bits;
-          mi_bit = in_mask ? mi_bit : 0u;
-          mask_idx[j] = mine[j] ? (in_mask ? mi_bit : kMaskNone) : mask_idx[j];
-          mword[j] = load_global_u32(reinterpret_cast<uint64_t>(a.mask), mi_bit >> 5) >> (mi_bit & 31u);
-          mword[j] = in_mask ? mword[j] : 0u;
-        }
-        // ---- bounds decode + frustum (early call), or the early call's bits (late call)
-        if constexpr (LATE) {
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            const bool was_visible = (mword[j] & 1u) != 0u;
-            const bool vis = mine[j] & ((st[j] & 8u) != 0u);
-            st[j] = mine[j] ? ((vis ? 2u : 0u) | (was_visible ? 4u : 0u) | (st[j] & 8u)) : st[j];
-          }
-        } else {
-          float pl[24], sg[18];
-#pragma unroll
-          for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
-#pragma unroll
-          for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            const uint4 b = bnd[j];
-            const bool was_visible = (mword[j] & 1u) != 0u;
-            const float cx = dequantize_half(b.x & 0xFFFFu), cy = dequantize_half(b.x >> 16), cz = dequantize_half(b.y & 0xFFFFu);
-            const float ex = dequantize_half(b.z & 0xFFFFu), ey = dequantize_half(b.z >> 16), ez = dequantize_half(b.w & 0xFFFFu);
-            const bool inside = mine[j] & test_frustum_planes(pl, sg, cx, cy, cz, ex, ey, ez);
-            // every meshlet inside the frustum goes on to the cone test, whose result the late call reuses; bit 1 means "visible unless
-            // occluded" only after the scatter below
-            st[j] = mine[j] ? ((inside ? 2u : 0u) | (was_visible ? 4u : 0u)) : st[j];
-          }
-        }
-        // ---- normal cone on dense lanes (early call), then the candidates join the occlusion queue
-        uint64_t vb[G];
-        uint32_t base[G + 1];
-        base[0] = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          vb[j] = __builtin_amdgcn_ballot_w64(mine[j] && (st[j] & 2u) != 0u);
-          base[j + 1] = base[j] + (uint32_t)__popcll((unsigned long long)vb[j]);
-        }
-        const uint32_t total = base[G];
-        if (total) {
-          uint4* const at = strip + pending;  // this round's records: behind what already waits
-          uint32_t slot[G];
-#pragma unroll
-          for (int j = 0; j < G; j++) {
-            slot[j] = base[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(vb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vb[j], 0u));
-            if ((vb[j] >> lane) & 1ull) {
-              const uint32_t tag = ((uint32_t)s << 8) | ((uint32_t)j << 6) | (uint32_t)lane;
-              if constexpr (LATE) {  // passed frustum and cone in the early call: straight into the queue (the cone bytes make room for the tag)
-                at[slot[j]] = make_uint4(bnd[j].x, (bnd[j].y & 0xFFFFu) | (tag << 16), bnd[j].z, bnd[j].w);
-              } else {
-                at[slot[j]] = bnd[j];
-                flg[slot[j]] = (st[j] & 4u) | (tag << 8);  // was_visible and the tag travel beside the record through the cone batches
-              }
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
-          uint32_t nb = LATE ? total : 0u;  // occlusion candidates of this round: at[0, nb)
-          if constexpr (!LATE) {
-            ConeU cu;
-#pragma unroll
-            for (int k = 0; k < 9; k++) cu.nm[k] = asf(row[kRowNm + k]);
-#pragma unroll
-            for (int k = 0; k < 6; k++) cu.w2[k >> 1][k & 1] = asf(row[kRowWorld2 + k]);
-#pragma unroll
-            for (int k = 0; k < 2; k++) cu.wt2[k] = asf(row[kRowWorldT2 + k]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) cu.wr2[k] = asf(row[kRowWorldR2 + k]);
-            cu.scale_max = asf(row[kRowScale]);
-            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
-              const uint32_t t = t0 + (uint32_t)lane;
-              const bool act = t < total;
-              const uint4 b = at[act ? t : total - 1u];
-              const uint32_t fl = flg[act ? t : 0u];
-              bool ok = act;
-              const bool nc = act && ((int32_t)b.w >> 24) != 127;  // cutoff >= 1.0 <=> s8 == 127: cone test skipped (cull_meshlets.slang:52)
-              if (__builtin_amdgcn_ballot_w64(nc)) {
-                const float qx = dequantize_half(b.x & 0xFFFFu), qy = dequantize_half(b.x >> 16), qz = dequantize_half(b.y & 0xFFFFu);
-                const float rx = dequantize_half(b.z & 0xFFFFu), ry = dequantize_half(b.z >> 16), rz = dequantize_half(b.w & 0xFFFFu);
-                const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
-                const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
-                const int tier1 = cone_visible_fast(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
-                bool cone_ok = tier1 == 1;
-                if (__builtin_amdgcn_ballot_w64(nc && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-                  const bool exact = cone_visible(cu, camx, camy, camz, qx, qy, qz, rx, ry, rz, axy.x, axy.y, azc.x, azc.y);
-                  cone_ok = tier1 == 2 ? exact : cone_ok;
-                }
-                ok = nc ? cone_ok : ok;
-              }
-              // the occlusion test is for the meshlets that were visible last frame; flag bit 0 = passed frustum and cone (published for
-              // the late call), bit 1 = visible unless occluded
-              const bool okv = ok && (fl & 4u) != 0u;
-              const uint64_t okb = __builtin_amdgcn_ballot_w64(okv);
-              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(okb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okb, 0u));
-              if (act) flg[t] = (ok ? 1u : 0u) | (okv ? 2u : 0u);
-              // (nb + rank <= t, and every lane of this batch has read its record: the LDS queue of a wave is in order)
-              if (okv) at[nb + rank] = make_uint4(b.x, (b.y & 0xFFFFu) | ((fl >> 8) << 16), b.z, b.w);
-              nb += (uint32_t)__popcll((unsigned long long)okb);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < G; j++) {
-              if ((vb[j] >> lane) & 1ull) {
-                const uint32_t f = flg[slot[j]];
-                st[j] = (st[j] & ~2u) | (f & 2u) | ((f & 1u) << 3);
-              }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the flags are rewritten by the next round
-          }
-          pending += nb;
-          pend_mi = mi_u;
-          pend_row = row;
-          flush_full(row);
-        }
-#pragma unroll
-        for (int j = 0; j < G; j++) st[j] = mine[j] ? (st[j] & ~1u) : st[j];  // decided (as far as this kernel's lanes go)
-      }
-      // ---- end of the sub-step: what the late call needs of it (early call), the words the finish reads, and how it can be finished
-      bool step_run = false;
-      uint32_t d0 = 0;
-      if ((group0 + G) * 64u <= N) {  // (wave-uniform)
-        d0 = readfirst_u(mask_idx[0]);
-        uint64_t bad = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) bad |= __builtin_amdgcn_ballot_w64(mask_idx[j] != d0 + 64u * (uint32_t)j + (uint32_t)lane);  // (kMaskNone lanes differ)
-        step_run = bad == 0ull && d0 <= 0xFFFFFFFFu - 64u * G;
-      }
-      if constexpr (!LATE) {
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint64_t w = __builtin_amdgcn_ballot_w64((st[j] & 8u) != 0u);
-          if (lane == 0 && group0 + j < nwords) gptr(a.camera_test_bits)[group0 + j] = w;
-        }
-        if (lane == 0) {
-          uint32_t* info = reinterpret_cast<uint32_t*>(a.step_info + step);
-          gptr(info)[0] = d0;
-          gptr(info)[1] = step_run ? 1u : 0u;
-        }
-      }
-      if (step_run) {  // finished from the words, after the item's last flush
-        fast_mask |= 1u << s;
-        if (lane == 0) s_run0[wave][s] = d0;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          const uint64_t pre = __builtin_amdgcn_ballot_w64((st[j] & 2u) != 0u), was = __builtin_amdgcn_ballot_w64((st[j] & 4u) != 0u);
-          if (lane == 0) {
-            s_pre[wave][s][j][0] = (uint32_t)pre;
-            s_pre[wave][s][j][1] = (uint32_t)(pre >> 32);
-            s_was[wave][s][j][0] = (uint32_t)was;
-            s_was[wave][s][j][1] = (uint32_t)(was >> 32);
-          }
-        }
-      } else {  // scattered mask bits (or the list's ragged end): every candidate through its batch now, then the per-lane finish
-        if (pending) flush_all(pend_row);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          if (group0 + j >= nwords) continue;  // wave-uniform
-          const uint32_t occ = s_occ[wave][s][j][lane >> 5];
-          const bool visible = (st[j] & 2u) != 0u && ((occ >> (lane & 31)) & 1u) != 0u;
-          update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
-          const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
-          const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
-          if (lane == 0) gptr(a.bits)[group0 + j] = bits;
-          cnt += (uint32_t)__popcll((unsigned long long)bits);
-        }
-        if (lane == 0 && group0 < nwords) {
-          gptr(a.chunk_counts)[step] = cnt;
-          if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (step / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    // ---- the item's last flush, then the steps that wait for it: mask words, emit ballots, counts -- from the words
-    if (pending) flush_all(pend_row);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma nounroll
-    for (int s = 0; s < R; s++) {
-      if (((fast_mask >> s) & 1u) == 0u) continue;  // (wave-uniform)
-      const uint32_t step = item * (uint32_t)R + (uint32_t)s;
-      const uint32_t group0 = step * G;
-      uint32_t* row8 = flg;  // (free between rounds) the run's 2 G visibility dwords: lane k then picks dword k and dword k - 1
-      uint32_t cnt = 0;
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        const uint64_t pre = (uint64_t)s_pre[wave][s][j][0] | ((uint64_t)s_pre[wave][s][j][1] << 32);
-        const uint64_t occ = (uint64_t)s_occ[wave][s][j][0] | ((uint64_t)s_occ[wave][s][j][1] << 32);
-        const uint64_t was = (uint64_t)s_was[wave][s][j][0] | ((uint64_t)s_was[wave][s][j][1] << 32);
-        const uint64_t vis = pre & occ;
-        const uint64_t emit = LATE ? (vis & ~was) : vis;
-        if (lane == 0) {
-          row8[2 * j] = (uint32_t)vis;
-          row8[2 * j + 1] = (uint32_t)(vis >> 32);
-          gptr(a.bits)[group0 + j] = emit;
-        }
-        cnt += (uint32_t)__popcll((unsigned long long)emit);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
-      const uint32_t d0 = readfirst_u(s_run0[wave][s]);
-      const uint32_t cur = lane < 2 * G ? row8[lane] : 0u;
-      const uint32_t prev = (lane >= 1 && lane <= 2 * G) ? row8[lane - 1] : 0u;
-      const uint32_t sh = d0 & 31u, w0 = d0 >> 5;
-      if (sh == 0u) {
-        if (lane < 2 * G) a.mask[w0 + (uint32_t)lane] = cur;
-      } else {
-        const uint32_t word = __builtin_amdgcn_alignbit(cur, prev, 32u - sh);  // (cur << sh) | (prev >> (32 - sh))
-        if (lane >= 1 && lane < 2 * G) {
-          a.mask[w0 + (uint32_t)lane] = word;
-        } else if (lane == 0 || lane == 2 * G) {  // the run's first / last word: only its own bits
-          const uint32_t own = lane == 0 ? (0xFFFFFFFFu << sh) : (0xFFFFFFFFu >> (32u - sh));
-          const uint32_t zero = own & ~word;
-          if (zero) atomicAnd(&a.mask[w0 + (uint32_t)lane], ~zero);
-          if (word) atomicOr(&a.mask[w0 + (uint32_t)lane], word);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the flag row is rewritten by the next sub-step / item
-      if (lane == 0) {
-        gptr(a.chunk_counts)[step] = cnt;
-        if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (step / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    item = ticket ? item_of(readlane_u(next_ticket, 0)) : item + gridDim.x * kWaves;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // VSM multi-view meshlet test (passes/cull_meshlets_hpb.slang:25-99): directional cone +
 // camera frustum, then "visible if ANY dirty clipmap view passes frustum + page-pyramid test".
 // The reference's `break` on the first visible view has no side effect, so the result is the OR
@@ -2288,16 +1880,14 @@ template <bool LATE>
 #ifndef OXC_SHARED_LATE_WAVES
 #define OXC_SHARED_LATE_WAVES 5
 #endif
-#ifndef OXC_SHARED_EARLY_WAVES
-#define OXC_SHARED_EARLY_WAVES 5
-#endif
-__global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WAVES : OXC_SHARED_EARLY_WAVES) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
-#if OXC_SHARED_RUN > 0
-  static_assert(kHizGroupsPerWave == 4, "meshlets_run_body is written for four groups per wave");
-  meshlets_run_body<LATE, OXC_SHARED_RUN>(a);
-#else
+__global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WAVES : 5) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
+  // (Round 4 built the form in which a wave takes several consecutive steps and fills its 64-lane occlusion batches ACROSS them -- a tagged
+  // per-wave LDS queue, results as cleared bits in per-(step, group) words, steps finished from those words after the last flush; byte-
+  // identical on the share / fuzz / full-size tests -- and measured it: 135 / 124 us (2 steps per item, 5 waves per SIMD, 30 VGPRs
+  // spilled), 96 / 78 us at 4 waves per SIMD, 101 / 108 us with one step per item (the queue machinery alone), against 78 / 65 us for
+  // this kernel.  Fuller batches (the early call's run at 31 % of the lanes, the late call's at 66 %) do not pay for the deferred finish,
+  // the LDS words and a third inlined copy of the batch.  Removed: git log -S meshlets_run_body.)
   meshlets_hiz_body<true, LATE, (int)kHizGroupsPerWave, LATE ? 2 : 1>(a);
-#endif
 }
 template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
