@@ -435,7 +435,10 @@ oxc_status oxc_create(int device, oxc_ctx** out) {
     delete ctx;
     return OXC_OUT_OF_MEMORY;
   }
+  // (hipMemset runs on the NULL stream, which does not order against the non-blocking streams callers pass in: without the synchronisation a
+  // fill that starts late -- the first one of a process loads its kernel lazily -- lands on slots the first calls have already written)
   (void)hipMemset(ctx->slots, 0, (size_t)kSlots * SLOT_U32S * 4 + 256);
+  (void)hipDeviceSynchronize();
   ctx->sink = ctx->slots + (size_t)kSlots * SLOT_U32S;
   *out = ctx;
   return OXC_OK;
@@ -930,6 +933,10 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->batch_dev), sizeof(BatchElem) * kMaxBatch);
     if (e != hipSuccess) return fail(ctx, OXC_OUT_OF_MEMORY, "hipMalloc(batch argument block)", e);
     OXC_HIP(ctx, hipMemset(ctx->batch_dev, 0, sizeof(BatchElem) * kMaxBatch));  // fields no plain-pipeline block uses stay 0
+    // The fill runs on the NULL stream; `s` is usually a non-blocking stream, i.e. NOT ordered behind it.  Round 4 found the race the hard way:
+    // in a fresh process the first hipMemset loads its kernel lazily, k_prepare_batch (on `s`) wrote the argument blocks first, the late fill
+    // zeroed them and the next kernel dereferenced null -- "memory access fault on address (nil)" in 2 of ~25 bench runs, only on slow boxes.
+    OXC_HIP(ctx, hipDeviceSynchronize());
   }
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t max_grid = ctx->num_cus * 8;
