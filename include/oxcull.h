@@ -444,6 +444,10 @@ typedef struct oxc_mesh_build_desc {
   const float* normals;   /* glm::vec3[vertex_count], optional (NULL: positions only) */
   const uint32_t* indices;
 } oxc_mesh_build_desc;
+/* (LOD 0 of a mesh whose input has degenerate triangles: `indices` / `indices_count` keep them -- the reference passes the index buffer
+ * through unchanged -- while the meshlets are built from the non-degenerate ones, so indices_count / 3 can exceed the sum of the meshlets'
+ * triangle_count.  Nothing on the cull path reads `indices`; a consumer that draws from them gets the degenerate triangles back, which
+ * rasterise nothing.) */
 typedef struct oxc_mesh_lod_view { /* the arrays of one GPU::MeshLOD (SceneGPU.hpp:125-139), host memory */
   const uint32_t* indices;
   const void* meshlets; /* GPU::Meshlet[meshlet_count], 16 B each */
