@@ -187,6 +187,35 @@ OXC_DEV bool test_frustum_planes(const float* pl2, const float* sg2, float cx, f
   return inside;
 }
 
+// The three packed plane distances test_frustum_planes compares (d[p] = {plane 2p, plane 2p + 1}), without the comparison: views whose
+// planes have the SAME normals and signs -- the clipmap views of one light: row 3 of an orthographic matrix is (0, 0, 0, 1), the normalised
+// normals are those of rows 0..2 and do not change with the clipmap's power-of-two scale -- differ only in the thresholds -n[6], -n[7], so
+// the distances are computed once per box and compared once per view (k_cull_meshlets_hpb_test).  Same expressions, same roundings.
+OXC_DEV void frustum_plane_dots(const float* pl2, const float* sg2, float cx, float cy, float cz, float ex, float ey, float ez, f2* d /*3*/) {
+  const f2 hxy = f2{ex, ey} * splat(0.5f);
+  const float hz = ez * 0.5f;
+#pragma unroll
+  for (int p = 0; p < 3; p++) {
+    const float* n = pl2 + p * 8;
+    const float* sg = sg2 + p * 6;
+    const f2 qx = splat(cx) + splat(hxy.x) * f2{sg[0], sg[1]};
+    const f2 qy = splat(cy) + splat(hxy.y) * f2{sg[2], sg[3]};
+    const f2 qz = splat(cz) + splat(hz) * f2{sg[4], sg[5]};
+    d[p] = (qx * f2{n[0], n[1]} + qy * f2{n[2], n[3]}) + qz * f2{n[4], n[5]};
+  }
+}
+
+// One plane pair of test_frustum_planes (n8 = planes2[p], sg6 = signs2[p]): the same expressions, for callers that walk the pairs in a loop.
+OXC_DEV bool frustum_pair_inside(const float* n, const float* sg, float cx, float cy, float cz, float ex, float ey, float ez) {
+  const f2 hxy = f2{ex, ey} * splat(0.5f);
+  const float hz = ez * 0.5f;
+  const f2 qx = splat(cx) + splat(hxy.x) * f2{sg[0], sg[1]};
+  const f2 qy = splat(cy) + splat(hxy.y) * f2{sg[2], sg[3]};
+  const f2 qz = splat(cz) + splat(hz) * f2{sg[4], sg[5]};
+  const f2 d = (qx * f2{n[0], n[1]} + qy * f2{n[2], n[3]}) + qz * f2{n[4], n[5]};
+  return !(d.x <= -n[6]) & !(d.y <= -n[7]);
+}
+
 // scene.slang:292-299: cofactor matrix of world's upper 3x3, column-major 3x3 out.
 OXC_DEV void normal_matrix(const float* w, float* nm) {
   float b[3][3];

@@ -174,6 +174,31 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
 #pragma unroll
       for (int c = 0; c < 3; c++) out->signs2[sub >> 1][c][sub & 1u] = (asu(pl[c]) & 0x80000000u) ? -1.0f : 1.0f;
     }
+    // Clipmap rows (view >= 1): does this view's frustum have the plane NORMALS of clipmap 0's, bit for bit?  (The clipmaps of one light
+    // do: orthographic matrices that differ by a power-of-two scale and a translation -- the normalised normals are the same floats, only
+    // the plane distances differ.)  k_cull_meshlets_hpb_test then computes a box's six plane distances once and compares them per view.
+    // Plane `sub` of clipmap 0 is derived again here, with the same arithmetic, and compared; the flag takes the row's vis_offset slot
+    // (the visibility offset is a property of the instance: the kernels read it from the camera's row).
+    uint32_t same_normals = 0u;
+    if (view >= 1) {
+      bool same = true;
+      if (view >= 2) {
+        float mvp0[16], p0[3];
+        mul_mat4(a.clipmaps[0].projection_view_mat, w, mvp0);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          float r0 = OXC_M(mvp0, 0, c), r1 = OXC_M(mvp0, 1, c), r2 = OXC_M(mvp0, 2, c), r3 = OXC_M(mvp0, 3, c);
+          float rk = sel == 0 ? r0 : (sel == 1 ? r1 : r2);
+          float sum = r3 + (neg ? -rk : rk);
+          p0[c] = sub == 4 ? r2 : sum;
+        }
+        const float l0 = len3(p0[0], p0[1], p0[2]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) same = same && asu(p0[c] / l0) == asu(pl[c]);
+      }
+      const uint64_t diff = __ballot(sub < 6 && !same);
+      same_normals = ((diff >> (lane & ~7)) & 0x3Full) == 0ull ? 1u : 0u;
+    }
 
     // cull_meshes frustum test of the mesh AABB (cull_meshes.slang:34): lane k tests plane k
     bool outside = false;
@@ -210,7 +235,7 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       float sy = len3(OXC_M(w, 1, 0), OXC_M(w, 1, 1), OXC_M(w, 1, 2));
       float sz = len3(OXC_M(w, 2, 0), OXC_M(w, 2, 1), OXC_M(w, 2, 2));
       out->scale_max = fmaxf(sx, fmaxf(sy, sz));
-      out->vis_offset = inst.meshlet_instance_visibility_offset;
+      out->vis_offset = view >= 1 ? same_normals : inst.meshlet_instance_visibility_offset;
       out->transform_index = inst.transform_index;
       out->_pad0[0] = out->_pad0[1] = out->_pad0[2] = 0u;  // zero dwords: dummy index source for degenerate meshlets (tris_test_body)
 
@@ -1028,7 +1053,10 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 // over dirty views; views a whole wave no longer needs are skipped.  Output: ballots, expanded
 // by k_cull_meshlets_emit<false,false> like the plain meshlet stage.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 6) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
+#ifndef OXC_HPB_WAVES
+#define OXC_HPB_WAVES 6  // waves per SIMD (80 VGPRs, 7 spilled dwords): 338-341 us per 10 M meshlets x 10 views against 347-353 at 5 and 348 at 4
+#endif
+__global__ __launch_bounds__(256, OXC_HPB_WAVES) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   // Round 2: the view loop is the OUTER loop of a wave step.  Round 1 walked one 64-meshlet group at a time and, inside it, one
   // clipmap view at a time, so every (group, view) paid the scalar-load round trips of the view's plane / matrix row on its own --
   // 0.89 ms per 10 M meshlets, latency-bound.  Here a wave holds G groups (all loads batched, as in the plain kernel) and a view's
@@ -1044,12 +1072,14 @@ __global__ __launch_bounds__(256, 6) void k_cull_meshlets_hpb_test(HpbTestArgs a
   __shared__ uint4 s_strip[kWaves][G * 64];   // the candidates of a round (camera frustum + cone survivors), dense
   __shared__ uint32_t s_strip2[kWaves][G * 64];  // of those, the strip positions of the ones inside the current view's frustum: the page test's lanes
   __shared__ uint32_t s_seen[kWaves][G * 64];  // per candidate: some view's pages want it
+  __shared__ uint64_t s_in[kWaves][16][G];     // per view and 64-candidate batch: the candidates inside the view's frustum
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = min(a.vis[0], a.n_cap);
   const uint32_t nwords = (N + 63u) / 64u;
   const uint32_t nchunks = (N + kMeshletChunk - 1) / kMeshletChunk;
   if (threadIdx.x < 13) s_level_off[threadIdx.x] = a.hpb_level_off[threadIdx.x];
   __syncthreads();
+  const uint64_t dirty_mask = __builtin_amdgcn_ballot_w64((uint32_t)lane < a.clipmap_count && a.dirty[(uint32_t)lane < a.clipmap_count ? lane : 0] != 0u);
   HpbView hpb;
   hpb.data = a.hpb_data;
   hpb.width = a.hpb_w;
@@ -1160,26 +1190,97 @@ __global__ __launch_bounds__(256, 6) void k_cull_meshlets_hpb_test(HpbTestArgs a
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off: in order, no barrier needed
         uint32_t open_count = total;  // candidates no view has accepted yet (wave-uniform)
-        for (uint32_t v = 0; v < a.clipmap_count && open_count; v++) {
-          if (a.dirty[v] == 0u) continue;  // uniform
-          const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
-          uint32_t n_in = 0;  // lanes inside this view's frustum so far: strip2[0 .. n_in)
+        // ---- phase A (round 4): the frustum of EVERY dirty view over the candidates, two batches at a time.  A box's six plane distances
+        // are computed once, against clipmap 0's normals; a view whose row says "same normals" (prepare_body) only compares them with its
+        // own plane offsets (7 instructions instead of ~90 per batch and view), any other view runs the whole test.  One ballot per
+        // (view, batch) goes to LDS; the page test below picks its lanes from there.
+        {
+          const kconst32p rrow = const_row(a.view_cache, mi_u);
+          float rpl[24], rsg[18];
+#pragma unroll
+          for (int k = 0; k < 24; k++) rpl[k] = asf(rrow[kRowPlanes + k]);
+#pragma unroll
+          for (int k = 0; k < 18; k++) rsg[k] = asf(rrow[kRowSigns + k]);
+          // Lane v holds view v's six plane offsets and its "same normals" flag: one vector load round trip per instance round, the
+          // view loop below then reads them with v_readlane instead of paying a scalar-load round trip per (view, chunk).
+          float lw[6];
+          uint64_t same_mask;
           {
-            float vpl[24], vsg[18];
+            const uint32_t vl = (uint32_t)lane < a.clipmap_count ? (uint32_t)lane : 0u;
+            const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.view_cache + (size_t)vl * a.mesh_instance_count + mi_u);
 #pragma unroll
-            for (int k = 0; k < 24; k++) vpl[k] = asf(vrow[kRowPlanes + k]);
-#pragma unroll
-            for (int k = 0; k < 18; k++) vsg[k] = asf(vrow[kRowSigns + k]);
-            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
-              const uint32_t t = t0 + (uint32_t)lane;
-              const bool act = t < total && seen[t < total ? t : 0u] == 0u;
-              const uint4 b = strip[t < total ? t : total - 1u];
-              OXC_HPB_DECODE(b);
-              const bool in = act & test_frustum_planes(vpl, vsg, cxj, cyj, czj, exj, eyj, ezj);
-              const uint64_t ib = __builtin_amdgcn_ballot_w64(in);
-              if (in) strip2[n_in + __builtin_amdgcn_mbcnt_hi((uint32_t)(ib >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ib, 0u))] = t;
-              n_in += (uint32_t)__popcll((unsigned long long)ib);
+            for (int p = 0; p < 3; p++) {
+              lw[2 * p] = -asf(lrow[kRowPlanes + p * 8 + 6]);
+              lw[2 * p + 1] = -asf(lrow[kRowPlanes + p * 8 + 7]);
             }
+            same_mask = __builtin_amdgcn_ballot_w64((uint32_t)lane < a.clipmap_count && lrow[kRowVisOffset] != 0u);
+#ifdef OXC_HPB_FORCE_SAME  // experiment only: what the kernel costs when every view takes the shared-normals path
+            same_mask = ~0ull;
+#endif
+          }
+          for (uint32_t c0 = 0; c0 < total; c0 += 128) {
+            f2 dd[2][3];
+            uint4 bb[2];
+            bool actb[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const uint32_t t = c0 + 64u * (uint32_t)h + (uint32_t)lane;
+              actb[h] = t < total;
+              bb[h] = strip[actb[h] ? t : total - 1u];
+              OXC_HPB_DECODE(bb[h]);
+              frustum_plane_dots(rpl, rsg, cxj, cyj, czj, exj, eyj, ezj, dd[h]);
+            }
+            for (uint32_t v = 0; v < a.clipmap_count; v++) {
+              if (((dirty_mask >> v) & 1ull) == 0ull) continue;  // uniform
+              uint64_t ib[2];
+              if ((same_mask >> v) & 1ull) {  // (wave-uniform) same plane normals as clipmap 0: only the offsets are this view's
+                float nw[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) nw[k] = asf(__builtin_amdgcn_readlane((int)asu(lw[k]), (int)v));
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                  bool in = actb[h];
+#pragma unroll
+                  for (int p = 0; p < 3; p++) in = in & !(dd[h][p].x <= nw[2 * p]) & !(dd[h][p].y <= nw[2 * p + 1]);
+                  ib[h] = __builtin_amdgcn_ballot_w64(in);
+                }
+              } else {
+                // Any other view: its own frustum, one plane pair at a time (a rolled loop: the 14 scalars of a pair instead of the 42 of
+                // the row next to clipmap 0's 42 -- unrolled, this branch alone cost the kernel 57 SGPR spills and 10 % of its time).
+                const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
+                bool inh[2] = {actb[0], actb[1]};
+#pragma nounroll
+                for (int p = 0; p < 3; p++) {
+                  float n8[8], sg6[6];
+#pragma unroll
+                  for (int k = 0; k < 8; k++) n8[k] = asf(vrow[kRowPlanes + p * 8 + k]);
+#pragma unroll
+                  for (int k = 0; k < 6; k++) sg6[k] = asf(vrow[kRowSigns + p * 6 + k]);
+#pragma unroll
+                  for (int h = 0; h < 2; h++) {
+                    OXC_HPB_DECODE(bb[h]);
+                    inh[h] = inh[h] & frustum_pair_inside(n8, sg6, cxj, cyj, czj, exj, eyj, ezj);
+                  }
+                }
+                ib[0] = __builtin_amdgcn_ballot_w64(inh[0]);
+                ib[1] = __builtin_amdgcn_ballot_w64(inh[1]);
+              }
+              if (lane < 2) s_in[wave][v][(c0 >> 6) + (uint32_t)lane] = lane == 0 ? ib[0] : ib[1];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+        }
+        for (uint32_t v = 0; v < a.clipmap_count && open_count; v++) {
+          if (((dirty_mask >> v) & 1ull) == 0ull) continue;  // uniform
+          const kconst32p vrow = const_row(a.view_cache + (size_t)v * a.mesh_instance_count, mi_u);
+          uint32_t n_in = 0;  // lanes inside this view's frustum and not yet accepted by another view: strip2[0 .. n_in)
+          for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const uint64_t inb = s_in[wave][v][t0 >> 6];
+            const bool in = ((inb >> lane) & 1ull) != 0ull && seen[t < total ? t : 0u] == 0u;  // (a set bit implies t < total)
+            const uint64_t ib = __builtin_amdgcn_ballot_w64(in);
+            if (in) strip2[n_in + __builtin_amdgcn_mbcnt_hi((uint32_t)(ib >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ib, 0u))] = t;
+            n_in += (uint32_t)__popcll((unsigned long long)ib);
           }
           if (n_in == 0) continue;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
