@@ -456,10 +456,9 @@ OXC_DEV kconst32p const_row(const InstCache* cache, uint32_t mi) { return (kcons
 // test kernel 28.0 -> 27.4 us per 4M meshlets, whole job +2.5 %).
 #define OXC_LOAD_MLI load_stream_u2
 #define OXC_LOAD_BND load_stream_u4
-template <int G, bool UNORD = false>
+template <int G, bool UNORD = false, uint32_t kWaves = kPlainBlockWaves>
 OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
   set_half_denorm_flush();
-  constexpr uint32_t kWaves = kPlainBlockWaves;
   constexpr uint32_t kStep = kWaves * G * 64;  // meshlets per block iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
@@ -579,15 +578,12 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
       }
       if (lane == 0) s_cnt[par][wave] = cnt;
       __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kWaves; w++) total += s_cnt[par][w];
-        s_base[par] = total ? __hip_atomic_fetch_add(gptr(a.count_a), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      }
+      // every wave scans the block's wave counts itself (lane w holds wave w's): its own offset and the block total come out of one scan
+      const uint32_t incl = wave_incl_scan((uint32_t)lane < kWaves ? s_cnt[par][(uint32_t)lane < kWaves ? lane : 0] : 0u, lane);
+      const uint32_t total = readlane_u(incl, (int)kWaves - 1);
+      if (threadIdx.x == 0) s_base[par] = total ? __hip_atomic_fetch_add(gptr(a.count_a), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       __syncthreads();
-      uint32_t at = s_base[par];
-      for (int w = 0; w < wave; w++) at += s_cnt[par][w];
+      uint32_t at = s_base[par] + (wave ? readlane_u(incl, wave - 1) : 0u);
 #pragma unroll
       for (int j = 0; j < G; j++) {
         if ((bits[j] >> lane) & 1ull)
@@ -1970,9 +1966,9 @@ __global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_c
 }
 // unordered_output: the same bodies appending their survivors themselves (MeshletTestArgs::out)
 template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
-__global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_cull_meshlets_test_unordered(MeshletTestArgs a) {
+__global__ __launch_bounds__(HIZ ? 1024 / G : 64 * kUnordBlockWaves, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_cull_meshlets_test_unordered(MeshletTestArgs a) {
   if constexpr (!HIZ)
-    meshlets_plain_body<G, true>(a);
+    meshlets_plain_body<G, true, kUnordBlockWaves>(a);
   else
     meshlets_hiz_body<OCCL, LATE, G, 0, true>(a);
 }
@@ -2364,7 +2360,7 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
   if (hiz && grid_limit) grid = std::min(grid, grid_limit);
   if (a.out) {  // unordered_output: the appending instantiations
     if (!hiz) {
-      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<false, false, false>), dim3(grid * (4 / kPlainBlockWaves)), dim3(64 * kPlainBlockWaves), 0, s, a);
+      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<false, false, false>), dim3((grid * 4 + kUnordBlockWaves - 1) / kUnordBlockWaves), dim3(64 * kUnordBlockWaves), 0, s, a);
     } else if (occl && late) {
       static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, true, true, kHizGroups>, hb, num_cus);
       hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, true, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);

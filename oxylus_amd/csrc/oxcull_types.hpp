@@ -99,6 +99,13 @@ constexpr uint32_t kHizGroupsPerWave = OXC_HIZ_G;  // groups per wave of the HiZ
 #define OXC_PLAIN_BLOCK_WAVES 4
 #endif
 constexpr uint32_t kPlainBlockWaves = OXC_PLAIN_BLOCK_WAVES;  // the plain test kernel's waves are independent: block size is a scheduling knob
+#ifndef OXC_UNORD_BLOCK_WAVES
+#define OXC_UNORD_BLOCK_WAVES 4
+#endif
+// The appending plain test (unordered_output) spends ONE returning atomic on cull_triangles_cmd.x per block iteration: the block size is how
+// many meshlets share an atomic (64 * G per wave).  Measured on configs[1] as one call (1 M meshlets, 977 block atomics at 4 waves):
+// 17.9 us per call at 4 waves, 17.5 at 8, 17.8 at 16 -- the counter is not what the call waits for (its two launches' ramp and drain are).
+constexpr uint32_t kUnordBlockWaves = OXC_UNORD_BLOCK_WAVES;
 constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block iteration of the test kernel
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
