@@ -1507,6 +1507,15 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
   constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;    // a block takes whole spans, chunk after chunk
   static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
   constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
+#ifndef OXC_TRI_LDS_VERTS
+// The corners of a triangle: nine ds_bpermute (36 B of LDS crossbar traffic per lane and pass) or, with the slot's transformed vertices written to
+// LDS once, three 16-byte reads per pass (64 B).  T = 64 (one pass per slot): the reads lose outright, fused kernels 99 / 209 -> 112 / 266 us.  WIDE
+// (two passes per slot, kernel bound by instruction issue rather than LDS bandwidth): 137 / 265 -> 132.5 / 258 us; 12-byte reads with the z flags
+// kept as a ballot: 136.5 / 262.6.  1 = WIDE only (default), 2 = every instantiation, 0 = ds_bpermute everywhere.
+#define OXC_TRI_LDS_VERTS 1
+#endif
+  constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
+  __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];  // per wave: the transformed vertices of the slot in hand (same-wave LDS traffic is in order)
   __shared__ uint32_t f_off[FUSED ? kFSpan : 1];
   __shared__ uint64_t f_mask[FUSED ? kFSpan * H : 1];
   __shared__ uint32_t f_id[FUSED ? kFSpan : 1];
@@ -1605,6 +1614,7 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         scy = ((cly / clw) * 0.5f + 0.5f) * a.resolution[1];
         wok = __builtin_amdgcn_ballot_w64((uint32_t)lane < vertex_count && clw > 0.0f);
       }
+      if constexpr (kLdsVerts) s_vert[wave][lane] = make_uint4(asu(clx), asu(cly), asu(clw), ((uint32_t)lane < vertex_count && czw.x >= 0.0f) ? 1u : 0u);
       // triangle phase: lane = triangle (two passes of 64 when WIDE)
 #pragma unroll
       for (int h = 0; h < H; h++) {
@@ -1612,10 +1622,20 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
         const uint32_t tl = min(t, max(tri_count, 1u) - 1u);
         const uint32_t tri = __builtin_amdgcn_alignbyte(d1[j][h], d0[j][h], (s_tbase[j] + tl * 3u) & 3u);
         const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
-        const float ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
-        const float bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
-        const float cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
-        const bool z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
+        float ax, ay, aw, bx, by, bw, cx, cy, cw;
+        bool z_all;
+        if constexpr (kLdsVerts) {  // one 16-byte LDS read per corner: {x, y, w, z-ok} of the vertex the vertex phase left there
+          const uint4 A = s_vert[wave][l0 & 63], B = s_vert[wave][l1 & 63], C = s_vert[wave][l2 & 63];
+          z_all = (A.w & B.w & C.w) != 0u;
+          ax = asf(A.x), ay = asf(A.y), aw = asf(A.z);
+          bx = asf(B.x), by = asf(B.y), bw = asf(B.z);
+          cx = asf(C.x), cy = asf(C.y), cw = asf(C.z);
+        } else {
+          ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
+          bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
+          cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
+          z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
+        }
         // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
         const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
         bool passed = t < tri_count && z_all && !(det >= 0.0001f);
