@@ -1997,7 +1997,10 @@ template <bool LATE>
 #ifndef OXC_SHARED_LATE_WAVES
 #define OXC_SHARED_LATE_WAVES 5
 #endif
-__global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WAVES : 5) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
+#ifndef OXC_SHARED_EARLY_WAVES
+#define OXC_SHARED_EARLY_WAVES 5
+#endif
+__global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WAVES : OXC_SHARED_EARLY_WAVES) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
   // (Round 4 built the form in which a wave takes several consecutive steps and fills its 64-lane occlusion batches ACROSS them -- a tagged
   // per-wave LDS queue, results as cleared bits in per-(step, group) words, steps finished from those words after the last flush; byte-
   // identical on the share / fuzz / full-size tests -- and measured it: 135 / 124 us (2 steps per item, 5 waves per SIMD, 30 VGPRs
