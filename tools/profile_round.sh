@@ -45,6 +45,11 @@ python tools/summarize_profiles.py ${TAG}_tris124_trace --stats $(find gpurun_ou
   --note "bench.py --tris 124 (8M meshlets x 124 triangles, wide_triangle_index), --steps 3 --warmup 1; rocprofv3 --kernel-trace --stats"
 cp gpurun_out/raw/trace_t124/bench.json gpurun_out/profiles_out/${TAG}_tris124_trace_bench.json
 keep_raw tris124 gpurun_out/raw/trace_t124 /nonexistent
+./tools/profile_trace.sh gpurun_out/raw/trace_vsm --workload vsm > /dev/null
+python tools/summarize_profiles.py ${TAG}_vsm_trace --stats $(find gpurun_out/raw/trace_vsm -name t_kernel_stats.csv | head -1) \
+  --note "bench.py --workload vsm (10M meshlets x 10 dirty clipmap views, generate_hpb + cull_meshes + cull_meshlets_hpb); rocprofv3 --kernel-trace --stats"
+keep_raw vsm gpurun_out/raw/trace_vsm /nonexistent
+mv profiles/${TAG}_vsm_trace.json gpurun_out/profiles_out/ 2>/dev/null
 mv profiles/${TAG}_config2_pmc.json profiles/${TAG}_config3_pmc.json profiles/${TAG}_config5_pmc.json profiles/${TAG}_config3_ordered_trace.json profiles/${TAG}_tris124_trace.json gpurun_out/profiles_out/ 2>/dev/null
 rm -rf gpurun_out/raw
 ls -la gpurun_out/profiles_out gpurun_out/profiles_out/raw; du -sh gpurun_out/profiles_out
