@@ -2129,6 +2129,21 @@ __global__ __launch_bounds__(256) void k_mv_group(MvArgs a, MvBlob blob) {
       if (cnt != 0u && cu == cnt && tu == kt && (((uint64_t)hi << 32) | lo) == kb) same |= 1u << u;
     }
     const bool leader = cnt != 0u && (uint32_t)__builtin_ctz(same | 0x10000u) == v;
+    // Views of the group whose frustum plane NORMALS are the leader's, bit for bit (the cascades of one light: orthographic matrices that
+    // differ by scale and translation): k_mv_test computes a box's six plane distances once for all of them (frustum_plane_dots).  The
+    // signs derive from the same sign bits.  Bits 16..31 of the group's view_mask.
+    bool eq = cnt != 0u;
+    if (eq) {  // my row's first 96 bytes against the leader's (six 16-byte loads each; the leader's are the same lines for the whole group)
+      const uint32_t lead = (uint32_t)__builtin_ctz(same | 0x10000u) & 15u;
+      const uint4* mine = reinterpret_cast<const uint4*>(table[v].rows + mi);
+      const uint4* theirs = reinterpret_cast<const uint4*>(table[lead].rows + mi);
+#pragma unroll
+      for (int q = 0; q < 6; q++) {  // planes2[p][c][k] at dword p * 8 + c * 2 + k: the normals are c < 3, i.e. all of the even quads and .xy of the odd ones
+        const uint4 x = mine[q], y = theirs[q];
+        eq = eq && x.x == y.x && x.y == y.y && ((q & 1) || (x.z == y.z && x.w == y.w));
+      }
+    }
+    const uint32_t nsame = (uint32_t)(__ballot(eq) >> seg) & same & 0xFFFFu;
     const uint32_t leaders = (uint32_t)(__ballot(leader) >> seg) & 0xFFFFu;
     const uint32_t g = (uint32_t)__popc(leaders & ((1u << v) - 1u)), ngroups = (uint32_t)__popc(leaders);
     uint32_t chunks = leader ? (cnt + kMvChunk - 1) / kMvChunk : 0u;
@@ -2136,7 +2151,7 @@ __global__ __launch_bounds__(256) void k_mv_group(MvArgs a, MvBlob blob) {
     for (int o = 8; o > 0; o >>= 1) chunks += (uint32_t)__shfl_xor((int)chunks, o, 64);
     if (mi < a.M) {
       MvGroup* out = a.groups + (size_t)mi * a.views;
-      if (leader) out[g] = MvGroup{kb, cnt, same};
+      if (leader) out[g] = MvGroup{kb, cnt, same | (nsame << 16)};
       if (v >= ngroups && v < a.views) out[v] = MvGroup{0, 0, 0};
       if (v == 0) a.grp_chunks[mi] = chunks;
     }
@@ -2177,7 +2192,10 @@ __global__ __launch_bounds__(256) void k_mv_steps(MvArgs a) {
 // transform) is then evaluated once per meshlet and kept as a 64-bit lane mask per 64-meshlet group; otherwise once per view.
 template <bool SAME_POS>
 // (waves per SIMD, same camera position, 10 M meshlets x 16 views: 6 -> 141 us, 7 -> 138, 8 -> 130)
-__global__ __launch_bounds__(256, SAME_POS ? 8 : 4) void k_mv_test(MvArgs a) {
+#ifndef OXC_MV_WAVES
+#define OXC_MV_WAVES 6
+#endif
+__global__ __launch_bounds__(256, SAME_POS ? OXC_MV_WAVES : 4) void k_mv_test(MvArgs a) {
   set_half_denorm_flush();
   constexpr int G = 4;
   const int lane = threadIdx.x & 63;
@@ -2196,12 +2214,30 @@ __global__ __launch_bounds__(256, SAME_POS ? 8 : 4) void k_mv_test(MvArgs a) {
     const uint32_t mi = readfirst_u(sd.x), gi = readfirst_u(sd.y) & 0xFFu, c = readfirst_u(sd.y) >> 8;
     const kconst32p grp = (kconst32p)(reinterpret_cast<uint64_t>(a.groups + (size_t)mi * a.views + gi));
     const uint64_t bounds = (uint64_t)grp[0] | ((uint64_t)grp[1] << 32);
-    const uint32_t count = grp[2], vmask = grp[3];
+    const uint32_t count = grp[2], vmask = grp[3] & 0xFFFFu, nmask = grp[3] >> 16;  // nmask: views with the leader's plane normals (k_mv_group)
     const uint32_t k0 = c * kMvChunk;
     uint4 bnd[G];
 #pragma unroll
     for (int j = 0; j < G; j++) bnd[j] = load_stream_u4(bounds, min(k0 + (uint32_t)j * 64u + (uint32_t)lane, count - 1u));
-    float cx[G], cy[G], cz[G], ex[G], ey[G], ez[G];
+    // Lane v holds what is view v's own in this step -- the six plane offsets of its row, the chunk's number in the view's numbering, the list
+    // index of the chunk's first meshlet: one vector-load chain per step (table entry -> row / prefix arrays) instead of a scalar round trip
+    // per view inside the loop below.
+    float lw[6];
+    uint32_t lp, lid0;
+    {
+      const MvView* wl = a.dev + ((uint32_t)lane < a.views ? (uint32_t)lane : 0u);
+      const uint32_t* rl = reinterpret_cast<const uint32_t*>(wl->rows + mi);
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        lw[2 * p] = -asf(rl[kRowPlanes + p * 8 + 6]);
+        lw[2 * p + 1] = -asf(rl[kRowPlanes + p * 8 + 7]);
+      }
+      lp = wl->vchunk0[mi] + c;              // this chunk in the view's own numbering
+      lid0 = wl->mesh_offsets[mi] + k0;
+    }
+#define OXC_MV_DECODE(b)                                                                                                             \
+  const float cxj = dequantize_half((b).x & 0xFFFFu), cyj = dequantize_half((b).x >> 16), czj = dequantize_half((b).y & 0xFFFFu); \
+  const float exj = dequantize_half((b).z & 0xFFFFu), eyj = dequantize_half((b).z >> 16), ezj = dequantize_half((b).w & 0xFFFFu)
     uint64_t okb[G];  // lanes that exist and pass the cone test (per view when the views have different camera positions)
     auto cone_pass = [&](const kconst32p row, float camx, float camy, float camz) {
       ConeU cu;
@@ -2221,12 +2257,13 @@ __global__ __launch_bounds__(256, SAME_POS ? 8 : 4) void k_mv_test(MvArgs a) {
         const bool nc = valid && ((int32_t)b.w >> 24) != 127;  // cutoff >= 1.0 <=> s8 == 127: cone test skipped
         bool ok = valid;
         if (__builtin_amdgcn_ballot_w64(nc)) {  // wave-uniform
+          OXC_MV_DECODE(b);
           const f2 axy = s8_over_127_x2((int32_t)(b.y << 8) >> 24, (int32_t)b.y >> 24);
           const f2 azc = s8_over_127_x2((int32_t)(b.w << 8) >> 24, (int32_t)b.w >> 24);
-          const int tier1 = cone_visible_fast(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+          const int tier1 = cone_visible_fast(cu, camx, camy, camz, cxj, cyj, czj, exj, eyj, ezj, axy.x, axy.y, azc.x, azc.y);
           bool cone_ok = tier1 == 1;
           if (__builtin_amdgcn_ballot_w64(nc && tier1 == 2)) {  // some lane sits within the margin: the canonical IEEE path decides
-            const bool exact = cone_visible(cu, camx, camy, camz, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j], axy.x, axy.y, azc.x, azc.y);
+            const bool exact = cone_visible(cu, camx, camy, camz, cxj, cyj, czj, exj, eyj, ezj, axy.x, axy.y, azc.x, azc.y);
             cone_ok = tier1 == 2 ? exact : cone_ok;
           }
           ok = nc ? cone_ok : ok;
@@ -2234,43 +2271,80 @@ __global__ __launch_bounds__(256, SAME_POS ? 8 : 4) void k_mv_test(MvArgs a) {
         okb[j] = __builtin_amdgcn_ballot_w64(ok);
       }
     };
+    const MvView* w0 = a.dev + (uint32_t)__builtin_ctz(vmask);  // the group's leader
+    const kconst32p row0 = const_row(w0->rows, mi);
+    if (SAME_POS) cone_pass(row0, w0->cam_pos[0], w0->cam_pos[1], w0->cam_pos[2]);
+    // The six plane distances of every box against the leader's plane normals, once (frustum_plane_dots: the expressions of
+    // test_frustum_planes).  A view with the same normals -- nmask -- only compares them with its own offsets.
+    f2 dd[G][3];
+    {
+      float rpl[24], rsg[18];
 #pragma unroll
-    for (int j = 0; j < G; j++) {
-      const uint4 b = bnd[j];
-      cx[j] = dequantize_half(b.x & 0xFFFFu), cy[j] = dequantize_half(b.x >> 16), cz[j] = dequantize_half(b.y & 0xFFFFu);
-      ex[j] = dequantize_half(b.z & 0xFFFFu), ey[j] = dequantize_half(b.z >> 16), ez[j] = dequantize_half(b.w & 0xFFFFu);
-    }
-    if (SAME_POS) {
-      const MvView* w0 = a.dev + (uint32_t)__builtin_ctz(vmask);
-      cone_pass(const_row(w0->rows, mi), w0->cam_pos[0], w0->cam_pos[1], w0->cam_pos[2]);
-    }
-    for (uint32_t m = vmask; m; m &= m - 1u) {
-      const uint32_t v = (uint32_t)__builtin_ctz(m);
-      const MvView* w = a.dev + v;
-      const kconst32p row = const_row(w->rows, mi);
-      if (!SAME_POS) cone_pass(row, w->cam_pos[0], w->cam_pos[1], w->cam_pos[2]);
-      const uint32_t p = gptr(w->vchunk0)[mi] + c;  // this chunk in the view's own numbering
-      const uint32_t id0 = gptr(w->mesh_offsets)[mi] + k0;
-      float pl[24], sg[18];
+      for (int k = 0; k < 24; k++) rpl[k] = asf(row0[kRowPlanes + k]);
 #pragma unroll
-      for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
-#pragma unroll
-      for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
-      uint32_t cnt = 0;
-      uint64_t bits[G];
+      for (int k = 0; k < 18; k++) rsg[k] = asf(row0[kRowSigns + k]);
 #pragma unroll
       for (int j = 0; j < G; j++) {
-        bits[j] = __builtin_amdgcn_ballot_w64(test_frustum_planes(pl, sg, cx[j], cy[j], cz[j], ex[j], ey[j], ez[j])) & okb[j];
+        OXC_MV_DECODE(bnd[j]);
+        frustum_plane_dots(rpl, rsg, cxj, cyj, czj, exj, eyj, ezj, dd[j]);
+      }
+    }
+    uint32_t blo = 0, bhi = 0;  // lane v * G + j: ballot j of view v
+    uint32_t cnts = 0;          // lane v: survivors of view v in this chunk
+    for (uint32_t m = vmask; m; m &= m - 1u) {
+      const uint32_t v = (uint32_t)__builtin_ctz(m);
+      uint64_t bits[G];
+      if (SAME_POS && ((nmask >> v) & 1u)) {  // (wave-uniform)
+        float nw[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) nw[k] = asf(readlane_u(asu(lw[k]), (int)v));
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          bool in = true;
+#pragma unroll
+          for (int p = 0; p < 3; p++) in = in & !(dd[j][p].x <= nw[2 * p]) & !(dd[j][p].y <= nw[2 * p + 1]);
+          bits[j] = __builtin_amdgcn_ballot_w64(in) & okb[j];
+        }
+      } else {
+        const MvView* w = a.dev + v;
+        const kconst32p row = const_row(w->rows, mi);
+        if (!SAME_POS) cone_pass(row, w->cam_pos[0], w->cam_pos[1], w->cam_pos[2]);
+        float pl[24], sg[18];
+#pragma unroll
+        for (int k = 0; k < 24; k++) pl[k] = asf(row[kRowPlanes + k]);
+#pragma unroll
+        for (int k = 0; k < 18; k++) sg[k] = asf(row[kRowSigns + k]);
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          // (SAME_POS: the records are fetched again here -- L2 hits, a rare path -- instead of being held across the view loop for its sake:
+          // 16 VGPRs that decide between 4 and 5 waves per SIMD)
+          const uint4 bj = SAME_POS ? load_global_u4(bounds, min(k0 + (uint32_t)j * 64u + (uint32_t)lane, count - 1u)) : bnd[j];
+          OXC_MV_DECODE(bj);
+          bits[j] = __builtin_amdgcn_ballot_w64(test_frustum_planes(pl, sg, cxj, cyj, czj, exj, eyj, ezj)) & okb[j];
+        }
+      }
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
         cnt += (uint32_t)__popcll((unsigned long long)bits[j]);
+        const bool here = (uint32_t)lane == v * (uint32_t)G + (uint32_t)j;  // (a select, not v_writelane: its lane index would have to travel in m0)
+        blo = here ? (uint32_t)bits[j] : blo;
+        bhi = here ? (uint32_t)(bits[j] >> 32) : bhi;
       }
-      if (lane < G) {  // lane j stores ballot j: one 32-byte run
-        const uint64_t mine = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
-        gptr(w->bits)[(size_t)p * G + lane] = mine;
-      }
-      if (lane == 0) {
-        gptr(w->counts)[p] = cnt;
-        gptr(w->idbase)[p] = id0;
-        if (cnt) __hip_atomic_fetch_add(gptr(w->supers) + (p / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cnts = (uint32_t)lane == v ? cnt : cnts;
+    }
+#undef OXC_MV_DECODE
+    // ---- results: lane v * G + j stores ballot j of view v (its view's 32-byte run), lane v the view's count / id base
+    {
+      static_assert(G == 4 && kMaxBatch == 16, "one ballot word per lane");
+      const uint32_t vv = (uint32_t)lane >> 2, jj = (uint32_t)lane & 3u;
+      const uint32_t pv = (uint32_t)__shfl((int)lp, (int)vv, 64);
+      if ((vmask >> vv) & 1u) gptr(a.dev[vv].bits)[(size_t)pv * G + jj] = (uint64_t)blo | ((uint64_t)bhi << 32);
+      if ((uint32_t)lane < 16u && ((vmask >> lane) & 1u)) {
+        const MvView* w = a.dev + lane;
+        gptr(w->counts)[lp] = cnts;
+        gptr(w->idbase)[lp] = lid0;
+        if (cnts) __hip_atomic_fetch_add(gptr(w->supers) + (lp / kChunksPerSuper) * kSuperStride, cnts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     step = OXC_TICKET_STEP(readlane_u(next_ticket, 0), K, kx);

@@ -199,8 +199,9 @@ def test_config5_full_size_properties(renderer, oracle_lib):
         assert torch.equal(frame.visible_meshlet_instances_indices_buffer[:c.cull_triangles_cmd_x].cpu(), got[v]["visible"])
 
 
-@pytest.mark.parametrize("views,move_cameras,cap_frac", [(2, False, 1.0), (5, True, 1.0), (16, True, 1.0), (7, False, 0.4)],
-                         ids=["2-views", "5-views-own-positions", "16-views-own-positions", "7-views-short-lists"])
+@pytest.mark.parametrize("views,move_cameras,cap_frac", [(2, False, 1.0), (5, True, 1.0), (16, True, 1.0), (7, False, 0.4), (6, "rotate", 1.0), (9, "mixed", 1.0)],
+                         ids=["2-views", "5-views-own-positions", "16-views-own-positions", "7-views-short-lists", "6-views-one-position-own-orientations",
+                              "9-views-one-position-cascades-and-others"])
 def test_multiview_batch_equals_single_calls(renderer, oracle_lib, views, move_cameras, cap_frac):
     """The batched views of one scene take the one-pass multi-view meshlet stage; every element's outputs -- the LOD-selected
     MeshletInstance list, the visible list, the counters -- must equal what a single oxc_cull_geometry call of that view writes.  Own camera
@@ -211,7 +212,21 @@ def test_multiview_batch_equals_single_calls(renderer, oracle_lib, views, move_c
     gpu = make_scene(SceneSpec(n_mesh_instances=700, meshlets_per_mesh=150, lod_count=3, seed=0x0A1DE5 + 9, with_geometry=False), "cuda")
     flags = L.CULL_TEST_FRUSTUM | L.CULL_SELECT_LOD
     cams = _cascade_cameras(gpu, views)
-    if move_cameras:
+    if move_cameras in ("rotate", "mixed"):
+        # One camera position, plane normals that are NOT the leader's (round 4: the kernel shares a box's plane distances between the views whose
+        # normals are, k_mv_group's mask; the others take their own frustum test inside the same step): perspective views turned about the y axis
+        # ("mixed": every third view; the rest stay cascades of the one light).
+        base = np.array(gpu.cull_camera().projection_view, dtype=np.float64).reshape(4, 4).T  # column-major -> matrix
+        for v, cam in enumerate(cams):
+            if move_cameras == "mixed" and v % 3 != 1:
+                continue
+            t = 0.35 * (v + 1)
+            rot = np.array([[np.cos(t), 0, np.sin(t), 0], [0, 1, 0, 0], [-np.sin(t), 0, np.cos(t), 0], [0, 0, 0, 1]])
+            m = (base @ rot).T.reshape(-1).astype(np.float32)
+            for k in range(16):
+                cam.projection_view[k] = float(m[k])
+            cam.near_clip = gpu.cull_camera().near_clip
+    elif move_cameras:
         for v, cam in enumerate(cams):
             cam.position[0], cam.position[1], cam.position[2] = 3.0 * v, -2.0 * v, -60.0 + 11.0 * v
         for k in range(16):  # the last view looks away from everything: no instance survives its cull_meshes
