@@ -2369,7 +2369,15 @@ __global__ __launch_bounds__(256) void k_mv_emit(MvArgs a) {
     // exclusive base of the span: all supers before its super + the chunk counts inside it
     const uint32_t c0 = span * 16u, sup = c0 / kChunksPerSuper;
     uint32_t acc = 0;
-    for (uint32_t i = (uint32_t)lane; i < sup; i += 64u) acc += gptr(w.supers)[i * kSuperStride];
+    // (eight loads in flight per lane: a view of 10 M meshlets has 610 super-chunks; measured on configs[4]: no change, the kernel streams its
+    // 156 MB of ids at the 3.5 TB/s default-policy stores reach)
+    for (uint32_t i0 = (uint32_t)lane; i0 < sup; i0 += 512u) {
+      uint32_t part[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; u++) part[u] = gptr(w.supers)[min(i0 + 64u * u, sup - 1u) * kSuperStride];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; u++) acc += i0 + 64u * u < sup ? part[u] : 0u;
+    }
     const uint32_t j = sup * kChunksPerSuper + (uint32_t)lane;
     if (j < c0) acc += gptr(w.counts)[j];
     const uint32_t base = wave_sum(acc);
@@ -2380,6 +2388,8 @@ __global__ __launch_bounds__(256) void k_mv_emit(MvArgs a) {
     if (lane == 63 && span == nspans - 1u) gptr(w.tri_cmd)[0] = base + incl;  // cull_triangles_cmd.x
     const uint32_t blo = (uint32_t)bits, bhi = (uint32_t)(bits >> 32);
     const uint64_t below = (1ull << lane) - 1ull;
+    // (Staging the span's ids in an LDS run and writing 16-byte stores, as expand_slots_wide does for the index list: 44 -> 115 us with either store
+    // policy -- the second pass over the 64 words and the LDS hand-offs cost more than the 64 short stores.)
 #pragma unroll 4
     for (int k = 0; k < 64; k++) {
       const uint64_t bk = (uint64_t)readlane_u(blo, k) | ((uint64_t)readlane_u(bhi, k) << 32);
