@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final validation of the tree: full GPU suite, default bench line, the N = 2 control flow on one GPU (gloo debug backend), profiles.
+# tools/validate_round.sh -- on the GPU box (gpurun -- bash tools/validate_round.sh): validation of the tree: full GPU suite, default bench line, the N = 2 control flow on one GPU (gloo debug backend), profiles.
 mkdir -p gpurun_out
 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|rror" | tail -5 > gpurun_out/final_pytest.txt; cat gpurun_out/final_pytest.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
