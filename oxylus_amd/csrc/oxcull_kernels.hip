@@ -1210,9 +1210,6 @@ __global__ __launch_bounds__(256, OXC_HPB_WAVES) void k_cull_meshlets_hpb_test(H
               lw[2 * p + 1] = -asf(lrow[kRowPlanes + p * 8 + 7]);
             }
             same_mask = __builtin_amdgcn_ballot_w64((uint32_t)lane < a.clipmap_count && lrow[kRowVisOffset] != 0u);
-#ifdef OXC_HPB_FORCE_SAME  // experiment only: what the kernel costs when every view takes the shared-normals path
-            same_mask = ~0ull;
-#endif
           }
           for (uint32_t c0 = 0; c0 < total; c0 += 128) {
             f2 dd[2][3];
