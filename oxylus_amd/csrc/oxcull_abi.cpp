@@ -390,8 +390,9 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
   if (c->use_hpb && do_meshlets) {
     if (c->use_hiz) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hiz and use_hpb are exclusive (CullGeometry.cpp:129,199)");
     if (views == 0 || views > 16) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: vsm_clipmap_count must be 1..16");
-    if (!c->vsm_clipmaps_buffer.dptr || c->vsm_clipmaps_buffer.bytes < (uint64_t)views * sizeof(oxc_virtual_clipmap) || !c->vsm_clipmap_dirty_flags_buffer.dptr)
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb needs vsm_clipmaps_buffer / vsm_clipmap_dirty_flags_buffer");
+    if (!c->vsm_clipmaps_buffer.dptr || c->vsm_clipmaps_buffer.bytes < (uint64_t)views * sizeof(oxc_virtual_clipmap) || !c->vsm_clipmap_dirty_flags_buffer.dptr ||
+        c->vsm_clipmap_dirty_flags_buffer.bytes < (uint64_t)views * 4u)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb needs vsm_clipmaps_buffer (76 B per clipmap) / vsm_clipmap_dirty_flags_buffer (4 B per clipmap)");
     const oxc_image_array_u8& h = c->hpb_attachment;
     if (!h.dptr || !h.width || !h.height || h.layers < views || h.levels < 1 || h.levels > 13)
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb without a valid hpb_attachment (layers >= clipmaps, 1..13 levels)");
@@ -1599,6 +1600,8 @@ oxc_status oxc_comm_destroy(oxc_ctx* ctx) {
 oxc_status oxc_pack_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, void* counts4_dptr, void* hip_stream) {
   if (!ctx) return OXC_INVALID_ARG;
   if (!c || c->struct_size != sizeof(oxc_cull_geometry_context) || !counts4_dptr) return fail(ctx, OXC_INVALID_ARG, "pack_counters: bad context struct or null output");
+  if (!c->visibility_buffer.dptr || !c->cull_triangles_cmd_buffer.dptr || !c->draw_geometry_cmd_buffer.dptr)
+    return fail(ctx, OXC_INVALID_ARG, "pack_counters: the context has no counter buffers yet (no cull_geometry call has filled them in)");
   OXC_HIP(ctx, hipSetDevice(ctx->device));
   OXC_ORDER(ctx, hip_stream);
   OXC_JOIN(ctx, hip_stream);
@@ -1616,6 +1619,8 @@ oxc_status oxc_pack_counters_batch(oxc_ctx* ctx, uint32_t count, const oxc_cull_
   b.count = count;
   for (uint32_t e = 0; e < count; e++) {
     if (cs[e].struct_size != sizeof(oxc_cull_geometry_context)) return fail(ctx, OXC_INVALID_ARG, "pack_counters_batch: bad context struct");
+    if (!cs[e].visibility_buffer.dptr || !cs[e].cull_triangles_cmd_buffer.dptr || !cs[e].draw_geometry_cmd_buffer.dptr)
+      return fail(ctx, OXC_INVALID_ARG, "pack_counters_batch: a context has no counter buffers yet (no cull_geometry call has filled them in)");
     b.vis[e] = static_cast<const uint32_t*>(cs[e].visibility_buffer.dptr);
     b.tri_cmd[e] = static_cast<const uint32_t*>(cs[e].cull_triangles_cmd_buffer.dptr);
     b.draw_cmd[e] = static_cast<const uint32_t*>(cs[e].draw_geometry_cmd_buffer.dptr);

@@ -529,3 +529,18 @@ def test_pack_counters_equals_read_counters(renderer, oracle_lib):
     c = renderer.read_counters(ctx)
     assert packed.cpu().tolist() == [c.cull_triangles_cmd_x, c.early_visible_meshlet_instances, c.late_visible_meshlet_instances, c.draw_index_count]
     assert c.cull_triangles_cmd_x > 0 and c.draw_index_count > 0
+
+
+def test_pack_counters_of_a_context_without_counter_buffers_is_refused(renderer, oracle_lib):
+    """oxc_pack_counters / oxc_pack_counters_batch launch a kernel that reads the context's counter buffers: a context no cull_geometry call has
+    filled in yet (null buffers) is an argument error, not a fault on the device."""
+    gpu = make_scene(SceneSpec(n_mesh_instances=4, meshlets_per_mesh=8, seed=3), "cuda")
+    renderer.prepared_frame = PreparedFrame.create(gpu)
+    ctx = CullGeometryContext(init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM, cull_camera=gpu.cull_camera())
+    packed = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ctx.c()  # (a well-formed struct: what is refused is the missing buffers)
+    with pytest.raises(L.OxcError) as ei:
+        renderer.pack_counters(ctx, packed)
+    assert ei.value.status == L.OXC_INVALID_ARG and "counter buffers" in str(ei.value)
+    renderer.cull_geometry(ctx)
+    renderer.pack_counters(ctx, packed)  # (filled in now)
