@@ -436,6 +436,32 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
             one()  # back to the main form for the kernel profile
         torch.cuda.synchronize()
 
+    # ---- the same step replayed from a HIP graph (N = 1): its eight dependent launches back to back, no host in between ----
+    graph_variant = None
+    if world == 1:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                one()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for _ in range(steps):
+                    g.replay()
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - t0
+            pvg, listsg = read_lists(groups)
+            graph_variant = {"ms_per_step": round(dtg / steps * 1e3, 6), "steps": steps,
+                             "outputs_match_main_line": bool(pvg == per_view and all(torch.equal(a[1], b[1]) for a, b in zip(listsg, got_lists)))}
+            del g
+        except Exception as ex:  # a runtime that cannot capture the batched call: the eager line stands
+            graph_variant = {"error": str(ex)[:200]}
+            torch.cuda.synchronize()
+
     # ---- per-kernel times (HIP-event pair per launch) and rooflines ----
     n_prof = 30
     r.profile_begin()
@@ -528,7 +554,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
                    "counts_all_gather_bytes_per_rank_per_step": (16 * min(vb, views) * len(groups)) if world > 1 else 0,
                    "per_view_processed": [t for t, _ in per_view], "per_view_visible": [v for _, v in per_view]},
         "bit_match": bit_match, "bit_match_sample": f"per-view list lengths and visible counts of all {views} views; the visible lists of views {[v for v, _ in got_lists][:1]}..{[v for v, _ in got_lists][-1:]} byte for byte",
-        "explicit_lists_variant": variant, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
+        "explicit_lists_variant": variant, "hip_graph_replay_variant": graph_variant, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
     if nested:
         del base, lanes
         torch.cuda.empty_cache()
