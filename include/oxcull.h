@@ -595,7 +595,8 @@ uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
  * big-triangle / clip queues (default 2^22); only before the context's first draw, which allocates them -- the tests shrink it to reach
  * the overflow paths with a small scene. */
 enum { OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU = 0, OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU = 1, OXC_TUNE_RASTER_BIG_CAPACITY = 2,
-       OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */ };
+       OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */,
+       OXC_TUNE_FUSED_SELECT = 4 /* 0: the HiZ meshlet stage keeps its emit launch in front of the fused triangle kernel (default 1: the fused kernel finds its ids itself) */ };
 oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value);
 
 /* Test hook: what the last oxc_draw_visbuffer on this context did with its triangles; synchronises the stream.

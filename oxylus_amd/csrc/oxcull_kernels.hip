@@ -1403,7 +1403,26 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 #define OXC_EMIT_WIDE_NT 1
 #endif
 constexpr uint32_t kEmitRun = OXC_EMIT_RUN;  // dwords a wave stages between flushes (>= 384 + 3: one WIDE slot)
-template <int H, uint32_t kCornerBits>
+#ifndef OXC_FUSED_RUN
+#define OXC_FUSED_RUN 768
+#endif
+// ... and in the fused triangle kernel of round 5 (FMODE 2 / 3), whose block also holds the prefix of the meshlet stage's sums: 8 blocks per CU
+// have 20 KB of LDS each.  (Run length 512 / 1024 / 2048 dwords measured in round 4: 549 / 548 / 544 us per frame.)
+constexpr uint32_t kFusedRun = OXC_FUSED_RUN;
+#ifndef OXC_FUSED_TICKETS
+#define OXC_FUSED_TICKETS 1  // the round-4 structure with the spans after a block's first drawn from TriTestArgs::ticket at the span's end (beside the index_count atomic)
+#endif
+#ifndef OXC_FUSED_STATIC_ROUNDS
+#define OXC_FUSED_STATIC_ROUNDS 2  // spans a block takes by its index before it draws tickets (>= 1)
+#endif
+#ifndef OXC_FUSED_OVERLAP
+// What of the next span's fetch chain (ids -> MeshletInstance -> row -> Meshlet record -> indices -> positions) is in flight while the
+// block expands the current span: 0 = nothing, 1 = the MeshletInstance records (two VGPRs held).
+#define OXC_FUSED_OVERLAP 1
+#endif
+static_assert(kFusedRun >= 384u + 3u && kFusedRun % 4u == 0u, "a run holds at least one WIDE slot; rows stay 16-byte aligned");
+constexpr uint32_t kSelectMaxSupers = 1024;  // FMODE 3: per-64-step sums a block can scan (4 per thread): 2^24 meshlet instances
+template <int H, uint32_t kCornerBits, uint32_t kRunLen = kEmitRun>
 OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int first_slot, int nslots, uint32_t g0, uint32_t* __restrict__ out, uint32_t* run, int lane) {
   typedef uint32_t u4v __attribute__((ext_vector_type(4)));
   constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
@@ -1441,7 +1460,7 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
     }
     const uint32_t n3 = cnt * 3u;
     if (n3 == 0u) continue;                      // (wave-uniform)
-    if (filled + n3 > kEmitRun) flush();         // (wave-uniform; same wave, in-order LDS: the flush has read the run before it is rewritten)
+    if (filled + n3 > kRunLen) flush();         // (wave-uniform; same wave, in-order LDS: the flush has read the run before it is rewritten)
     uint32_t* at = run + pad + filled;
     uint32_t before = 0;
 #pragma unroll
@@ -1459,6 +1478,135 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
     filled += n3;
   }
   if (filled) flush();
+}
+
+// ------------------------------------------------------------------------------------------
+// The "select" form of the fused triangle kernel (round 5): the id at position `slot` of the (ascending) visible list, found from what the HiZ
+// meshlet test left -- per 64 candidates a ballot word, per 64 wave steps (16 384 candidates) their survivor sum (prefix P in LDS) -- i.e. what
+// k_cull_meshlets_emit computes for every position, computed for the 64 consecutive positions of a wave.  Called by whole waves (every lane
+// with a valid slot < P[last]); scratch: 64 + 512 words of LDS owned by the wave, 16-byte aligned.
+//   super S: the last one with P[S] <= slot (empty supers are skipped by the search);  step: first c of S whose inclusive count > r;
+//   word j of the step's four and the n-th set bit of it by popcount narrowing.
+// ------------------------------------------------------------------------------------------
+OXC_DEV uint32_t select_visible_id(const uint64_t* __restrict__ bits, const uint32_t* P, uint32_t nwords, uint32_t slot, uint32_t* scratch, int lane) {
+  static_assert(kHizGroupsPerWave == 4, "four ballot words (256 candidates) per counted step");
+  uint32_t lo = 0, hi = kSelectMaxSupers;  // P[hi] > slot (P[kSelectMaxSupers] = V)
+#pragma unroll
+  for (int it = 0; it < 10; it++) {  // 2^10 = kSelectMaxSupers
+    const uint32_t mid = (lo + hi) >> 1;
+    const bool le = P[mid] <= slot;
+    lo = le ? mid : lo;
+    hi = le ? hi : mid;
+  }
+  const uint32_t S = lo;
+  const uint32_t r = slot - P[S];
+  // One round per distinct super among the wave's 64 positions (usually one, rarely more than two): lane k loads the four ballot words of
+  // step k of the super -- 2 KB per wave, one hop; the per-step counts the meshlet test also left are their popcounts -- the wave scans the
+  // counts, every lane finds its step in the scan and takes that step's four words out of the wave's LDS scratch.
+  uint32_t* const incl64 = scratch;                                   // [64]
+  uint4* const words = reinterpret_cast<uint4*>(scratch + 64);         // [64][2]: 16-byte aligned (the scratch row is)
+  uint32_t word0 = 0, rr = 0;
+  uint4 w01 = make_uint4(0u, 0u, 0u, 0u), w23 = w01;
+  uint64_t todo = ~0ull;
+  while (todo) {
+    const uint32_t Su = readlane_u(S, __ffsll((unsigned long long)todo) - 1);
+    const uint32_t wi = (Su * kChunksPerSuper + (uint32_t)lane) * 4u;  // first ballot word of this lane's step
+    const uint32_t last = nwords - 1u;
+    uint4 a01 = load_global_u4(reinterpret_cast<uint64_t>(bits), min(wi, last & ~3u) >> 1);
+    uint4 a23 = load_global_u4(reinterpret_cast<uint64_t>(bits), (min(wi, last & ~3u) >> 1) + 1u);
+    // words at or beyond nwords were not written by this call's test kernel (stale): they count nothing
+    if (wi + 0u > last) a01.x = a01.y = 0u;
+    if (wi + 1u > last) a01.z = a01.w = 0u;
+    if (wi + 2u > last) a23.x = a23.y = 0u;
+    if (wi + 3u > last) a23.z = a23.w = 0u;
+    const uint32_t c = (uint32_t)__popc(a01.x) + (uint32_t)__popc(a01.y) + (uint32_t)__popc(a01.z) + (uint32_t)__popc(a01.w) + (uint32_t)__popc(a23.x) +
+                       (uint32_t)__popc(a23.y) + (uint32_t)__popc(a23.z) + (uint32_t)__popc(a23.w);
+    const uint32_t incl = wave_incl_scan(c, lane);
+    incl64[lane] = incl;
+    words[lane * 2 + 0] = a01;
+    words[lane * 2 + 1] = a23;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
+    const bool mine = S == Su;
+    uint32_t a0 = 0, b0 = 63;  // first index whose inclusive count exceeds r (exists: r < the super's sum)
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+      const uint32_t mid = (a0 + b0) >> 1;
+      const bool gt = incl64[mid] > r;
+      b0 = gt ? mid : b0;
+      a0 = gt ? a0 : min(mid + 1u, 63u);
+    }
+    const uint32_t before = a0 ? incl64[a0 - 1u] : 0u;
+    const uint4 m01 = words[a0 * 2 + 0], m23 = words[a0 * 2 + 1];
+    if (mine) {
+      word0 = (Su * kChunksPerSuper + a0) * 4u;
+      rr = r - before;
+      w01 = m01;
+      w23 = m23;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are rewritten by the next round
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
+  const uint64_t w0 = (uint64_t)w01.x | ((uint64_t)w01.y << 32), w1 = (uint64_t)w01.z | ((uint64_t)w01.w << 32);
+  const uint64_t w2 = (uint64_t)w23.x | ((uint64_t)w23.y << 32), w3 = (uint64_t)w23.z | ((uint64_t)w23.w << 32);
+  const uint32_t p0 = (uint32_t)__popcll((unsigned long long)w0), p1 = (uint32_t)__popcll((unsigned long long)w1), p2 = (uint32_t)__popcll((unsigned long long)w2);
+  uint32_t j = 0;
+  uint64_t w = w0;
+  if (rr >= p0) {
+    rr -= p0, j = 1, w = w1;
+    if (rr >= p1) {
+      rr -= p1, j = 2, w = w2;
+      if (rr >= p2) rr -= p2, j = 3, w = w3;
+    }
+  }
+  uint32_t pos = 0;
+#pragma unroll
+  for (uint32_t sh = 32; sh >= 1u; sh >>= 1) {  // the rr-th set bit (0-based) of w
+    const uint32_t below = (uint32_t)__popcll((unsigned long long)(w & ((1ull << sh) - 1ull)));
+    if (rr >= below) {
+      rr -= below;
+      w >>= sh;
+      pos += sh;
+    }
+  }
+  return (word0 + j) * 64u + pos;
+}
+
+// The prefix select_visible_id searches: every block scans the meshlet stage's per-64-step sums once (<= kSelectMaxSupers of them, 4 per
+// thread of a 256-thread block) into P (LDS, kSelectMaxSupers + 1 words; P[kSelectMaxSupers] = the pass's visible count, returned), and
+// block 0 stores what the emit kernel's last span would have stored (cull_meshlets_hiz.slang:67-78).  Ends with a block barrier.
+template <bool LATE>
+OXC_DEV uint32_t build_select_prefix(const TriTestArgs& a, uint32_t* P, uint32_t* s_red4, uint32_t* nwords_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
+  const uint32_t nsteps = (N + 255u) / 256u;  // wave steps of the HiZ meshlet test that published a count (64 * kHizGroupsPerWave candidates each)
+  const uint32_t n_supers = (nsteps + kChunksPerSuper - 1) / kChunksPerSuper;
+  uint32_t v[4], t = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; k++) {
+    const uint32_t i = threadIdx.x * 4u + k;
+    v[k] = gptr(a.m_supers)[min(i, n_supers ? n_supers - 1u : 0u) * kSuperStride];
+    v[k] = i < n_supers ? v[k] : 0u;
+    t += v[k];
+  }
+  const uint32_t incl = wave_incl_scan(t, lane);
+  if (lane == 63) s_red4[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - t;
+  for (int k = 0; k < wave; k++) run += s_red4[k];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; k++) {
+    P[threadIdx.x * 4u + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255) P[kSelectMaxSupers] = run;
+  __syncthreads();
+  const uint32_t V = P[kSelectMaxSupers];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    gptr(a.tri_cmd_w)[0] = V;         // cull_triangles_cmd.x
+    gptr(a.vis_w)[LATE ? 2 : 1] = V;  // visibility.early / .late
+  }
+  *nwords_out = (N + 63u) / 64u;
+  return V;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1494,8 +1642,11 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
 // (cull_triangles.slang:71-88 does that per 64-thread workgroup; a single address retires ~88 atomics per microsecond here, hence the
 // span), and the four waves write it the way tris_emit_body does.  No pass masks, chunk counts or visible ids go through memory and
 // no emit launch follows; the runs land in arrival order (ascending inside a span).
-template <bool LATE, bool WIDE, bool SMALL, bool FUSED = false>
+// SELECT (round 5, with FUSED): no k_cull_meshlets_emit ran -- the block finds the ids of its span itself (select_visible_id) and writes
+// them to visible_meshlet_instances_indices as a by-product.
+template <bool LATE, bool WIDE, bool SMALL, bool FUSED = false, bool SELECT = false>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
+  static_assert(!SELECT || FUSED, "the select form is a form of the fused kernel");
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
   constexpr int S = 16;  // slots per wave per chunk
@@ -1529,60 +1680,51 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
   __shared__ uint32_t f_off[FUSED ? kFSpan : 1];
   __shared__ uint64_t f_mask[FUSED ? kFSpan * H : 1];
   __shared__ uint32_t f_id[FUSED ? kFSpan : 1];
-  __shared__ __attribute__((aligned(16))) uint32_t f_run[FUSED ? 4 * (kEmitRun + 8u) : 4];
+  constexpr uint32_t kRun = SELECT ? kFusedRun : kEmitRun;  // (SELECT: the block also holds the prefix of the meshlet stage's sums; 8 blocks per CU have 20 KB each)
+  __shared__ __attribute__((aligned(16))) uint32_t f_run[FUSED ? 4 * (kRun + 8u) : 4];
   __shared__ uint32_t f_base;
+  __shared__ uint32_t f_next;
+  constexpr bool kTickets = FUSED && OXC_FUSED_TICKETS != 0;
+  __shared__ uint32_t s_P[SELECT ? kSelectMaxSupers + 1u : 1u];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t V = a.tri_cmd[0];
+  uint32_t nwords_m = 0;  // SELECT: ballot words the meshlet test wrote
+  (void)nwords_m;
+  const uint32_t V = [&]() -> uint32_t {
+    if constexpr (SELECT)
+      return build_select_prefix<LATE>(a, s_P, s_red, &nwords_m);
+    else
+      return a.tri_cmd[0];
+  }();
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
   const uint32_t nchunks = FUSED ? (V + kFSpan - 1) / kFSpan * kChunksPerSpan : (V + kTriChunk - 1) / kTriChunk;  // (FUSED: whole spans; a chunk beyond V re-does the last slot and leaves empty masks)
+  // kTickets: the spans of the first max(2, whole) rounds of the grid go by block index (span = block + round * grid), what is left of the
+  // last, partial round is drawn from a counter in arrival order -- only blocks that have a second span behind them draw, spread out in
+  // time (2 048 blocks drawing at the end of their FIRST span queue on the one address: early launch 99 -> 103 us)
+  const uint32_t static_spans = kTickets ? max(2u, nchunks / kChunksPerSpan / gridDim.x) * gridDim.x : 0u;
+  (void)static_spans;
   for (uint32_t chunk = FUSED ? blockIdx.x * kChunksPerSpan : blockIdx.x; chunk < nchunks;
        chunk = !FUSED ? chunk + gridDim.x : ((chunk % kChunksPerSpan) != kChunksPerSpan - 1u ? chunk + 1u : chunk - (kChunksPerSpan - 1u) + gridDim.x * kChunksPerSpan)) {
     // ---- lanes 0..15 fetch the MeshletInstance of this wave's 16 slots; everything that is uniform per
     // slot from there on (LOD pointers, Meshlet record, mvp) travels through scalar loads into SGPRs
     uint2 h_rec;
-    {
+    if constexpr (SELECT) {
+      if (chunk % kChunksPerSpan == 0u) {  // (block-uniform) first chunk of a span: its ids, by the waves that own a slot of it
+        if (threadIdx.x < kFSpan) {
+          const uint32_t raw = (chunk / kChunksPerSpan) * kFSpan + threadIdx.x;
+          const uint32_t id = select_visible_id(a.m_bits, s_P, nwords_m, min(raw, V - 1u), f_run + wave * (kRun + 8u), lane);
+          if (raw < V) gptr(a.visible_w)[first + raw] = id;
+          f_id[threadIdx.x] = id;
+        }
+        __syncthreads();
+      }
+      const uint32_t mli = f_id[(chunk % kChunksPerSpan) * kTriChunk + (uint32_t)(lane & 15) * 4 + wave];
+      h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
+    } else {
       const uint32_t slot = min(chunk * kTriChunk + (uint32_t)(lane & 15) * 4 + wave, V - 1u);
       const uint32_t mli = a.visible[first + slot];
       h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
     }
-    uint32_t s_mi[S];
-    uint64_t s_meshlets[S], s_micro[S], s_vidx[S], s_pos[S];
-    uint32_t s_vbase[S], s_tbase[S], s_vmax[S], s_tcount[S];
-    uint32_t vid[S], d0[S][H], d1[S][H];
-    uint2 q[S];
-    auto stage_row = [&](int j) {
-      s_mi[j] = readlane_u(h_rec.x, j);
-      const kconst32p row = const_row(a.cache, s_mi[j]);
-      s_meshlets[j] = (uint64_t)row[kRowBounds + 2] | ((uint64_t)row[kRowBounds + 3] << 32);
-      s_micro[j] = (uint64_t)row[kRowBounds + 4] | ((uint64_t)row[kRowBounds + 5] << 32);
-      s_vidx[j] = (uint64_t)row[kRowBounds + 6] | ((uint64_t)row[kRowBounds + 7] << 32);
-      s_pos[j] = (uint64_t)row[kRowBounds + 8] | ((uint64_t)row[kRowBounds + 9] << 32);
-    };
-    auto stage_rec = [&](int j) {  // Meshlet {vertex_offset, tri_offset(bytes), vertex_count, tri_count} (SceneGPU.hpp, 16 B)
-      const k32 m = (k32)(s_meshlets[j] + (uint64_t)readlane_u(h_rec.y, j) * 16u);
-      const uint32_t vcount = min(m[2], 64u);  // one lane per vertex / triangle (defines.slang:9-23)
-      const uint32_t tcount = min(m[3], 64u * (uint32_t)H);
-      const bool empty = vcount == 0u || tcount == 0u;  // nothing to test: read the zero dwords of the row instead of the mesh
-      const uint64_t zeros = reinterpret_cast<uint64_t>(a.cache + s_mi[j]) + kRowScale * 4 + 4;
-      s_vbase[j] = empty ? 0u : m[0];
-      s_tbase[j] = empty ? 0u : m[1];
-      s_vmax[j] = empty ? 0u : vcount - 1u;  // an empty meshlet reads one zero dword (vertex id 0) and the row's first 8 bytes
-      s_tcount[j] = empty ? 0u : tcount;
-      s_micro[j] = empty ? zeros : s_micro[j];
-      s_vidx[j] = empty ? zeros : s_vidx[j];
-      s_pos[j] = empty ? reinterpret_cast<uint64_t>(a.cache + s_mi[j]) : s_pos[j];
-    };
-    auto stage_idx = [&](int j) {
-      vid[j] = OXC_TRI_LOAD_U32(s_vidx[j], s_vbase[j] + min((uint32_t)lane, s_vmax[j]));
-      const uint32_t tmax = max(s_tcount[j], 1u) - 1u;
-#pragma unroll
-      for (int h = 0; h < H; h++) {  // scene.slang:336-342,365-372 via aligned dword loads
-        const uint32_t boff = s_tbase[j] + min((uint32_t)lane + 64u * (uint32_t)h, tmax) * 3u;
-        d0[j][h] = OXC_TRI_LOAD_U32(s_micro[j], boff >> 2);
-        d1[j][h] = OXC_TRI_LOAD_U32(s_micro[j], (boff + 2u) >> 2);
-      }
-    };
-    auto stage_pos = [&](int j) { q[j] = OXC_TRI_LOAD_U2(s_pos[j], vid[j]); };  // u16x4, stride 8
+#include "oxcull_tri_stages.inc"
 #pragma unroll
     for (int j = 0; j < kRowAhead; j++) stage_row(j);
 #pragma unroll
@@ -1595,78 +1737,9 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
     uint32_t mlo[H], mhi[H];  // lane j: pass mask(s) of slot j
 #pragma unroll
     for (int h = 0; h < H; h++) mlo[h] = mhi[h] = 0;
-#pragma unroll
-    for (int j = 0; j < S; j++) {
-      if (j + kRowAhead < S) stage_row(j + kRowAhead);
-      if (j + kRecAhead < S) stage_rec(j + kRecAhead);
-      if (j + kIdxAhead < S) stage_idx(j + kIdxAhead);
-      if (j + kPosAhead < S) stage_pos(j + kPosAhead);
-      const bool valid = chunk * kTriChunk + (uint32_t)j * 4 + wave < V;  // wave-uniform
-      const uint32_t vertex_count = s_vmax[j] + 1u;  // (>= 1; the lanes of an empty meshlet are masked by tri_count == 0)
-      const uint32_t tri_count = s_tcount[j];
-      const kconst32p row = const_row(a.cache, s_mi[j]);
-      f2 m_xy[4], m_zw[4];  // column c of projection_view * world: rows (0,1) and (2,3)
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        m_xy[c] = f2{asf(row[kRowMvp + c * 4 + 0]), asf(row[kRowMvp + c * 4 + 1])};
-        m_zw[c] = f2{asf(row[kRowMvp + c * 4 + 2]), asf(row[kRowMvp + c * 4 + 3])};
-      }
-      // vertex phase: lane = vertex
-      const float px = dequantize_half(q[j].x & 0xFFFFu), py = dequantize_half(q[j].x >> 16), pz = dequantize_half(q[j].y & 0xFFFFu);
-      const f2 cxy = ((m_xy[0] * splat(px) + m_xy[1] * splat(py)) + m_xy[2] * splat(pz)) + m_xy[3];
-      const f2 czw = ((m_zw[0] * splat(px) + m_zw[1] * splat(py)) + m_zw[2] * splat(pz)) + m_zw[3];
-      const float clx = cxy.x, cly = cxy.y, clw = czw.y;
-      const uint64_t zok = __builtin_amdgcn_ballot_w64((uint32_t)lane < vertex_count && czw.x >= 0.0f);
-      float scx = 0.0f, scy = 0.0f;
-      uint64_t wok = 0;
-      if constexpr (SMALL) {
-        scx = ((clx / clw) * 0.5f + 0.5f) * a.resolution[0];
-        scy = ((cly / clw) * 0.5f + 0.5f) * a.resolution[1];
-        wok = __builtin_amdgcn_ballot_w64((uint32_t)lane < vertex_count && clw > 0.0f);
-      }
-      if constexpr (kLdsVerts) s_vert[wave][lane] = make_uint4(asu(clx), asu(cly), asu(clw), ((uint32_t)lane < vertex_count && czw.x >= 0.0f) ? 1u : 0u);
-      // triangle phase: lane = triangle (two passes of 64 when WIDE)
-#pragma unroll
-      for (int h = 0; h < H; h++) {
-        const uint32_t t = (uint32_t)lane + 64u * (uint32_t)h;
-        const uint32_t tl = min(t, max(tri_count, 1u) - 1u);
-        const uint32_t tri = __builtin_amdgcn_alignbyte(d1[j][h], d0[j][h], (s_tbase[j] + tl * 3u) & 3u);
-        const int l0 = (int)(tri & 0xFFu), l1 = (int)((tri >> 8) & 0xFFu), l2 = (int)((tri >> 16) & 0xFFu);
-        float ax, ay, aw, bx, by, bw, cx, cy, cw;
-        bool z_all;
-        if constexpr (kLdsVerts) {  // one 16-byte LDS read per corner: {x, y, w, z-ok} of the vertex the vertex phase left there
-          const uint4 A = s_vert[wave][l0 & 63], B = s_vert[wave][l1 & 63], C = s_vert[wave][l2 & 63];
-          z_all = (A.w & B.w & C.w) != 0u;
-          ax = asf(A.x), ay = asf(A.y), aw = asf(A.z);
-          bx = asf(B.x), by = asf(B.y), bw = asf(B.z);
-          cx = asf(C.x), cy = asf(C.y), cw = asf(C.z);
-        } else {
-          ax = bperm_f(l0, clx), ay = bperm_f(l0, cly), aw = bperm_f(l0, clw);
-          bx = bperm_f(l1, clx), by = bperm_f(l1, cly), bw = bperm_f(l1, clw);
-          cx = bperm_f(l2, clx), cy = bperm_f(l2, cly), cw = bperm_f(l2, clw);
-          z_all = (((zok >> (l0 & 63)) & (zok >> (l1 & 63)) & (zok >> (l2 & 63))) & 1ull) != 0ull;
-        }
-        // determinant(float3x3(c0.xyw, c1.xyw, c2.xyw)), first-row cofactor expansion (cull.slang:169-171)
-        const float det = (ax * (by * cw - bw * cy) - ay * (bx * cw - bw * cx)) + aw * (bx * cy - by * cx);
-        bool passed = t < tri_count && z_all && !(det >= 0.0001f);
-        if constexpr (SMALL) {
-          const float x0 = bperm_f(l0, scx), x1 = bperm_f(l1, scx), x2 = bperm_f(l2, scx);
-          const float y0 = bperm_f(l0, scy), y1 = bperm_f(l1, scy), y2 = bperm_f(l2, scy);
-          const bool w_all = (((wok >> (l0 & 63)) & (wok >> (l1 & 63)) & (wok >> (l2 & 63))) & 1ull) != 0ull;
-          const float lox = fminf(fminf(x0, x1), x2), hix = fmaxf(fmaxf(x0, x1), x2);
-          const float loy = fminf(fminf(y0, y1), y2), hiy = fmaxf(fmaxf(y0, y1), y2);
-          const bool small = floorf(lox + 0.5f) == floorf(hix + 0.5f) || floorf(loy + 0.5f) == floorf(hiy + 0.5f);
-          passed = passed && !(w_all && small);
-        }
-        const uint64_t mask = valid ? __builtin_amdgcn_ballot_w64(passed) : 0ull;
-        // (s_nop 1: the SGPR read by v_writelane was written by a VALU instruction -- v_readfirstlane here -- and this target wants two
-        // wait states between the two; the compiler pads its own code but cannot see into an asm statement.  Round 3 found the rule the
-        // hard way: with a v_cmp-written pair fed to the asm directly, the masks came out stale.)
-        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mlo[h]) : "s"(readfirst_u((uint32_t)mask)), "n"(j));
-        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mhi[h]) : "s"(readfirst_u((uint32_t)(mask >> 32))), "n"(j));
-        cnt += (uint32_t)__popcll((unsigned long long)mask);
-      }
-    }
+#define OXC_TRI_SLOT0 (chunk * kTriChunk)
+#include "oxcull_tri_slots.inc"
+#undef OXC_TRI_SLOT0
     if constexpr (FUSED) {
       (void)cnt;
       const uint32_t c4 = chunk % kChunksPerSpan;
@@ -1682,7 +1755,9 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       uint32_t c = 0;
 #pragma unroll
       for (int h = 0; h < H; h++) c += in_span ? (uint32_t)__popcll((unsigned long long)f_mask[(in_span ? threadIdx.x : 0u) * H + h]) : 0u;
-      const uint32_t id = (in_span && slot < V) ? a.visible[first + slot] : 0u;
+      uint32_t id = 0u;
+      if constexpr (!SELECT) id = (in_span && slot < V) ? a.visible[first + slot] : 0u;
+      (void)slot;
       const uint32_t incl = wave_incl_scan(c, lane);
       if (lane == 63) s_red[wave] = incl;
       __syncthreads();
@@ -1690,16 +1765,32 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       for (int k = 0; k < wave; k++) woff += s_red[k];
       if (in_span) {
         f_off[threadIdx.x] = woff + incl - c;
-        f_id[threadIdx.x] = id;
+        if constexpr (!SELECT) f_id[threadIdx.x] = id;  // (SELECT: the span's ids have been there since its first chunk)
       }
       if (threadIdx.x == 255) {
         const uint32_t total3 = (woff + incl) * 3u;
-        f_base = total3 ? __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // DrawIndexedIndirect.index_count
+        uint32_t base = 0u, tk = 0u;
+        if (total3) base = __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // DrawIndexedIndirect.index_count
+        if constexpr (kTickets) {  // the span after this one, when it is a drawn one (both round trips overlap)
+          const uint32_t span_now = chunk / kChunksPerSpan;
+          if (span_now + gridDim.x >= static_spans && static_spans < nchunks / kChunksPerSpan)
+            tk = __hip_atomic_fetch_add(gptr(a.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f_next = tk;
+        }
+        f_base = base;
       }
       __syncthreads();
-      expand_slots_wide<H, kCornerBits>(f_mask, f_id, wave * (int)(kFSpan / 4), (int)(kFSpan / 4), f_base + f_off[wave * (kFSpan / 4)] * 3u, a.out,
-                                        f_run + wave * (kEmitRun + 8u), lane);
+      expand_slots_wide<H, kCornerBits, kRun>(f_mask, f_id, wave * (int)(kFSpan / 4), (int)(kFSpan / 4), f_base + f_off[wave * (kFSpan / 4)] * 3u, a.out,
+                                              f_run + wave * (kRun + 8u), lane);
       __syncthreads();  // the span's LDS rows are rewritten by the block's next span
+      if constexpr (kTickets) {
+        // (the loop header adds one grid of spans to the span just done: hand it the span before the drawn one, or one past everything)
+        const uint32_t nspans_all = nchunks / kChunksPerSpan;
+        const uint32_t span_now = chunk / kChunksPerSpan;
+        const uint32_t nxt = span_now + gridDim.x < static_spans ? span_now + gridDim.x : static_spans + f_next;
+        chunk = (nxt < nspans_all ? nxt - gridDim.x : nspans_all) * kChunksPerSpan + (kChunksPerSpan - 1u);
+        __syncthreads();  // (f_next is rewritten at the next span's end: every wave has read it)
+      }
     } else {
     {
       const uint32_t slot = chunk * kTriChunk + (uint32_t)lane * 4 + wave;
@@ -1716,6 +1807,166 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       a.chunk_counts[chunk] = c;
       if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 5: the fused triangle kernel (unordered_output; k_cull_triangles_fused above is round 4's form, FMODE 1 here for reference):
+//  * spans beyond OXC_FUSED_STATIC_ROUNDS x the grid are drawn from a ticket counter (one returning atomic per span, read at the span's end);
+//  * the ids of a span sit in LDS (double-buffered): the next span's are fetched beside the index_count atomic's round trip, and the
+//    MeshletInstance records of its first chunk are in flight while the block expands the current span (OXC_FUSED_OVERLAP);
+//  * every wave scans the span's 128 triangle counts itself: one block barrier less per span;
+//  * SELECT: the block finds its ids ITSELF from the meshlet stage's ballots and counts (select_visible_id above) and writes them to
+//    visible_meshlet_instances_indices as a by-product -- the two k_cull_meshlets_emit launches of a frame are gone.
+// Same per-slot pipeline (the .inc files), same bytes per slot; runs land in arrival order, ascending inside a span, like round 4's.
+// ------------------------------------------------------------------------------------------
+template <bool LATE, bool WIDE, bool SMALL, bool SELECT>
+OXC_DEV void tris_fused2_body(const TriTestArgs& a) {
+  set_half_denorm_flush();
+  constexpr int H = WIDE ? 2 : 1;
+  constexpr int S = 16;  // slots per wave per chunk
+  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;
+  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;
+  constexpr int kRecAhead = kIdxAhead + 1;
+  constexpr int kRowAhead = kIdxAhead + 2;
+  typedef const uint32_t __attribute__((address_space(4))) * k32;
+  __shared__ uint32_t s_red[4];
+  constexpr uint32_t kFSpan = kFusedTriSpan;
+  constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;
+  static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
+  constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;  // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
+  constexpr uint32_t kRun = kFusedRun;
+  constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
+  __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];
+  __shared__ uint64_t f_mask[kFSpan * H];
+  __shared__ uint32_t f_id[2u * kFSpan];  // the ids of the span in hand and of the next one
+  __shared__ __attribute__((aligned(16))) uint32_t f_run[4 * (kRun + 8u)];
+  __shared__ uint32_t f_base;
+  __shared__ uint32_t f_next;
+  __shared__ uint32_t s_P[SELECT ? kSelectMaxSupers + 1u : 1u];  // SELECT: exclusive prefix of the meshlet stage's per-64-step sums; s_P[kSelectMaxSupers] = V
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t V = 0, first = 0;  // visible meshlets of this pass; where its list starts (cull_triangles.slang:34-37)
+  uint2 h_rec;  // lanes 0..15: the MeshletInstance records of the wave's 16 slots of the chunk in hand (or, kOverlap: of the next span's first chunk)
+  {
+    // ================= FMODE 2 / 3 =================
+    uint32_t nwords_m = 0;
+    if constexpr (SELECT) {
+      V = build_select_prefix<LATE>(a, s_P, s_red, &nwords_m);
+      first = LATE ? a.vis[1] : 0u;
+    } else {
+      V = a.tri_cmd[0];
+      first = LATE ? a.vis[1] : 0u;
+    }
+    const uint32_t nspans = (V + kFSpan - 1) / kFSpan;
+    uint32_t span = blockIdx.x;
+    if (span >= nspans) return;  // (block-uniform)
+    uint32_t* const sel_scratch = f_run + wave * (kRun + 8u);  // 64 words per wave, free outside the expansion
+    // ids of span `sp` -> f_id[nb]: slot s of the pass's visible list, s clamped to V - 1 (a slot beyond V re-does the last one and
+    // leaves an empty mask).  SELECT also writes them to the visible list (the emit kernel's output, ascending by construction).
+    auto fetch_ids = [&](const uint32_t sp, const uint32_t nb) {
+      if (threadIdx.x < kFSpan) {  // (wave-uniform)
+        const uint32_t raw = sp * kFSpan + threadIdx.x;
+        const uint32_t slot = min(raw, V - 1u);
+        uint32_t id;
+        if constexpr (SELECT) {
+          id = select_visible_id(a.m_bits, s_P, nwords_m, slot, sel_scratch, lane);
+          if (raw < V) gptr(a.visible_w)[first + raw] = id;
+        } else {
+          id = a.visible[first + slot];
+        }
+        f_id[nb * kFSpan + threadIdx.x] = id;
+      }
+    };
+    auto load_hrec = [&](const uint32_t nb, const uint32_t c4) {
+      const uint32_t mli = f_id[nb * kFSpan + c4 * kTriChunk + (uint32_t)(lane & 15) * 4 + wave];
+      h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
+    };
+    uint32_t buf = 0;
+    fetch_ids(span, 0u);
+    __syncthreads();
+    constexpr int kOverlap = OXC_FUSED_OVERLAP;
+    bool staged = false;  // (block-uniform) the first chunk's MeshletInstance records are already in flight
+    // spans [0, kStaticRounds * grid) go by block index (round r of block b: span b + r * grid), the rest by ticket t: span kStaticRounds * grid + t
+    constexpr uint32_t kStaticRounds = OXC_FUSED_STATIC_ROUNDS;
+    uint32_t round = 0;
+    for (;;) {
+      // the span after this one: by block index for the first rounds, then one returning atomic per span on a counter of the call
+      // (TriTestArgs::ticket, zeroed by the prepare kernel).  The answer is read at the end of the span.
+      uint32_t tk = 0;
+      for (uint32_t c4 = 0; c4 < kChunksPerSpan; c4++) {
+        if (!(kOverlap == 1 && c4 == 0u && staged)) load_hrec(buf, c4);
+        const uint32_t slot0 = span * kFSpan + c4 * kTriChunk;  // the chunk's first slot of the visible list
+#include "oxcull_tri_stages.inc"
+#pragma unroll
+        for (int j = 0; j < kRowAhead; j++) stage_row(j);
+#pragma unroll
+        for (int j = 0; j < kRecAhead; j++) stage_rec(j);
+#pragma unroll
+        for (int j = 0; j < kIdxAhead; j++) stage_idx(j);
+#pragma unroll
+        for (int j = 0; j < kPosAhead; j++) stage_pos(j);
+        // (the ticket of the span after this one: drawn behind the last chunk's prologue loads -- a returning atomic in front of them
+        //  holds up wave 0's first counted wait, and 2 048 blocks drawing one at kernel start queue for 26 us on the one address)
+        if (c4 == kChunksPerSpan - 1u && round >= kStaticRounds - 1u && threadIdx.x == 0)
+          tk = __hip_atomic_fetch_add(gptr(a.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t cnt = 0;
+        uint32_t mlo[H], mhi[H];  // lane j: pass mask(s) of slot j
+#pragma unroll
+        for (int h = 0; h < H; h++) mlo[h] = mhi[h] = 0;
+#define OXC_TRI_SLOT0 slot0
+#include "oxcull_tri_slots.inc"
+#undef OXC_TRI_SLOT0
+        (void)cnt;
+        if (lane < S) {  // slot (chunk c4, j = lane, wave) sits at c4 * 64 + j * 4 + wave of the span
+#pragma unroll
+          for (int h = 0; h < H; h++) f_mask[(c4 * kTriChunk + (uint32_t)lane * 4 + wave) * H + h] = (uint64_t)mlo[h] | ((uint64_t)mhi[h] << 32);
+        }
+      }
+      if (threadIdx.x == 0) f_next = round >= kStaticRounds - 1u ? gridDim.x * kStaticRounds + tk : span + gridDim.x;
+      __syncthreads();  // (1) the span's masks and the next span's number are in LDS
+      const uint32_t next = f_next;
+      const bool has_next = next < nspans;  // (block-uniform)
+      // the next span's ids: the waves that own a slot of it (0 and 1 of four when a span is 128) find / load them while wave 3, which owns
+      // none, is already on its way to the index_count atomic below
+      if (has_next) fetch_ids(next, buf ^ 1u);
+      // every wave scans the span's triangle counts itself (kFSpan / 64 wave scans): no hand-off through LDS, no barrier for it
+      uint32_t excl[kFSpan / 64];
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t p = 0; p < kFSpan / 64u; p++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int h = 0; h < H; h++) c += (uint32_t)__popcll((unsigned long long)f_mask[(p * 64u + (uint32_t)lane) * H + h]);
+        const uint32_t incl = wave_incl_scan(c, lane);
+        excl[p] = total + incl - c;
+        total += readlane_u(incl, 63);
+      }
+      uint32_t got = 0;
+      if (threadIdx.x == 255 && total) got = __hip_atomic_fetch_add(gptr(a.draw_cmd), total * 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // DrawIndexedIndirect.index_count
+      if (threadIdx.x == 255) f_base = got;
+      __syncthreads();  // (2) the run's base and the next span's ids are in LDS
+      const uint32_t gbase = f_base;
+      // ---- expansion of the span, the MeshletInstance records of the next span's first chunk in flight behind it.  (Staging the rest of
+      // that chunk's prologue -- rows, Meshlet records, index and position loads -- between four parts of the expansion was built too: the
+      // ~50 SGPRs it holds across the expansion turn into 320-380 SGPR and ~47 VGPR spills in a kernel that has 78 SGPRs at 8 waves per SIMD.)
+      if (kOverlap >= 1 && has_next) load_hrec(buf ^ 1u, 0u);
+      constexpr int kPart = (int)(kFSpan / 16u);
+#pragma unroll
+      for (int part = 0; part < 4; part++) {
+        const int fs = wave * (int)(kFSpan / 4u) + part * kPart;
+        uint32_t e = excl[0];
+#pragma unroll
+        for (uint32_t p = 1; p < kFSpan / 64u; p++) e = (uint32_t)fs >= p * 64u ? excl[p] : e;  // (wave-uniform)
+        const uint32_t off = readlane_u(e, fs & 63);
+        expand_slots_wide<H, kCornerBits, kRun>(f_mask, f_id + buf * kFSpan, fs, kPart, gbase + off * 3u, a.out, f_run + wave * (kRun + 8u), lane);
+      }
+      if (!has_next) break;
+      __syncthreads();  // (3) the span's LDS rows are rewritten by the next span
+      span = next;
+      buf ^= 1u;
+      staged = true;
+      round++;
     }
   }
 }
@@ -2037,9 +2288,23 @@ template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
   tris_emit_body<LATE, WIDE>(a);
 }
+#ifndef OXC_FUSED_MODE
+#define OXC_FUSED_MODE 1  // structure of the fused kernel: 1 = round 4 (static span stride; default), 2 = round 5 experiment (tickets + LDS ids + next-span records in flight: measured slower)
+#endif
 template <bool LATE, bool WIDE, bool SMALL>
 __global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused(TriTestArgs a) {
-  tris_test_body<LATE, WIDE, SMALL, true>(a);
+  if constexpr (OXC_FUSED_MODE == 1)
+    tris_test_body<LATE, WIDE, SMALL, true>(a);
+  else
+    tris_fused2_body<LATE, WIDE, SMALL, false>(a);
+}
+// ... and the form that finds its ids itself (TriTestArgs::m_bits != null): no k_cull_meshlets_emit launch precedes it
+template <bool LATE, bool WIDE, bool SMALL>
+__global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused_select(TriTestArgs a) {
+  if constexpr (OXC_FUSED_MODE == 1)
+    tris_test_body<LATE, WIDE, SMALL, true, true>(a);
+  else
+    tris_fused2_body<LATE, WIDE, SMALL, true>(a);
 }
 
 // Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
@@ -2544,6 +2809,19 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_tri
 void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
+  if (a.m_bits) {
+    switch (v) {
+      case 0: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, false, false>), g, b, 0, s, a); break;
+      case 1: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, false, true>), g, b, 0, s, a); break;
+      case 2: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, true, false>), g, b, 0, s, a); break;
+      case 3: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, true, true>), g, b, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, false, false>), g, b, 0, s, a); break;
+      case 5: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, false, true>), g, b, 0, s, a); break;
+      case 6: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, true, false>), g, b, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, true, true>), g, b, 0, s, a); break;
+    }
+    return;
+  }
   switch (v) {
     case 0: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, false>), g, b, 0, s, a); break;
     case 1: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, true>), g, b, 0, s, a); break;

@@ -125,6 +125,19 @@ struct TriTestArgs {
   // cull_triangles.slang:71-88 does per workgroup) writes the packed indices and the draw command itself
   uint32_t* draw_cmd;
   uint32_t* out;  // reordered_indices
+  // round 5, fused kernel: spans beyond the grid are drawn from this counter (zeroed by the prepare kernel: the ordered form's
+  // first triangle super-chunk accumulator, which the fused form does not use)
+  uint32_t* ticket;
+  // round 5, "select" form (m_bits != null; HiZ meshlet stage of the same call, in order): no meshlet emit kernel ran -- the kernel finds
+  // the ids of its spans from the meshlet test's ballots (m_bits: one word per 64 candidates), per-step counts and per-64-step sums,
+  // and writes visible_meshlet_instances_indices, cull_triangles_cmd.x and visibility.early / .late itself
+  const uint64_t* m_bits;
+  const uint32_t* m_chunk_counts;
+  const uint32_t* m_supers;
+  uint32_t n_host, n_cap;  // as MeshletTestArgs: the list length (host-known or vis[0] clamped)
+  uint32_t* visible_w;
+  uint32_t* vis_w;
+  uint32_t* tri_cmd_w;
 };
 
 struct TriEmitArgs {
@@ -293,6 +306,11 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   tt.resolution[0] = c.cam.resolution[0];
   tt.resolution[1] = c.cam.resolution[1];
   tt.draw_cmd = tt.out = nullptr;
+  tt.ticket = nullptr;
+  tt.m_bits = nullptr;
+  tt.m_chunk_counts = tt.m_supers = nullptr;
+  tt.n_host = tt.n_cap = 0;
+  tt.visible_w = tt.vis_w = tt.tri_cmd_w = nullptr;
   TriEmitArgs& te = e.temit;
   te.tri_masks = c.tri_masks;
   te.visible = c.visible_out;

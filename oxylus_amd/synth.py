@@ -204,6 +204,46 @@ class Scene:
                   _lod_tables=tables)
         return s.bind()
 
+    def take(self, ranges, device=None) -> "Scene":
+        """The sub-scene of several mesh-instance ranges [(a, b), ...] laid end to end (SURVEY 8e's interleaved assignment: a rank owns every
+        world-th block of instances): slice() of each range, the pieces' arrays concatenated and their shard-local indices shifted by
+        what lies in front of them -- mesh / transform indices by the instances, visibility offsets by the mask bits (K per instance),
+        MeshletInstance records by the instances, the blob tables by the array runs.  One range gives slice(a, b)."""
+        ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+        assert ranges, "at least one non-empty range"
+        pieces = [self.slice(a, b, device) for a, b in ranges]
+        if len(pieces) == 1:
+            return pieces[0]
+        K = self.spec.meshlets_per_mesh
+        names = ("bounds", "meshlets", "micro", "vidx", "positions", "lods", "meshes", "transforms")
+        run = {n: 0 for n in ("inst", "meshlet", "vidx", "micro", "vertex")}
+        mis, mlis, tables = [], [], {k: [] for k in ("meshlet_start", "vidx_start", "micro_start", "mesh_vertex_start")}
+        for pc in pieces:
+            mi = pc.mesh_instances.clone()
+            mi[:, 0] += run["inst"]
+            mi[:, 3] += run["inst"]
+            mi[:, 4] += run["inst"] * K
+            mis.append(mi)
+            ml = pc.meshlet_instances.clone()
+            ml[:, 0] += run["inst"]
+            mlis.append(ml)
+            t = pc._lod_tables
+            tables["meshlet_start"].append(t["meshlet_start"] + run["meshlet"])
+            tables["vidx_start"].append(t["vidx_start"] + run["vidx"])
+            tables["micro_start"].append(t["micro_start"] + run["micro"])
+            tables["mesh_vertex_start"].append(t["mesh_vertex_start"] + run["vertex"])
+            run["inst"] += pc.n_mesh_instances
+            run["meshlet"] += pc.bounds.shape[0]
+            run["vidx"] += pc.vidx.shape[0]
+            run["micro"] += pc.micro.shape[0]
+            run["vertex"] += pc.positions.shape[0]
+        kw = {n: torch.cat([getattr(pc, n) for pc in pieces]).contiguous() for n in names}
+        spec = SceneSpec(**{**self.spec.__dict__, "n_mesh_instances": run["inst"]})
+        s = Scene(spec=spec, device=pieces[0].device, mesh_instances=torch.cat(mis).contiguous(), meshlet_instances=torch.cat(mlis).contiguous(),
+                  camera=self.camera, n_meshes=run["inst"], lod_meshlet_counts=self.lod_meshlet_counts,
+                  _lod_tables={k: torch.cat(v) for k, v in tables.items()}, **kw)
+        return s.bind()
+
     def algorithmic_bytes_meshlet_stage(self, visible_fraction: float) -> float:
         """8 B MeshletInstance + 16 B MeshletBounds read, 4*v B written, per-mesh
         tables (20+64+64+64 B) amortised over K meshlets."""

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, top=0):
+def _worker(rank, world, port, out_dir, top=0, block=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +35,7 @@ def _worker(rank, world, port, out_dir, top=0):
 
     spec = SceneSpec(n_mesh_instances=21, meshlets_per_mesh=96, seed=77)
     scene = make_scene(spec, "cpu")  # every rank generates the same scene, keeps only its shard
-    shard, first = shard_scene(scene, rank, world)
+    shard, first = shard_scene(scene, rank, world, block)  # (block > 0: interleaved blocks of instances, `first` is then the piece table)
     # HiZ: rank 0 builds, everyone receives
     levels, offs, total = __import__("oxylus_amd.synth", fromlist=["hiz_layout"]).hiz_layout(128, 128)
     hz = torch.zeros(total // 4)
@@ -56,18 +56,19 @@ def _worker(rank, world, port, out_dir, top=0):
     glob = merge_visible(torch.from_numpy(res["late_visible"]), first)
     # packed triangle indices carry shard-local 24-bit ids; globalise them the same way
     idx = torch.from_numpy(res["late_indices"]).to(torch.int64)
-    idx_glob = (((idx >> 8) + first) << 8) | (idx & 0xFF)
+    idx_glob = (merge_visible(idx >> 8, first) << 8) | (idx & 0xFF)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), counts=allc.numpy(), offsets=offs_r.numpy(), visible=glob.numpy(), indices=idx_glob.numpy(),
              hiz_sum=float(hz.double().sum()))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("block", [0, 4], ids=["contiguous", "interleaved-blocks-of-4-instances"])
 @pytest.mark.parametrize("top", [0, 2], ids=["whole-pyramid", "top-mips"])
-def test_two_rank_shards_union_equals_single(tmp_path, oracle_lib, top):
+def test_two_rank_shards_union_equals_single(tmp_path, oracle_lib, top, block):
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), top), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), top, block), nprocs=world, join=True)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oxylus_amd.synth import SceneSpec, make_depth, make_scene
     from util import oracle_frame, oracle_hiz
@@ -82,10 +83,13 @@ def test_two_rank_shards_union_equals_single(tmp_path, oracle_lib, top):
     assert r[0]["counts"][:, 0].sum() == single["late_emitted"]
     assert r[0]["counts"][:, 3].sum() == len(single["late_indices"])
     assert r[0]["offsets"][1, 0] == r[0]["counts"][0, 0]
-    # contiguous ranges + ascending shard-local order => concatenation IS the global ascending list
     vis = np.concatenate([r[0]["visible"], r[1]["visible"]])
-    assert np.array_equal(vis, single["late_visible"].astype(np.int64))
     idx = np.concatenate([r[0]["indices"], r[1]["indices"]])
+    if block:  # interleaved blocks: every rank's list ascends, the global list is their merge
+        assert all(np.all(np.diff(r[k]["visible"]) > 0) for k in range(world))
+        vis, idx = np.sort(vis), np.sort(idx)
+    # contiguous ranges + ascending shard-local order => concatenation IS the global ascending list
+    assert np.array_equal(vis, single["late_visible"].astype(np.int64))
     assert np.array_equal(idx, single["late_indices"].astype(np.int64))
     # the broadcast delivered rank 0's pyramid
     assert r[0]["hiz_sum"] == r[1]["hiz_sum"] == float(hz.double().sum())
@@ -153,6 +157,19 @@ def test_two_rank_multiview_shards_union_equals_single(tmp_path, oracle_lib):
         assert np.array_equal(np.concatenate([r[0][f"v{v}"], r[1][f"v{v}"]]), vis.numpy().astype(np.int64)), f"view {v}: union of the shard lists"
         seen += vis.numel()
     assert seen > 30  # (the small cascades see little of a 23-instance scene; the wide ones most of it)
+
+
+def test_interleaved_shard_ranges_cover_and_disjoint():
+    from oxylus_amd.shard import shard_ranges
+
+    for n, w, blk in ((21, 2, 4), (100, 8, 7), (5, 8, 1), (64, 4, 64), (1000, 8, 64)):
+        per_rank = shard_ranges(n, w, blk)
+        assert len(per_rank) == w
+        flat = sorted(x for rs in per_rank for x in rs)
+        assert flat[0][0] == 0 and flat[-1][1] == n and all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1))
+        assert all(b - a <= blk for a, b in flat)
+        sizes = [sum(b - a for a, b in rs) for rs in per_rank]
+        assert max(sizes) - min(sizes) <= blk
 
 
 def test_shard_ranges_cover_and_disjoint():
