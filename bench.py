@@ -64,10 +64,12 @@ def parse():
     ap.add_argument("--copies", type=int, default=0, help="config2: independent scene copies rotated through (default: >= 1.1 GB)")
     ap.add_argument("--streams", type=int, default=3, help="config2: independent batches in flight (contexts on their own HIP streams)")
     ap.add_argument("--batch", type=int, default=16, help="config2 / config5: frames (views) per oxc_cull_geometry_batch call (max 16)")
-    ap.add_argument("--explicit-lists", action="store_true", help="config5: write the per-view MeshletInstance records (the reference's cull_meshes output) on the main line; "
-                                                                   "by default they stay implicit {first, count} runs (include/oxcull.h: implicit_meshlet_instances) and the explicit form is timed as a variant")
-    ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement")
+    ap.add_argument("--implicit-lists", action="store_true", help="config5: leave the per-view MeshletInstance lists implicit ({first, count} runs per mesh instance, include/oxcull.h: "
+                                                                   "implicit_meshlet_instances) on the main line; by default the records are written as the reference's cull_meshes writes them "
+                                                                   "(reference-equivalent output) and the implicit form is timed as a variant")
+    ap.add_argument("--no-configs1", action="store_true", help="config3: skip the nested configs[1] measurement (1M meshlets, frustum + cone)")
     ap.add_argument("--no-configs4", action="store_true", help="config3: skip the nested configs[4] measurement (10M meshlets x 16 views)")
+    ap.add_argument("--no-configs0", action="store_true", help="config3: skip the nested configs[0] measurement (1k entities, host only, ~2 s)")
     ap.add_argument("--no-real-geometry", action="store_true", help="config3: skip the nested run of the same frame over instanced real meshes (clusteriser-built)")
     ap.add_argument("--async-triangles", action="store_true",
                     help="config3: time the main line with async_triangles = 1 (triangle stages on the context's own stream, frames pipeline); the default line is in "
@@ -579,9 +581,12 @@ def bench_config3(args, e):
     main_async, main_ahead, main_share, main_unord = use_async[0], use_overlap[0], use_share[0], use_unord[0]
     variants = []
     if not args.no_scheduling_ab:
-        for other in (u for u in (0, 1, 2) if u != main_unord):  # the list layouts of include/oxcull.h (compared as sorted sets)
+        for other in (u for u in (0, 1) if u != main_unord):  # the list layouts of include/oxcull.h (compared as sorted sets)
             variants.append(timed_variant(main_async, main_ahead, main_share, other))
         variants.append(timed_variant(main_async, main_ahead, not main_share))
+        if main_share or main_unord:  # the library's all-defaults form: ascending lists, every call testing on its own
+            variants.append(timed_variant(main_async, main_ahead, False, 0))
+            variants[-1]["library_defaults"] = True
         variants.append(timed_variant(not main_async, main_ahead, main_share))
         if world == 1:
             variants.append(timed_variant(main_async, not main_ahead, main_share))
@@ -594,8 +599,8 @@ def bench_config3(args, e):
                               "unordered_output": main_unord, "ms_per_frame": round(ms_per_frame, 6)},
                 "variants": variants,
                 "note": "unordered_output (include/oxcull.h): 0 = ascending lists, test + ordered emit per stage; 1 = the triangle stage as ONE launch that appends behind an "
-                        "atomic_add on index_count per 256-meshlet span (cull_triangles.slang:71-88), HiZ meshlet stage unchanged; 2 = the HiZ meshlet tests append as well, one "
-                        "atomic_add pair per wave step (cull_meshlets_hiz.slang:67-78 aggregated through the ballot) -- variants of it are compared with the main line as sorted sets.  "
+                        "atomic_add on index_count per 128-meshlet span (cull_triangles.slang:71-88) and finds the ids of its spans from the meshlet test's ballots (no meshlet emit "
+                        "launch; the visible list it writes is the ascending one) -- variants are compared with the main line as sorted sets.  library_defaults = ordered + unshared.  "
                         "share_pass_tests: the late call of a frame reads the early call's frustum + cone results (one bit per meshlet) instead of testing again -- a cache "
                         "inside liboxcull, valid because both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884); the variant that flips it is "
                         "the frame with every call testing on its own.  async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "
@@ -615,6 +620,28 @@ def bench_config3(args, e):
             run_frame()  # (leaves the pyramids in the main mode's state for the kernel profile below)
         torch.cuda.synchronize()
 
+    # ---- SURVEY 8d's f: candidates that reach test_occlusion (four pyramid taps = 16 B each), counted by the counting instantiations of
+    # the two meshlet tests in one untimed frame (oxc_debug_count_occlusion_candidates) ----
+    occl_candidates = {"early": None, "late": None}
+    if hasattr(lib, "oxc_debug_count_occlusion_candidates"):
+        cnt = [torch.zeros(256 * 64, dtype=torch.int32, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            mask.copy_(mask0, non_blocking=True)
+            produce_hiz(0, False)
+            c = cctx[0]
+            c.async_triangles, c.share_pass_tests, c.unordered_output = 0, int(use_share[0]), use_unord[0]
+            for k_, flags in enumerate((L.CULL_TEST_ALL, L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+                check(lib.oxc_debug_count_occlusion_candidates(ctxp, C.c_void_p(cnt[k_].data_ptr())))
+                c.cull_flags = flags
+                check(lib.oxc_cull_geometry(ctxp, pf, C.byref(c), sp))
+            check(lib.oxc_debug_count_occlusion_candidates(ctxp, None))
+        torch.cuda.synchronize()
+        occl_candidates = {"early": int(cnt[0].to(torch.int64).sum().item()), "late": int(cnt[1].to(torch.int64).sum().item())}
+        if outputs_checksum() != sum_main and rank == 0:
+            print("[bench] WARNING: the counting instantiations changed an output", file=sys.stderr, flush=True)
+        del cnt
+
     # ---- per-kernel times (>= 50 launches each) and rooflines: algorithmic bytes of SURVEY 8d ----
     if rank == 0 and os.environ.get("OXC_BENCH_TRACE"):
         print("[bench]   kernel profile", file=sys.stderr, flush=True)
@@ -626,10 +653,10 @@ def bench_config3(args, e):
     alg = {  # per launch
         "hiz": hiz_algorithmic_bytes(HW, HW, hiz[0].levels),
         "prepare_instances": M * (212 + 384),
-        # 8 B MeshletInstance + 16 B MeshletBounds per meshlet + the mask word read and written (1/8 B each); the 16*f B of HiZ
-        # taps of SURVEY 8d are left out (f is not observable from the counters): a lower bound, so frac is conservative
-        "cull_meshlets_test": n_meshlets * (24.0 + 0.25),
-        "cull_meshlets_test_late": n_meshlets * (24.0 + 0.25),
+        # 8 B MeshletInstance + 16 B MeshletBounds per meshlet + the mask word read and written (1/8 B each) + SURVEY 8d's 16 f: four
+        # pyramid taps per candidate that reaches test_occlusion (counted above; round 4 left them out)
+        "cull_meshlets_test": n_meshlets * (24.0 + 0.25) + 16.0 * (occl_candidates["early"] or 0),
+        "cull_meshlets_test_late": n_meshlets * (24.0 + 0.25) + 16.0 * (occl_candidates["late"] or 0),
         "cull_meshlets_emit": n_meshlets / 8.0 + 4.0 * v_early,
         "cull_meshlets_emit_late": n_meshlets / 8.0 + 4.0 * v_late,
         "cull_triangles_test": v_early * (tri_bytes_per_meshlet + 8.0 * H),
@@ -643,14 +670,16 @@ def bench_config3(args, e):
     # the second clock: the committed rocprofv3 --kernel-trace --stats averages of the same kernels (of the build the profile was taken
     # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
     # (the committed profiles are of the default workload: T = 64, ordered lists; any other shape has no counters of its own and says so)
-    prof_names = ["r04_config3_pmc.json"] if (not wide and not args.small_triangle_cull and main_unord == 1 and main_share and n_meshlets == 10_000_000) else []
+    std_shape = not args.small_triangle_cull and main_unord == 1 and main_share
+    prof_names = (["r05_config3_pmc.json", "r04_config3_pmc.json"] if (std_shape and not wide and n_meshlets == 10_000_000) else
+                  ["r05_tris124_pmc.json"] if (std_shape and wide and n_meshlets == 8_000_000) else [])
     rp = rocprof_kernel_us(prof_names) if prof_names else {}
     rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
                 "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
                 "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
                 "cull_meshlets_emit": ["oxc::k_cull_meshlets_emit<true, false>"], "cull_meshlets_emit_late": ["oxc::k_cull_meshlets_emit<true, true>"],
-                "cull_triangles_test": ["oxc::k_cull_triangles_fused<false, false, false>" if main_unord else "oxc::k_cull_triangles_test<false, false, false>"],
-                "cull_triangles_test_late": ["oxc::k_cull_triangles_fused<true, false, false>" if main_unord else "oxc::k_cull_triangles_test<true, false, false>"],
+                "cull_triangles_test": [f"oxc::k_cull_triangles_fused_select<false, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<false, {str(wide).lower()}, false>"],
+                "cull_triangles_test_late": [f"oxc::k_cull_triangles_fused_select<true, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<true, {str(wide).lower()}, false>"],
                 "cull_triangles_emit": ["oxc::k_cull_triangles_emit<false, false>"], "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit<true, false>"]}
     kernels, frame_alg, frame_kernel_us = {}, 0.0, 0.0
     for name, k in kern.items():
@@ -677,9 +706,9 @@ def bench_config3(args, e):
         dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
         dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        dom_name = "k_cull_triangles_fused" if main_unord else "k_cull_triangles_test"
+        dom_name = "k_cull_triangles_fused_select" if main_unord else "k_cull_triangles_test"
         traffic, traffic_src, traffic_same = pmc_traffic(prof_names, lambda k: dom_name in k) if prof_names else (None, None, None)
-        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + ("; test + expansion in one launch: 988 B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
+        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + (f"; ids from the meshlet test's ballots, test + expansion in one launch: {tri_bytes_per_meshlet} B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
                     "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_profile_is_of_this_device_code": traffic_same, "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
@@ -688,7 +717,8 @@ def bench_config3(args, e):
     stage = {"algorithmic_bytes_per_frame": round(frame_alg), "ms_per_frame": round(ms_per_frame, 6),
              "achieved_GBps": round(frame_alg / (ms_per_frame * 1e-3) / 1e9, 1), "stage_frac": round(frame_alg / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
              "sum_of_kernel_us_per_frame": round(frame_kernel_us, 1),
-             "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures, HiZ taps excluded.  "
+             "occlusion_candidates": occl_candidates,
+             "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures incl. 16 B of pyramid taps per occlusion candidate (counted).  "
                      "With share_pass_tests the late meshlet test is still CHARGED the reference's 24.25 B per meshlet although it fetches ~14.7 (no MeshletInstance "
                      "record and no bounds for steps nothing of which passed the camera tests): ~95 MB of the frame's algorithmic bytes, and that kernel's frac, are the "
                      "reference's traffic, not this kernel's (SURVEY 8d defines algorithmic bytes by the reference's data flow)"}
@@ -1003,7 +1033,7 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
         bytes_per_launch = n_meshlets * batch * (24.0 + 212.0 / K + 0.125)
         us = kern["cull_meshlets_test"]["avg_us"]
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
-        traffic, src, traffic_same = pmc_traffic(["r03_config2_pmc.json", "r02_config2_pmc.json", "r01_config2_pmc.json"], lambda k: "k_cull_meshlets_test_batch" in k)
+        traffic, src, traffic_same = pmc_traffic(["r05_config2_pmc.json", "r04_config2_pmc.json"], lambda k: "k_cull_meshlets_test_batch" in k)
         roofline = {"bound": "hbm", "kernel": f"k_cull_meshlets_test_batch ({batch} frames per launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, "traffic_profile_is_of_this_device_code": traffic_same,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
@@ -1052,15 +1082,13 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
 # ------------------------------------------------------------------------------------------------------------------
 # configs[0]: ~1k entities, ECS transform update + host AABB frustum test (CPU only, the reference's own runnable case)
 # ------------------------------------------------------------------------------------------------------------------
-def bench_config1(args):
+def measure_config1(args, seconds: float) -> dict:
     """BASELINE configs[0].  No GPU: the engine's coarse cull is host code (Scene.cpp:1690-1740 world-matrix chain through
     parents, BoundingVolume.cpp:32-53 AABB::get_transformed, :72-88 AABB::is_on_frustum against Camera::get_frustum,
     Camera.cpp:57-74).  The scalar C restatement (oracle/) IS the implementation measured here -- there is no HIP path for
     1 000 entities (one launch costs more than the whole update) -- so this line carries no roofline.  All-core figure: one
-    independent 1 000-entity scene per host thread."""
+    independent 1 000-entity scene per host thread.  `seconds`: CPU time budget of the two timed runs together."""
     import threading
-
-    import numpy as np
 
     import oracle
     from oxylus_amd.synth import camera_frustum_planes, make_entities
@@ -1073,7 +1101,7 @@ def bench_config1(args):
     t0 = time.perf_counter()
     oracle.entities_update_and_cull(trs, parent, aabb, planes, passes=200)
     per_pass = (time.perf_counter() - t0) / 200
-    passes = int(max(200, min(args.cpu_seconds / 2 / per_pass, 5_000_000)))
+    passes = int(max(200, min(seconds / 2 / per_pass, 5_000_000)))
     t0 = time.perf_counter()
     oracle.entities_update_and_cull(trs, parent, aabb, planes, passes=passes)
     dt1 = time.perf_counter() - t0
@@ -1086,15 +1114,60 @@ def bench_config1(args):
         t.join()
     dtn = time.perf_counter() - t0
     one, allc = n * passes / dt1, n * passes * cores / dtn
-    print(json.dumps({
+    return {
         "metric": "entities/s (ECS transform update + AABB frustum test, host)", "value": round(allc, 1), "unit": "entities/s", "n_gpus": 0, "steps": passes,
         "warmup": 200, "ms_per_step": round(dtn / passes * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[0]: {n} entities in parent chains of depth 3: world = parent * T*R*S, world AABB = baked.get_transformed(world), "
                                "AABB::is_on_frustum against Camera::get_frustum (60 deg, 16:9, 0.1..1000)", "entities": n, "visible": nvis, "threads": cores,
                    "scenes_in_flight": cores},
-        "single_thread_value": round(one, 1), "roofline": None,
+        "single_thread_value": round(one, 1), "ms_per_update_one_thread": round(dt1 / passes * 1e3, 6), "roofline": None,
         "cpu_baseline": {"value": round(one, 1), "unit": "entities/s", "cores": 1, "kind": "port",
-                         "sample": f"{passes} updates of the same {n}-entity scene, oracle/oxcull_oracle.c orc_entities_update_and_cull, one thread, {dt1:.1f} s"}}))
+                         "sample": f"{passes} updates of the same {n}-entity scene, oracle/oxcull_oracle.c orc_entities_update_and_cull, one thread, {dt1:.1f} s"}}
+
+
+def bench_config1(args):
+    print(json.dumps(measure_config1(args, args.cpu_seconds)))
+
+
+def line_summary(line: dict) -> dict:
+    """The nested figures of the default line once more, compact, as its LAST key: the driver keeps the tail of stdout (round-4 review:
+    the nested tris124 / configs1 / configs4 values were in no driver-held record)."""
+    def g(d, *path, nd=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return round(d, nd) if (nd is not None and isinstance(d, float)) else d
+
+    sm = {"ms_per_frame": g(line, "config", "ms_per_frame", nd=4), "stage_frac": g(line, "stage", "stage_frac"), "roofline_frac": g(line, "roofline", "frac"),
+          "bit_match": line.get("bit_match"), "hiz_bit_match": line.get("hiz_bit_match")}
+    for v in g(line, "scheduling_ab", "variants") or []:
+        key = ("defaults_ms_per_frame" if v.get("library_defaults") else
+               "ordered_shared_ms" if (v["unordered_output"] == 0 and v["share_pass_tests"] and not v["async_triangles"] and not v["hiz_one_frame_ahead_on_second_stream"]) else
+               "unordered_unshared_ms" if (v["unordered_output"] == 1 and not v["share_pass_tests"] and not v["async_triangles"] and not v["hiz_one_frame_ahead_on_second_stream"]) else None)
+        if key:
+            sm[key] = round(v["ms_per_frame"], 4)
+            sm.setdefault("variants_match", True)
+            sm["variants_match"] = bool(sm["variants_match"] and v["outputs_match_main_line"])
+    if "tris124" in line:
+        sm["tris124"] = {"ms_per_frame": g(line, "tris124", "ms_per_frame", nd=4), "frac": g(line, "tris124", "roofline", "frac"), "stage_frac": g(line, "tris124", "stage", "stage_frac"),
+                         "traffic": g(line, "tris124", "roofline", "traffic"), "bit_match": g(line, "tris124", "bit_match")}
+    if "configs1" in line:
+        c1 = line["configs1"]
+        sm["configs1"] = {"batched_frac": g(c1, "roofline", "frac"), "batched_stage_frac": g(c1, "batched", "stage_frac"), "value": g(c1, "batched", "value"),
+                          "one_call_us": round(1e3 * c1["one_call_per_frame_unordered"]["ms_per_frame"], 2), "one_call_frac": g(c1, "one_call_per_frame_unordered", "stage_frac"),
+                          "one_call_launches": g(c1, "one_call_per_frame_unordered", "launches_per_call"),
+                          "bit_match": bool(c1.get("bit_match") and c1["one_call_per_frame_unordered"].get("sorted_list_equals_the_checkers"))}
+    if "configs4" in line:
+        c4 = line["configs4"]
+        sm["configs4"] = {"ms_per_step": g(c4, "ms_per_step", nd=4), "value": g(c4, "value"), "frac": g(c4, "roofline", "frac"), "stage_frac": g(c4, "stage", "stage_frac"),
+                          "lists": g(c4, "config", "meshlet_instance_lists"), "bit_match": c4.get("bit_match")}
+    if "configs0" in line:
+        sm["configs0"] = {"entities_per_s": g(line, "configs0", "value"), "cores": g(line, "configs0", "config", "threads"), "one_core": g(line, "configs0", "single_thread_value"),
+                          "ms_per_update_one_thread": g(line, "configs0", "ms_per_update_one_thread")}
+    if "real_geometry" in line:
+        sm["real_geometry"] = {"ms_per_frame": g(line, "real_geometry", "ms_per_frame", nd=4), "bit_match": g(line, "real_geometry", "bit_match")}
+    return sm
 
 
 def main():
@@ -1163,7 +1236,11 @@ def main():
 
             stage_note("real_geometry")
             line["real_geometry"] = bench_aux.bench_real_geometry(args, e.r, e.dev, e.stream, e.rank)
+        if e.world == 1 and not args.no_configs0:
+            stage_note("configs0")
+            line["configs0"] = measure_config1(args, min(args.cpu_seconds, 2.0))  # BASELINE configs[0]: CPU only by definition, milliseconds per update
         if e.rank == 0:
+            line["summary"] = line_summary(line)  # LAST key: lands in the tail of stdout
             print(json.dumps(line))
     if e.dist is not None:
         e.dist.destroy_process_group()

@@ -188,13 +188,16 @@ typedef struct oxc_cull_geometry_context {
    * 64-thread workgroup in cull_meshlets.slang:55-70 and cull_triangles.slang:71-88, two per visible thread in
    * cull_meshlets_hiz.slang:67-78 -- so its order is whatever the race gives.
    *   0 (default) = ascending lists, deterministic: test -> ballots -> ordered emit, two launches per stage.
-   *   1 = unordered where that is the faster form on this part: the triangle stage is ONE launch (a block tests a span of 256 visible
-   *       meshlets and appends its packed indices behind one atomic_add on index_count), the plain meshlet stage (no use_hiz / use_hpb)
-   *       is one launch (one atomic_add on cull_triangles_cmd.x per 1024 meshlets); the HiZ / HPB meshlet stages keep the ordered
-   *       two-launch form (their per-wave-step appends would queue on one address: see 2).
-   *   2 = as 1, and the HiZ meshlet stage also appends by itself: one atomic_add pair per wave step (256 meshlets) with a survivor on
-   *       the early / late counter and cull_triangles_cmd.x -- the reference's literal scheme aggregated through the ballot; a single
-   *       address retires ~88 atomics per microsecond on MI355X, which is what this form measures.  share_pass_tests is ignored.
+   *   1 = unordered where that is the faster form on this part: the triangle stage is ONE launch (a block tests a span of visible
+   *       meshlets -- implementation-defined, currently 128 -- and appends its packed indices behind one atomic_add on index_count);
+   *       the plain meshlet stage (no use_hiz / use_hpb) is one launch (one atomic_add on cull_triangles_cmd.x per 1024 meshlets).
+   *       The HiZ / HPB meshlet stages keep their ASCENDING visible list; when the triangle stage of the same in-order call follows
+   *       a HiZ meshlet stage, no meshlet emit kernel is launched either -- the fused triangle kernel finds the ids of its spans from
+   *       the meshlet test's ballots and writes that ascending list itself (same bytes).
+   *   Any other value returns OXC_INVALID_ARG.  (Rounds 4 built "2": the HiZ meshlet tests appending with one atomic_add pair per
+   *   256-meshlet wave step, the reference's literal scheme aggregated through the ballot -- 150 / 154 us per launch against 79 + 11 /
+   *   66 + 11 for test + ordered emit, every step queueing on two addresses that retire ~88 atomics per microsecond; removed in round 5,
+   *   the measurement is in DESIGN.md.)
    * Inside a block's run the ids ascend; the runs land in arrival order.  A triangle's three packed indices stay adjacent.  Sorting a
    * list gives the bytes of the ordered form (tests/test_gpu_unordered.py).  Ignored by oxc_cull_geometry_batch's fused path. */
   uint32_t unordered_output;
@@ -598,6 +601,12 @@ enum { OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU = 0, OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU 
        OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */,
        OXC_TUNE_FUSED_SELECT = 4 /* 0: the HiZ meshlet stage keeps its emit launch in front of the fused triangle kernel (default 1: the fused kernel finds its ids itself) */ };
 oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value);
+
+/* Measurement aid: counters_dptr != NULL -- the HiZ calls (use_hiz + OXC_CULL_TEST_OCCLUSION) that follow on this context run counting
+ * instantiations of their meshlet test, which ADD the number of candidates that reach test_occlusion (cull_meshlets_hiz.slang:53-65:
+ * SURVEY 8d's f, four pyramid taps = 16 B each) to 256 u32 counters 256 bytes apart (u32[256 * 64], caller-zeroed; their sum is the
+ * count).  Same outputs, slower kernels: not for timed runs.  NULL switches it off again. */
+oxc_status oxc_debug_count_occlusion_candidates(oxc_ctx* ctx, void* counters_dptr);
 
 /* Test hook: what the last oxc_draw_visbuffer on this context did with its triangles; synchronises the stream.
  * out4 = {triangles queued for the big path (pixel box beyond 8 x 8), triangles that crossed a clip plane, 64 x 64 tiles handed to

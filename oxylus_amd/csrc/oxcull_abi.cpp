@@ -127,6 +127,7 @@ struct oxc_ctx {
   // overrides the defaults (tuning aid of tools/kbench.py)
   uint32_t async_mtest_per_cu = kAsyncMeshletBlocksPerCU, async_tri_per_cu = kAsyncTriangleBlocksPerCU;
   uint32_t tri_blocks_per_cu = kTriangleBlocksPerCU;  // grid cap of the triangle kernels (blocks walk their chunks with a grid stride)
+  uint32_t* dbg_occlusion = nullptr;  // oxc_debug_count_occlusion_candidates: 256 strided counters the counting instantiations of the HiZ meshlet tests add to
   uint32_t fused_select = 1;  // oxc_debug_set_tuning(OXC_TUNE_FUSED_SELECT, 0): keep the meshlet emit launches in front of the fused triangle kernel (A/B aid)
   // profiling (oxc_profile_begin/end)
   bool profiling = false;
@@ -381,7 +382,7 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visibility mask buffer missing or < ceil(N/32)*4 bytes");
   }
   if (c->small_triangle_cull > 1u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: small_triangle_cull must be 0 or 1");
-  if (c->share_pass_tests > 1u || c->unordered_output > 2u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: share_pass_tests must be 0 or 1, unordered_output 0, 1 or 2");
+  if (c->share_pass_tests > 1u || c->unordered_output > 1u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: share_pass_tests must be 0 or 1, unordered_output 0 or 1");
   if (c->implicit_meshlet_instances > 1u || c->_reserved1 != 0u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: implicit_meshlet_instances must be 0 or 1, _reserved1 0");
   if (c->meshlet_instance_runs_buffer.dptr && c->meshlet_instance_runs_buffer.bytes < (uint64_t)M * 8u)
     return fail(ctx, OXC_INVALID_ARG, "cull_geometry: meshlet_instance_runs_buffer < 8 bytes per mesh instance");
@@ -602,7 +603,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   const uint32_t mask_bits = (uint32_t)std::min<uint64_t>(f->meshlet_instance_visibility_mask_buffer.bytes / 4u * 32u, 0xFFFFFFFEull);
   // unordered_output (include/oxcull.h): which stages append by themselves
   const bool unord_tris = c->unordered_output != 0u && do_tris;
-  const bool unord_meshlets = do_meshlets && !c->use_hpb && ((c->unordered_output != 0u && !c->use_hiz) || (c->unordered_output == 2u && c->use_hiz));
+  const bool unord_meshlets = do_meshlets && !c->use_hpb && !c->use_hiz && c->unordered_output != 0u;  // (the plain meshlet test appends by itself)
   if (c->use_hiz && occl && c->share_pass_tests && do_meshlets && !unord_meshlets) {
     oxc_ctx::SharedTests now;
     now.N = N;
@@ -680,7 +681,6 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   pa.do_cull_meshes = do_meshes ? 1u : 0u;
   pa.init_vis = c->init_cull_meshes ? 1u : 0u;
   pa.seed_total = 0;
-  pa.zero_vis = (unord_meshlets && c->use_hiz) ? (late ? 2u : 3u) : 0u;  // the appending HiZ kernels add to the early / late counter
   pa.cam = c->cull_camera;
   pa.clipmaps = static_cast<const oxc_virtual_clipmap*>(c->vsm_clipmaps_buffer.dptr);
   pa.view_cache = ctx->lane[0].view_cache;
@@ -781,6 +781,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     }
     ta.near_clip = c->cull_camera.near_clip;
     std::memcpy(ta.cam_pos, c->cull_camera.position, 12);
+    ta.dbg_occlusion = ctx->dbg_occlusion;  // (oxc_debug_count_occlusion_candidates; null unless a measurement asked for it)
     if (share_mode) {  // include/oxcull.h: the late call of a frame reuses the early call's frustum + cone results (decided above)
       ta.share = share_mode;
       ta.camera_test_bits = ctx->lane[0].camera_test_bits;
@@ -790,7 +791,6 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     if (unord_meshlets) {  // the test kernel appends: it writes the visible list (wait for the stages that still read it) and both counters
       ta.out = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
       ta.count_a = tri_cmd;
-      ta.count_b = c->use_hiz ? vis + (late ? 2 : 1) : nullptr;
       oxc_status wst = wait_for_visible_list(vis);
       if (wst != OXC_OK) return wst;
       KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
@@ -1720,6 +1720,12 @@ oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
       return OXC_OK;
     default: return fail(ctx, OXC_INVALID_ARG, "set_tuning: unknown knob");
   }
+}
+
+oxc_status oxc_debug_count_occlusion_candidates(oxc_ctx* ctx, void* counters_dptr) {
+  if (!ctx) return OXC_INVALID_ARG;
+  ctx->dbg_occlusion = static_cast<uint32_t*>(counters_dptr);
+  return OXC_OK;
 }
 
 oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32_t* host_out, void* hip_stream) {

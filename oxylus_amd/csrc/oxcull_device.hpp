@@ -327,9 +327,6 @@ OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
 // likewise -- the same floats as the 24 divisions and 48 min / max of the general path (up to the sign of a zero, which neither
 // q * 0.5 + 0.5 nor the depth comparison sees) for 36 instructions.  Lanes whose sums could leave the finite range (any |P0| + |SX| +
 // |SY| + |SZ| above 2^120, or a NaN) send the wave down the general path.  (tests: test_project_aabb_matches_ieee_division_bit_for_bit)
-#ifndef OXC_PROJ_LEAN
-#define OXC_PROJ_LEAN 0
-#endif
 template <bool TRY_AFFINE = false>
 OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez, float* out) {
   float SX[4], SY[4], SZ[4], P[8][4];
@@ -364,94 +361,6 @@ OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy,
     SZ[i] = OXC_M(mvp, i, 2) * ez;
     P[0][i] = ((OXC_M(mvp, i, 0) * p0x + OXC_M(mvp, i, 1) * p0y) + OXC_M(mvp, i, 2) * p0z) + OXC_M(mvp, i, 3);
   }
-#if OXC_PROJ_LEAN
-  // Round 5: the same quotients without ever holding the eight corners (32 VGPRs).  Corner (bx, by, bz) is
-  // fl(fl(fl(P0 + bx SX) + by SY) + bz SZ) with "+ 0" exact; rounding is monotone in each addend, so the component-wise minimum / maximum
-  // over the corners is ((P0 + min(0, SX)) + min(0, SY)) + min(0, SZ) (/ max) -- the orthographic branch above rests on the same identity --
-  // which gives depth = min w and the window test from 16 held values; the corners are then formed one at a time, in the fold order of the
-  // code below (7, 6, 5, 4, 3, 2, 1, 0; each by the additions that define it: P4 = P0 + SX, P6 = P4 + SY, P7 = P6 + SZ, P5 = P4 + SZ,
-  // P2 = P0 + SY, P3 = P2 + SZ, P1 = P0 + SZ).  The window's |z| >= 2^-60 becomes "the z numerators do not straddle zero and the one
-  // nearest zero is >= 2^-60": a box whose z numerators change sign takes the IEEE divisions (same quotients, by the argument below).
-  {
-    float clo[4], chi[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      clo[i] = ((P[0][i] + fminf(SX[i], 0.0f)) + fminf(SY[i], 0.0f)) + fminf(SZ[i], 0.0f);
-      chi[i] = ((P[0][i] + fmaxf(SX[i], 0.0f)) + fmaxf(SY[i], 0.0f)) + fmaxf(SZ[i], 0.0f);
-    }
-    const float depth = clo[3];
-    if (depth < near_clip) return false;
-    const float amax = fmaxf(fmaxf(fmaxf(__builtin_fabsf(clo[0]), __builtin_fabsf(chi[0])), fmaxf(__builtin_fabsf(clo[1]), __builtin_fabsf(chi[1]))),
-                             fmaxf(__builtin_fabsf(clo[2]), __builtin_fabsf(chi[2])));
-    const float zmin = clo[2] > 0.0f ? clo[2] : (chi[2] < 0.0f ? -chi[2] : 0.0f);
-    const bool in_window = amax <= 1.152921504606846976e18f && zmin >= 8.673617379884035e-19f && depth >= 9.313225746154785e-10f &&
-                           chi[3] <= 1.152921504606846976e18f;
-    const bool fast = __builtin_amdgcn_ballot_w64(!in_window) == 0;
-    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
-    auto visit = [&](const float* c, bool first) {  // c = {x, y, z, w} of one corner
-      float qx, qy, qz;
-      if (fast) {  // (wave-uniform)
-        const float w = c[3];
-        const float r0 = __builtin_amdgcn_rcpf(w);
-        const float e = __builtin_fmaf(-w, r0, 1.0f);
-        const float r = __builtin_fmaf(e, r0, r0);
-        const f2 n = {c[0], c[1]};
-        const f2 nw = splat(-w), rr = splat(r);
-        f2 q = n * rr;
-        f2 e1 = __builtin_elementwise_fma(nw, q, n);
-        q = __builtin_elementwise_fma(e1, rr, q);
-        e1 = __builtin_elementwise_fma(nw, q, n);
-        q = __builtin_elementwise_fma(e1, rr, q);
-        const float nz = c[2];
-        float z = nz * r;
-        float ez2 = __builtin_fmaf(-w, z, nz);
-        z = __builtin_fmaf(ez2, r, z);
-        ez2 = __builtin_fmaf(-w, z, nz);
-        z = __builtin_fmaf(ez2, r, z);
-        qx = q.x, qy = q.y, qz = z;
-      } else {
-        qx = c[0] / c[3], qy = c[1] / c[3], qz = c[2] / c[3];
-      }
-      if (first) {
-        lo[0] = hi[0] = qx, lo[1] = hi[1] = qy, lo[2] = hi[2] = qz;
-      } else {
-        lo[0] = fminf(qx, lo[0]), hi[0] = fmaxf(qx, hi[0]);
-        lo[1] = fminf(qy, lo[1]), hi[1] = fmaxf(qy, hi[1]);
-        lo[2] = fminf(qz, lo[2]), hi[2] = fmaxf(qz, hi[2]);
-      }
-    };
-    float A[4], B[4], C[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) A[i] = P[0][i] + SX[i];  // P4
-#pragma unroll
-    for (int i = 0; i < 4; i++) B[i] = A[i] + SY[i];     // P6
-#pragma unroll
-    for (int i = 0; i < 4; i++) C[i] = B[i] + SZ[i];     // P7
-    visit(C, true);
-    visit(B, false);
-#pragma unroll
-    for (int i = 0; i < 4; i++) C[i] = A[i] + SZ[i];     // P5
-    visit(C, false);
-    visit(A, false);
-#pragma unroll
-    for (int i = 0; i < 4; i++) B[i] = P[0][i] + SY[i];  // P2
-#pragma unroll
-    for (int i = 0; i < 4; i++) C[i] = B[i] + SZ[i];     // P3
-    visit(C, false);
-    visit(B, false);
-#pragma unroll
-    for (int i = 0; i < 4; i++) C[i] = P[0][i] + SZ[i];  // P1
-    visit(C, false);
-    visit(P[0], false);
-    out[0] = lo[0] * 0.5f + 0.5f;
-    out[1] = lo[1] * 0.5f + 0.5f;
-    out[2] = lo[2];
-    out[3] = hi[0] * 0.5f + 0.5f;
-    out[4] = hi[1] * 0.5f + 0.5f;
-    out[5] = hi[2];
-    return true;
-  }
-#endif
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     P[1][i] = P[0][i] + SZ[i];

@@ -94,8 +94,6 @@ OXC_DEV void prepare_body(const PrepareArgs& a, const uint32_t view) {
       a.meshlets_cmd[1] = 1;
       a.meshlets_cmd[2] = 1;
     }
-    if (a.zero_vis & 1u) a.vis[1] = 0;  // the appending HiZ kernels ADD to the counters (unordered_output = 2)
-    if (a.zero_vis & 2u) a.vis[2] = 0;
   }
   if (main_view) {
     for (uint32_t i = tid; i < a.n_supers_meshlets; i += nthreads) a.supers_meshlets[i * kSuperStride] = 0;
@@ -632,7 +630,10 @@ OXC_DEV void meshlets_plain_body(const MeshletTestArgs& a) {
 // instance: its InstCache row, mask words and pyramid texels stay in the L2 of the XCD the counter's blocks run on; measured ~1 %).
 constexpr uint32_t kTicketRun = 4;
 OXC_DEV uint32_t OXC_TICKET_STEP(uint32_t t, uint32_t K, uint32_t x) { return ((t / kTicketRun) * K + x) * kTicketRun + t % kTicketRun; }
-template <bool OCCL, bool LATE, int G, int SHARE = 0, bool UNORD = false>
+// COUNT (measurement aid, oxc_debug_count_occlusion_candidates): the same kernel also adds the number of candidates that reach
+// test_occlusion -- SURVEY 8d's f, each costs four pyramid taps = 16 B -- to MeshletTestArgs::dbg_occlusion; a separate instantiation,
+// so that the kernels that are timed do not carry the pointer.
+template <bool OCCL, bool LATE, int G, int SHARE = 0, bool COUNT = false>
 OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   // SHARE (only with OCCL, G == 4): 1 = early call that also runs the cone test for the meshlets that were not visible last frame and
   // publishes the "passed frustum and cone" ballots and each step's mask run, 2 = late call that takes both from the early call of the
@@ -685,8 +686,6 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
   // this part (one counter: 520 us per launch), hence many counters: 8 -> 116 us, 32 -> 82, 256 -> 79 (fixed stride: 87), 512 -> 83;
   // two steps per ticket or drawing the ticket later in the step are worse (config 3, early pass; the late pass 113 -> 101 us).
   const uint32_t nsteps = nchunks * kWaves;
-  const uint32_t out_first = (UNORD && LATE) ? gptr(a.vis)[1] : 0u;  // the late list follows the early one (cull_meshlets_hiz.slang:73)
-  (void)out_first;
   const uint32_t K = min(kTicketCounters, gridDim.x), kx = blockIdx.x % K;  // every counter in use has at least one block drawing from it
   uint32_t* const ticket = a.tickets ? a.tickets + kx * kSuperStride : nullptr;
   auto draw_ticket = [&]() -> uint32_t {
@@ -895,6 +894,9 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
           }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if constexpr (COUNT) {
+            if (nb && lane == 0) __hip_atomic_fetch_add(gptr(a.dbg_occlusion) + (step & 255u) * kSuperStride, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (nb) {
             float mvp[16];
 #pragma unroll
@@ -1012,10 +1014,8 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       }
     }
     uint32_t cnt = 0;
-    uint64_t ebits[UNORD ? G : 1];
 #pragma unroll
     for (int j = 0; j < G; j++) {
-      if constexpr (UNORD) ebits[j] = 0ull;
       if (group0 + j >= nwords) continue;  // wave-uniform
       const bool visible = (st[j] & 2u) != 0u;
       // Every mask read of this wave step precedes its writes.  With TestOcclusion off the
@@ -1023,31 +1023,14 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
       if (OCCL && !step_run) update_visibility_mask(a.mask, mask_idx[j], visible, (group0 + j) * 64 + lane < N && mask_idx[j] != kMaskNone, lane);
       const bool emit = visible && (!LATE || (st[j] & 4u) == 0u);
       const uint64_t bits = __builtin_amdgcn_ballot_w64(emit);
-      if constexpr (UNORD)
-        ebits[j] = bits;
-      else if (lane == 0)
-        gptr(a.bits)[group0 + j] = bits;
+      if (lane == 0) gptr(a.bits)[group0 + j] = bits;
       cnt += (uint32_t)__popcll((unsigned long long)bits);
     }
-    if constexpr (UNORD) {
-      // unordered_output = 2: the reference's own slot allocation (cull_meshlets_hiz.slang:67-78: an atomic_add on the early / late counter
-      // and one on cull_triangles_cmd.x per visible THREAD), aggregated to one pair per wave step through the ballots.  Every step
-      // with a survivor queues on the same two addresses (~88 atomics per microsecond each): the measured cost of the literal scheme.
-      if (cnt) {  // (wave-uniform)
-        uint32_t at = 0;
-        if (lane == 0) {
-          at = __hip_atomic_fetch_add(gptr(a.count_b), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add(gptr(a.count_a), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        at = readfirst_u(at) + out_first;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          if ((ebits[j] >> lane) & 1ull)
-            gptr(a.out)[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(ebits[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ebits[j], 0u))] = (group0 + j) * 64 + (uint32_t)lane;
-          at += (uint32_t)__popcll((unsigned long long)ebits[j]);
-        }
-      }
-    } else if (lane == 0 && group0 < nwords) {
+    // (Round 4 also built the reference's literal slot allocation here -- cull_meshlets_hiz.slang:67-78: an atomic_add on the early / late
+    // counter and one on cull_triangles_cmd.x, aggregated to one pair per wave step through the ballots -- as unordered_output = 2:
+    // 150 / 154 us per launch against 79 + 11 / 66 + 11 for this kernel + the ordered emit; every step with a survivor queues on the same
+    // two addresses.  Removed in round 5: git log -S count_b.)
+    if (lane == 0 && group0 < nwords) {
       gptr(a.chunk_counts)[step] = cnt;
       if (cnt) __hip_atomic_fetch_add(gptr(a.supers) + (step / kChunksPerSuper) * kSuperStride, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1406,21 +1389,13 @@ constexpr uint32_t kEmitRun = OXC_EMIT_RUN;  // dwords a wave stages between flu
 #ifndef OXC_FUSED_RUN
 #define OXC_FUSED_RUN 768
 #endif
-// ... and in the fused triangle kernel of round 5 (FMODE 2 / 3), whose block also holds the prefix of the meshlet stage's sums: 8 blocks per CU
+// ... and in the select form of the fused triangle kernel, whose block also holds the prefix of the meshlet stage's sums (4 KB): 8 blocks per CU
 // have 20 KB of LDS each.  (Run length 512 / 1024 / 2048 dwords measured in round 4: 549 / 548 / 544 us per frame.)
 constexpr uint32_t kFusedRun = OXC_FUSED_RUN;
-#ifndef OXC_FUSED_TICKETS
-#define OXC_FUSED_TICKETS 1  // the round-4 structure with the spans after a block's first drawn from TriTestArgs::ticket at the span's end (beside the index_count atomic)
-#endif
-#ifndef OXC_FUSED_STATIC_ROUNDS
-#define OXC_FUSED_STATIC_ROUNDS 2  // spans a block takes by its index before it draws tickets (>= 1)
-#endif
-#ifndef OXC_FUSED_OVERLAP
-// What of the next span's fetch chain (ids -> MeshletInstance -> row -> Meshlet record -> indices -> positions) is in flight while the
-// block expands the current span: 0 = nothing, 1 = the MeshletInstance records (two VGPRs held).
-#define OXC_FUSED_OVERLAP 1
-#endif
 static_assert(kFusedRun >= 384u + 3u && kFusedRun % 4u == 0u, "a run holds at least one WIDE slot; rows stay 16-byte aligned");
+#ifndef OXC_FUSED_TICKETS
+#define OXC_FUSED_TICKETS 1  // fused triangle kernel: the spans of the last, partial round of the grid are drawn from TriTestArgs::ticket (tris_test_body)
+#endif
 constexpr uint32_t kSelectMaxSupers = 1024;  // FMODE 3: per-64-step sums a block can scan (4 per thread): 2^24 meshlet instances
 template <int H, uint32_t kCornerBits, uint32_t kRunLen = kEmitRun>
 OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int first_slot, int nslots, uint32_t g0, uint32_t* __restrict__ out, uint32_t* run, int lane) {
@@ -1812,166 +1787,6 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Round 5: the fused triangle kernel (unordered_output; k_cull_triangles_fused above is round 4's form, FMODE 1 here for reference):
-//  * spans beyond OXC_FUSED_STATIC_ROUNDS x the grid are drawn from a ticket counter (one returning atomic per span, read at the span's end);
-//  * the ids of a span sit in LDS (double-buffered): the next span's are fetched beside the index_count atomic's round trip, and the
-//    MeshletInstance records of its first chunk are in flight while the block expands the current span (OXC_FUSED_OVERLAP);
-//  * every wave scans the span's 128 triangle counts itself: one block barrier less per span;
-//  * SELECT: the block finds its ids ITSELF from the meshlet stage's ballots and counts (select_visible_id above) and writes them to
-//    visible_meshlet_instances_indices as a by-product -- the two k_cull_meshlets_emit launches of a frame are gone.
-// Same per-slot pipeline (the .inc files), same bytes per slot; runs land in arrival order, ascending inside a span, like round 4's.
-// ------------------------------------------------------------------------------------------
-template <bool LATE, bool WIDE, bool SMALL, bool SELECT>
-OXC_DEV void tris_fused2_body(const TriTestArgs& a) {
-  set_half_denorm_flush();
-  constexpr int H = WIDE ? 2 : 1;
-  constexpr int S = 16;  // slots per wave per chunk
-  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;
-  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;
-  constexpr int kRecAhead = kIdxAhead + 1;
-  constexpr int kRowAhead = kIdxAhead + 2;
-  typedef const uint32_t __attribute__((address_space(4))) * k32;
-  __shared__ uint32_t s_red[4];
-  constexpr uint32_t kFSpan = kFusedTriSpan;
-  constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;
-  static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
-  constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;  // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
-  constexpr uint32_t kRun = kFusedRun;
-  constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
-  __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];
-  __shared__ uint64_t f_mask[kFSpan * H];
-  __shared__ uint32_t f_id[2u * kFSpan];  // the ids of the span in hand and of the next one
-  __shared__ __attribute__((aligned(16))) uint32_t f_run[4 * (kRun + 8u)];
-  __shared__ uint32_t f_base;
-  __shared__ uint32_t f_next;
-  __shared__ uint32_t s_P[SELECT ? kSelectMaxSupers + 1u : 1u];  // SELECT: exclusive prefix of the meshlet stage's per-64-step sums; s_P[kSelectMaxSupers] = V
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t V = 0, first = 0;  // visible meshlets of this pass; where its list starts (cull_triangles.slang:34-37)
-  uint2 h_rec;  // lanes 0..15: the MeshletInstance records of the wave's 16 slots of the chunk in hand (or, kOverlap: of the next span's first chunk)
-  {
-    // ================= FMODE 2 / 3 =================
-    uint32_t nwords_m = 0;
-    if constexpr (SELECT) {
-      V = build_select_prefix<LATE>(a, s_P, s_red, &nwords_m);
-      first = LATE ? a.vis[1] : 0u;
-    } else {
-      V = a.tri_cmd[0];
-      first = LATE ? a.vis[1] : 0u;
-    }
-    const uint32_t nspans = (V + kFSpan - 1) / kFSpan;
-    uint32_t span = blockIdx.x;
-    if (span >= nspans) return;  // (block-uniform)
-    uint32_t* const sel_scratch = f_run + wave * (kRun + 8u);  // 64 words per wave, free outside the expansion
-    // ids of span `sp` -> f_id[nb]: slot s of the pass's visible list, s clamped to V - 1 (a slot beyond V re-does the last one and
-    // leaves an empty mask).  SELECT also writes them to the visible list (the emit kernel's output, ascending by construction).
-    auto fetch_ids = [&](const uint32_t sp, const uint32_t nb) {
-      if (threadIdx.x < kFSpan) {  // (wave-uniform)
-        const uint32_t raw = sp * kFSpan + threadIdx.x;
-        const uint32_t slot = min(raw, V - 1u);
-        uint32_t id;
-        if constexpr (SELECT) {
-          id = select_visible_id(a.m_bits, s_P, nwords_m, slot, sel_scratch, lane);
-          if (raw < V) gptr(a.visible_w)[first + raw] = id;
-        } else {
-          id = a.visible[first + slot];
-        }
-        f_id[nb * kFSpan + threadIdx.x] = id;
-      }
-    };
-    auto load_hrec = [&](const uint32_t nb, const uint32_t c4) {
-      const uint32_t mli = f_id[nb * kFSpan + c4 * kTriChunk + (uint32_t)(lane & 15) * 4 + wave];
-      h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
-    };
-    uint32_t buf = 0;
-    fetch_ids(span, 0u);
-    __syncthreads();
-    constexpr int kOverlap = OXC_FUSED_OVERLAP;
-    bool staged = false;  // (block-uniform) the first chunk's MeshletInstance records are already in flight
-    // spans [0, kStaticRounds * grid) go by block index (round r of block b: span b + r * grid), the rest by ticket t: span kStaticRounds * grid + t
-    constexpr uint32_t kStaticRounds = OXC_FUSED_STATIC_ROUNDS;
-    uint32_t round = 0;
-    for (;;) {
-      // the span after this one: by block index for the first rounds, then one returning atomic per span on a counter of the call
-      // (TriTestArgs::ticket, zeroed by the prepare kernel).  The answer is read at the end of the span.
-      uint32_t tk = 0;
-      for (uint32_t c4 = 0; c4 < kChunksPerSpan; c4++) {
-        if (!(kOverlap == 1 && c4 == 0u && staged)) load_hrec(buf, c4);
-        const uint32_t slot0 = span * kFSpan + c4 * kTriChunk;  // the chunk's first slot of the visible list
-#include "oxcull_tri_stages.inc"
-#pragma unroll
-        for (int j = 0; j < kRowAhead; j++) stage_row(j);
-#pragma unroll
-        for (int j = 0; j < kRecAhead; j++) stage_rec(j);
-#pragma unroll
-        for (int j = 0; j < kIdxAhead; j++) stage_idx(j);
-#pragma unroll
-        for (int j = 0; j < kPosAhead; j++) stage_pos(j);
-        // (the ticket of the span after this one: drawn behind the last chunk's prologue loads -- a returning atomic in front of them
-        //  holds up wave 0's first counted wait, and 2 048 blocks drawing one at kernel start queue for 26 us on the one address)
-        if (c4 == kChunksPerSpan - 1u && round >= kStaticRounds - 1u && threadIdx.x == 0)
-          tk = __hip_atomic_fetch_add(gptr(a.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t cnt = 0;
-        uint32_t mlo[H], mhi[H];  // lane j: pass mask(s) of slot j
-#pragma unroll
-        for (int h = 0; h < H; h++) mlo[h] = mhi[h] = 0;
-#define OXC_TRI_SLOT0 slot0
-#include "oxcull_tri_slots.inc"
-#undef OXC_TRI_SLOT0
-        (void)cnt;
-        if (lane < S) {  // slot (chunk c4, j = lane, wave) sits at c4 * 64 + j * 4 + wave of the span
-#pragma unroll
-          for (int h = 0; h < H; h++) f_mask[(c4 * kTriChunk + (uint32_t)lane * 4 + wave) * H + h] = (uint64_t)mlo[h] | ((uint64_t)mhi[h] << 32);
-        }
-      }
-      if (threadIdx.x == 0) f_next = round >= kStaticRounds - 1u ? gridDim.x * kStaticRounds + tk : span + gridDim.x;
-      __syncthreads();  // (1) the span's masks and the next span's number are in LDS
-      const uint32_t next = f_next;
-      const bool has_next = next < nspans;  // (block-uniform)
-      // the next span's ids: the waves that own a slot of it (0 and 1 of four when a span is 128) find / load them while wave 3, which owns
-      // none, is already on its way to the index_count atomic below
-      if (has_next) fetch_ids(next, buf ^ 1u);
-      // every wave scans the span's triangle counts itself (kFSpan / 64 wave scans): no hand-off through LDS, no barrier for it
-      uint32_t excl[kFSpan / 64];
-      uint32_t total = 0;
-#pragma unroll
-      for (uint32_t p = 0; p < kFSpan / 64u; p++) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int h = 0; h < H; h++) c += (uint32_t)__popcll((unsigned long long)f_mask[(p * 64u + (uint32_t)lane) * H + h]);
-        const uint32_t incl = wave_incl_scan(c, lane);
-        excl[p] = total + incl - c;
-        total += readlane_u(incl, 63);
-      }
-      uint32_t got = 0;
-      if (threadIdx.x == 255 && total) got = __hip_atomic_fetch_add(gptr(a.draw_cmd), total * 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // DrawIndexedIndirect.index_count
-      if (threadIdx.x == 255) f_base = got;
-      __syncthreads();  // (2) the run's base and the next span's ids are in LDS
-      const uint32_t gbase = f_base;
-      // ---- expansion of the span, the MeshletInstance records of the next span's first chunk in flight behind it.  (Staging the rest of
-      // that chunk's prologue -- rows, Meshlet records, index and position loads -- between four parts of the expansion was built too: the
-      // ~50 SGPRs it holds across the expansion turn into 320-380 SGPR and ~47 VGPR spills in a kernel that has 78 SGPRs at 8 waves per SIMD.)
-      if (kOverlap >= 1 && has_next) load_hrec(buf ^ 1u, 0u);
-      constexpr int kPart = (int)(kFSpan / 16u);
-#pragma unroll
-      for (int part = 0; part < 4; part++) {
-        const int fs = wave * (int)(kFSpan / 4u) + part * kPart;
-        uint32_t e = excl[0];
-#pragma unroll
-        for (uint32_t p = 1; p < kFSpan / 64u; p++) e = (uint32_t)fs >= p * 64u ? excl[p] : e;  // (wave-uniform)
-        const uint32_t off = readlane_u(e, fs & 63);
-        expand_slots_wide<H, kCornerBits, kRun>(f_mask, f_id + buf * kFSpan, fs, kPart, gbase + off * 3u, a.out, f_run + wave * (kRun + 8u), lane);
-      }
-      if (!has_next) break;
-      __syncthreads();  // (3) the span's LDS rows are rewritten by the next span
-      span = next;
-      buf ^= 1u;
-      staged = true;
-      round++;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // Triangle stage, emit kernel: ordered expansion of the pass masks into packed indices
 // (visbuffer.slang:13-14, cull_triangles.slang:82-88) and DrawIndexedIndirect.index_count.
 // ------------------------------------------------------------------------------------------
@@ -2245,14 +2060,8 @@ __global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_c
   else
     meshlets_hiz_body<OCCL, LATE, G>(a);
 }
-// unordered_output: the same bodies appending their survivors themselves (MeshletTestArgs::out)
-template <bool HIZ, bool OCCL, bool LATE, int G = (int)kGroupsPerWave>
-__global__ __launch_bounds__(HIZ ? 1024 / G : 64 * kUnordBlockWaves, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_cull_meshlets_test_unordered(MeshletTestArgs a) {
-  if constexpr (!HIZ)
-    meshlets_plain_body<G, true, kUnordBlockWaves>(a);
-  else
-    meshlets_hiz_body<OCCL, LATE, G, 0, true>(a);
-}
+// unordered_output: the plain body appending its survivors itself (MeshletTestArgs::out)
+__global__ __launch_bounds__(64 * kUnordBlockWaves) void k_cull_meshlets_test_unordered(MeshletTestArgs a) { meshlets_plain_body<(int)kGroupsPerWave, true, kUnordBlockWaves>(a); }
 // the two calls of a frame sharing the frustum test (MeshletTestArgs::share)
 template <bool LATE>
 #ifndef OXC_SHARED_LATE_WAVES
@@ -2269,6 +2078,11 @@ __global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WA
   // this kernel.  Fuller batches (the early call's run at 31 % of the lanes, the late call's at 66 %) do not pay for the deferred finish,
   // the LDS words and a third inlined copy of the batch.  Removed: git log -S meshlets_run_body.)
   meshlets_hiz_body<true, LATE, (int)kHizGroupsPerWave, LATE ? 2 : 1>(a);
+}
+// measurement aid: the occlusion kernels that also count the candidates reaching test_occlusion (MeshletTestArgs::dbg_occlusion)
+template <bool LATE, int SHARE>
+__global__ __launch_bounds__(1024 / kHizGroupsPerWave, 4) void k_cull_meshlets_test_counting(MeshletTestArgs a) {
+  meshlets_hiz_body<true, LATE, (int)kHizGroupsPerWave, SHARE, true>(a);
 }
 template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
@@ -2288,23 +2102,14 @@ template <bool LATE, bool WIDE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
   tris_emit_body<LATE, WIDE>(a);
 }
-#ifndef OXC_FUSED_MODE
-#define OXC_FUSED_MODE 1  // structure of the fused kernel: 1 = round 4 (static span stride; default), 2 = round 5 experiment (tickets + LDS ids + next-span records in flight: measured slower)
-#endif
 template <bool LATE, bool WIDE, bool SMALL>
 __global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused(TriTestArgs a) {
-  if constexpr (OXC_FUSED_MODE == 1)
-    tris_test_body<LATE, WIDE, SMALL, true>(a);
-  else
-    tris_fused2_body<LATE, WIDE, SMALL, false>(a);
+  tris_test_body<LATE, WIDE, SMALL, true>(a);
 }
 // ... and the form that finds its ids itself (TriTestArgs::m_bits != null): no k_cull_meshlets_emit launch precedes it
 template <bool LATE, bool WIDE, bool SMALL>
 __global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused_select(TriTestArgs a) {
-  if constexpr (OXC_FUSED_MODE == 1)
-    tris_test_body<LATE, WIDE, SMALL, true, true>(a);
-  else
-    tris_fused2_body<LATE, WIDE, SMALL, true>(a);
+  tris_test_body<LATE, WIDE, SMALL, true, true>(a);
 }
 
 // Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
@@ -2740,22 +2545,20 @@ static uint32_t resident_grid(K kernel, uint32_t block, uint32_t num_cus) {
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, uint32_t grid_limit, hipStream_t s) {
   constexpr uint32_t hb = 1024 / kHizGroups;
   if (hiz && grid_limit) grid = std::min(grid, grid_limit);
-  if (a.out) {  // unordered_output: the appending instantiations
-    if (!hiz) {
-      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<false, false, false>), dim3((grid * 4 + kUnordBlockWaves - 1) / kUnordBlockWaves), dim3(64 * kUnordBlockWaves), 0, s, a);
-    } else if (occl && late) {
-      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, true, true, kHizGroups>, hb, num_cus);
-      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, true, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
-    } else if (occl) {
-      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, true, false, kHizGroups>, hb, num_cus);
-      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, true, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
-    } else if (late) {
-      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, false, true, kHizGroups>, hb, num_cus);
-      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, false, true, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
-    } else {
-      static const uint32_t cap = resident_grid(k_cull_meshlets_test_unordered<true, false, false, kHizGroups>, hb, num_cus);
-      hipLaunchKernelGGL((k_cull_meshlets_test_unordered<true, false, false, kHizGroups>), dim3(std::min(grid, cap)), dim3(hb), 0, s, a);
-    }
+  if (a.out) {  // unordered_output: the appending instantiation of the plain kernel (the HiZ kernels keep the ordered form)
+    hipLaunchKernelGGL(k_cull_meshlets_test_unordered, dim3((grid * 4 + kUnordBlockWaves - 1) / kUnordBlockWaves), dim3(64 * kUnordBlockWaves), 0, s, a);
+    return;
+  }
+  if (hiz && occl && a.dbg_occlusion) {  // (measurement aid: not a timed path)
+    const dim3 g(std::min(grid, num_cus * 4u)), b(hb);
+    if (a.share == 2)
+      hipLaunchKernelGGL((k_cull_meshlets_test_counting<true, 2>), g, b, 0, s, a);
+    else if (a.share == 1)
+      hipLaunchKernelGGL((k_cull_meshlets_test_counting<false, 1>), g, b, 0, s, a);
+    else if (late)
+      hipLaunchKernelGGL((k_cull_meshlets_test_counting<true, 0>), g, b, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_cull_meshlets_test_counting<false, 0>), g, b, 0, s, a);
     return;
   }
   if (!hiz) {

@@ -34,9 +34,6 @@ struct PrepareArgs {
   uint32_t do_cull_meshes;
   uint32_t init_vis;    // write vis/meshlets_cmd initial values
   uint32_t seed_total;  // initial vis.total (0 for the reference flow)
-  // unordered_output = 2 (the HiZ meshlet tests append with atomics on the visibility counters instead of an emit kernel that stores
-  // the totals): bit 0 = zero vis[1] (early count), bit 1 = zero vis[2] (late count) -- cull_meshlets_hiz.slang:67-78 adds to both
-  uint32_t zero_vis;
   oxc_cull_camera cam;
   // multi-view (use_hpb): blockIdx.y = 1 + v computes rows view_cache[v * M + mi] with
   // clipmaps[v].projection_view_mat in place of the camera matrix
@@ -81,13 +78,12 @@ struct MeshletTestArgs {
   // bits starts; the late call of the same frame reads them instead of testing again.  share: 0 = off, 1 = write them (early call),
   // 2 = read them (late call).
   uint32_t share;
-  // unordered_output (include/oxcull.h): the test kernel appends its survivors itself -- slot allocation by atomic_add as the reference
-  // does (cull_meshlets.slang:55-70, cull_meshlets_hiz.slang:67-78), aggregated per block (plain kernel) or per wave step (HiZ
-  // kernels) through the ballot -- and no emit kernel runs.  out = visible_meshlet_instances_indices, count_a = cull_triangles_cmd.x,
-  // count_b = visibility.early / .late (HiZ kernels; null for the plain kernel).  Null `out`: the ordered two-launch form.
+  // unordered_output (include/oxcull.h), plain kernel only: the test kernel appends its survivors itself -- slot allocation by atomic_add as
+  // the reference does (cull_meshlets.slang:55-70), aggregated per block through the ballots -- and no emit kernel runs.
+  // out = visible_meshlet_instances_indices, count_a = cull_triangles_cmd.x.  Null `out`: the ordered two-launch form.
   uint32_t* out;
   uint32_t* count_a;
-  uint32_t* count_b;
+  uint32_t* dbg_occlusion;     // measurement aid (null: off): 256 counters, stride kSuperStride words, the counting instantiations add the candidates that reach test_occlusion
   uint64_t* camera_test_bits;  // [ceil(N / 64)]
   uint2* step_info;        // [steps]: {first mask bit of the step, 1 if the step's 64 * G meshlets are one run of mask bits}
   const float* hiz_data;
@@ -252,7 +248,6 @@ inline void prepare_args_of(const BatchCore& c, PrepareArgs& pa) {
   pa.do_cull_meshes = c.do_cull_meshes;
   pa.init_vis = c.init_vis;
   pa.seed_total = 0;
-  pa.zero_vis = 0;
   pa.cam = c.cam;
   pa.clipmaps = nullptr;
   pa.view_cache = c.view_cache;
@@ -277,7 +272,8 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   ta.bits = c.bits;
   ta.chunk_counts = c.m_chunk_counts;
   ta.supers = c.m_supers;
-  ta.out = ta.count_a = ta.count_b = nullptr;  // batched elements keep the ordered form
+  ta.out = ta.count_a = nullptr;  // batched elements keep the ordered form
+  ta.dbg_occlusion = nullptr;
   ta.hiz_data = nullptr;
   ta.hiz_w = ta.hiz_h = ta.hiz_levels = ta.hiz_lds_first = 0;
   ta.near_clip = c.cam.near_clip;

@@ -27,7 +27,7 @@ STAGE_MESHLETS = 2
 STAGE_TRIANGLES = 4
 STAGE_ALL = 7
 
-TUNE_ASYNC_MTEST_BLOCKS_PER_CU, TUNE_ASYNC_TRI_BLOCKS_PER_CU, TUNE_RASTER_BIG_CAPACITY, TUNE_TRI_BLOCKS_PER_CU = 0, 1, 2, 3  # oxc_debug_set_tuning knobs
+TUNE_ASYNC_MTEST_BLOCKS_PER_CU, TUNE_ASYNC_TRI_BLOCKS_PER_CU, TUNE_RASTER_BIG_CAPACITY, TUNE_TRI_BLOCKS_PER_CU, TUNE_FUSED_SELECT = 0, 1, 2, 3, 4  # oxc_debug_set_tuning knobs
 
 
 class Buffer(C.Structure):
@@ -276,6 +276,7 @@ EXPORTS = [
     "oxc_debug_read_u32",
     "oxc_debug_shared_tests_mode",
     "oxc_debug_set_tuning",
+    "oxc_debug_count_occlusion_candidates",
     "oxc_debug_project_aabb",
 ]
 
@@ -342,6 +343,7 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_debug_shared_tests_mode.restype = C.c_uint32
     lib.oxc_debug_raster_stats.argtypes = [vp, vp, vp]
     lib.oxc_debug_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.oxc_debug_count_occlusion_candidates.argtypes = [vp, vp]
     lib.oxc_comm_unique_id.argtypes = [vp, vp]
     lib.oxc_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     lib.oxc_comm_destroy.argtypes = [vp]

@@ -154,7 +154,7 @@ class CullGeometryContext:
     small_triangle_cull: bool = False  # extension (north star): also drop triangles whose screen bbox covers no pixel centre
     async_triangles: bool = False  # extension (scheduling only): the triangle stage runs on the context's own stream; RendererInstance.join_triangles
     share_pass_tests: bool = False  # extension (caching only): the late HiZ call of a frame reuses the early call's frustum + cone results (include/oxcull.h)
-    unordered_output: int = 0  # extension (order only): 0 ascending lists, 1 / 2 the reference's atomic slot allocation (include/oxcull.h)
+    unordered_output: int = 0  # extension (order only): 0 ascending lists, 1 the reference's atomic slot allocation where it is faster (include/oxcull.h)
     implicit_meshlet_instances: bool = False  # extension (multi-view batch only): the MeshletInstance list stays implicit, runs in meshlet_instance_runs_buffer
     meshlet_instance_runs_buffer: Optional[torch.Tensor] = None  # int32 [M, 2] {first, count} per mesh instance (out)
     stages: int = 0

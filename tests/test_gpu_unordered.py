@@ -1,5 +1,6 @@
 """GPU: unordered_output (include/oxcull.h) -- the reference's own slot allocation (atomic_add on the counter: cull_meshlets.slang:55-70,
-cull_meshlets_hiz.slang:67-78, cull_triangles.slang:71-88), aggregated per block / wave step through the ballots, one launch per stage.
+cull_triangles.slang:71-88), aggregated per block through the ballots, one launch per stage; the HiZ meshlet stage keeps its ascending list
+and, in front of the fused triangle kernel, launches no emit kernel (the triangle kernel finds its ids from the ballots and writes the list).
 
 SURVEY 8c(1): "counts equal and sorted index arrays byte-identical".  The ordered form emits ascending lists (packed triangle indices
 ascend with (meshlet instance, triangle, corner)), so every list of an unordered call, sorted, must be the checker's bytes; the mask does
@@ -46,42 +47,71 @@ def test_plain_pipeline_unordered_is_the_ordered_set(renderer, oracle_lib, m, k,
     cpu = make_scene(spec, "cpu")
     gpu = cpu.to("cuda")
     want = oracle_frame(cpu)
+    renderer.profile_begin()
     got = gpu_frame(renderer, gpu, unordered_output=1)
+    ran = renderer.profile_end()["kernels"]
+    # the unordered path really ran (a silent fall-back to the ordered kernels would pass every comparison below): no emit launch at all
+    assert "cull_meshlets_emit" not in ran and "cull_triangles_emit" not in ran, sorted(ran)
+    assert ran["cull_meshlets_test"]["launches"] == 1 and ran["cull_triangles_test"]["launches"] == 1, ran
     assert got["visible"].size == want["visible"].size and got["indices"].size == want["indices"].size
     assert_same(want, sorted_lists(got), ["visible", "indices"])
     assert_triangles_adjacent(got["indices"])
+    renderer.profile_begin()
     ordered = gpu_frame(renderer, gpu)
+    ran0 = renderer.profile_end()["kernels"]
+    assert ran0["cull_meshlets_emit"]["launches"] == 1 and ran0["cull_triangles_emit"]["launches"] == 1, ran0
     assert_same(want, ordered, ["visible", "indices"])  # the default stays ascending, unsorted comparison
     if m >= 300:  # the unordered list really is in another order (runs of different blocks land in arrival order) ... usually
         assert want["visible"].size > 64
 
 
-@pytest.mark.parametrize("mode", [1, 2], ids=["triangles-only", "meshlets-too"])
+@pytest.mark.parametrize("select", [True, False], ids=["triangle-kernel-finds-its-ids", "meshlet-emit-kept"])
 @pytest.mark.parametrize("m,k,hw,p_mask,seed,share", [
     (300, 1000, 1024, 0.3, 11, False),  # the bench's shape
-    (300, 1000, 1024, 0.3, 11, True),   # ... with the late call reusing the early call's camera tests (ignored by mode 2)
+    (300, 1000, 1024, 0.3, 11, True),   # ... with the late call reusing the early call's camera tests
     (1500, 37, 512, 0.3, 12, False),    # many instances per wave step
     (7, 333, 256, 0.5, 13, True),       # ragged
     (3, 70, 256, 1.0, 14, False),       # less than one step, everything visible last frame
     (40, 1000, 1024, 0.0, 15, False),   # nothing visible last frame: the early call emits nothing
 ], ids=["bench-shape", "bench-shape-shared", "many-instances-per-step", "ragged-shared", "tiny", "cold-mask"])
-def test_two_pass_hiz_frame_unordered_is_the_ordered_set(renderer, oracle_lib, mode, m, k, hw, p_mask, seed, share):
+def test_two_pass_hiz_frame_unordered_is_the_ordered_set(renderer, oracle_lib, select, m, k, hw, p_mask, seed, share):
+    """Round 5: the fused triangle kernel behind a HiZ meshlet stage finds the ids of its spans itself from the ballots + counts and writes
+    the ascending visible list and the counters as a by-product -- no k_cull_meshlets_emit launch (select); OXC_TUNE_FUSED_SELECT = 0 keeps
+    the emit launch in front of it.  Same bytes either way."""
     spec = SceneSpec(n_mesh_instances=m, meshlets_per_mesh=k, with_geometry=True, seed=seed)
     cpu, gpu, hiz, ohiz, mask = _hiz_setup(renderer, spec, hw, p_mask, seed)
     want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True)
-    got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=mode, share_pass_tests=share)
-    assert_same(want, sorted_lists(got), HIZ_KEYS)
-    for tag in ("early", "late"):
-        if got[f"{tag}_indices"].size:
-            assert_triangles_adjacent(got[f"{tag}_indices"])
-    if mode == 1:  # the HiZ meshlet stage keeps its ordered emit: the visible lists are ascending as they stand
+    renderer.debug_set_tuning(L.TUNE_FUSED_SELECT, 1 if select else 0)
+    try:
+        renderer.profile_begin()
+        got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=1, share_pass_tests=share)
+        ran = renderer.profile_end()["kernels"]
+        assert ("cull_meshlets_emit" in ran) == (not select) and ("cull_meshlets_emit_late" in ran) == (not select), sorted(ran)
+        assert "cull_triangles_emit" not in ran and "cull_triangles_emit_late" not in ran, sorted(ran)
+        assert_same(want, sorted_lists(got), HIZ_KEYS)
+        for tag in ("early", "late"):
+            if got[f"{tag}_indices"].size:
+                assert_triangles_adjacent(got[f"{tag}_indices"])
+        # the visible lists are ascending as they stand (written by the emit kernel or by the triangle kernel)
         assert_same(want, got, ["early_visible", "late_visible"])
         assert got["share_modes"] == ([1, 3] if share else [0, 0])
-    else:
-        assert got["share_modes"] == [0, 0]  # the appending kernels test on their own
-    # a second frame on the same seeded context re-zeroes what the appending kernels add to
-    again = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=mode, share_pass_tests=share)
-    assert_same(want, sorted_lists(again), HIZ_KEYS)
+        # a second frame on the same seeded context re-zeroes what the appending kernels add to
+        again = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=1, share_pass_tests=share)
+        assert_same(want, sorted_lists(again), HIZ_KEYS)
+    finally:
+        renderer.debug_set_tuning(L.TUNE_FUSED_SELECT, 1)
+
+
+def test_unordered_output_values_other_than_0_and_1_are_refused(renderer):
+    """Round 4's mode 2 (the HiZ meshlet tests appending per wave step) was a measured loss and left the boundary in round 5."""
+    spec = SceneSpec(n_mesh_instances=4, meshlets_per_mesh=64, with_geometry=True, seed=3)
+    gpu = make_scene(spec, "cuda")
+    frame = PreparedFrame.create(gpu, with_triangles=True)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(use_hiz=False, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), stages=L.STAGE_ALL, unordered_output=2)
+    renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
+    with pytest.raises(L.OxcError, match="unordered_output"):
+        renderer.cull_geometry(ctx)
 
 
 def test_repeated_calls_on_one_seeded_context_restart_their_counters(renderer, oracle_lib):
@@ -95,7 +125,7 @@ def test_repeated_calls_on_one_seeded_context_restart_their_counters(renderer, o
     ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL)
     renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
     mask_gpu = mask.cuda()
-    for rep, mode in enumerate([2, 2, 0, 1, 2]):
+    for rep, mode in enumerate([1, 1, 0, 1, 0]):
         frame.meshlet_instance_visibility_mask_buffer.copy_(mask_gpu)
         ctx.unordered_output = mode
         for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):

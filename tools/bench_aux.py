@@ -285,9 +285,10 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
     generalised: doubling extents around the camera), per-view cull_meshes (frustum + LOD select, cull_meshes.slang:35-57) +
     cull_meshlets, up to 16 views per oxc_cull_geometry_batch call.  `value` counts the meshlets the meshlet stage actually
     PROCESSED (per view: the length of the list cull_meshes produced), not candidates x views.
-    Main line: implicit_meshlet_instances = 1 (include/oxcull.h) -- the per-view MeshletInstance lists stay {first, count} runs per mesh
-    instance, nothing in this call reads the 8-byte records; the explicit form (records written: 466 MB per step) is timed as a variant and
-    must give the same visible lists.  N > 1: every rank culls its own contiguous range of mesh instances (weak scaling: 10M meshlets per
+    Main line (round 5; round 4 had it the other way round): the per-view MeshletInstance records are WRITTEN, as the reference's cull_meshes
+    writes them and its later passes read them (466 MB per step) -- the reference-equivalent output; the extension implicit_meshlet_instances = 1
+    (include/oxcull.h: the lists stay {first, count} runs per mesh instance, nothing in this call reads the records) is timed as a clearly
+    labelled variant and must give the same visible lists (--implicit-lists swaps the two).  N > 1: every rank culls its own contiguous range of mesh instances (weak scaling: 10M meshlets per
     rank, generated per rank) and the per-view {visible, processed} counts are all-gathered every step (RCCL); `value` comes from the
     gathered sums.  nested=True: return the result (bench.py hangs it into the driver's default line as "configs4")."""
     import dataclasses
@@ -335,7 +336,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
             groups.append((n, cf, cc))
         return groups
 
-    implicit_main = not getattr(args, "explicit_lists", False)
+    implicit_main = bool(getattr(args, "implicit_lists", False))
     groups = make_groups(implicit_main)
 
     def check(st):
@@ -420,18 +421,21 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         unique_meshlets, steps_256 = int(cu.sum()), int(((cu + 255) // 256).sum())
         view_chunks, kept_rows = int(((allc + 255) // 256).sum()), int(allk.numel())
 
-    # ---- the explicit form (records written) as a variant: same visible lists ----
+    # ---- the other list form as a variant: same visible lists ----
     variant = None
-    if implicit_main and groups[0][0] > 1:
-        g2 = make_groups(False)
+    if groups[0][0] > 1:
+        g2 = make_groups(not implicit_main)
         with torch.cuda.stream(stream):
             for _ in range(2):
                 one(g2)
         pv2, lists2 = read_lists(g2)
         dt2 = timed(g2, max(4, steps // 4))
-        variant = {"implicit_meshlet_instances": 0, "ms_per_step": round(dt2 / max(4, steps // 4) * 1e3, 6),
+        variant = {"implicit_meshlet_instances": int(not implicit_main), "ms_per_step": round(dt2 / max(4, steps // 4) * 1e3, 6),
+                   "value": round(world_processed * max(4, steps // 4) / dt2, 1),
                    "outputs_match_main_line": bool(pv2 == per_view and all(torch.equal(a[1], b[1]) for a, b in zip(lists2, got_lists))),
-                   "note": "the per-view MeshletInstance records written as the reference's cull_meshes does (8 B per processed meshlet-view)"}
+                   "note": ("EXTENSION, not the reference's output: the per-view MeshletInstance lists left implicit ({first, count} runs per mesh instance; a consumer expands "
+                            "record i = {m, i - first[m]}); same counters, lod_index and visible lists" if implicit_main is False else
+                            "the per-view MeshletInstance records written as the reference's cull_meshes does (8 B per processed meshlet-view)")}
         with torch.cuda.stream(stream):
             one()  # back to the main form for the kernel profile
         torch.cuda.synchronize()
@@ -503,10 +507,10 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         kt = kernels["cull_meshlets_test"]
         traffic, tsrc = None, None
         try:  # HBM bytes of k_mv_test from the committed PMC profile of this workload (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
-            pm = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_config5_pmc.json")))
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_config5_pmc.json" if os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_config5_pmc.json")) else "r04_config5_pmc.json")))
             for kn, cs in pm.get("pmc", {}).items():
                 if "k_mv_test" in kn and "hbm_read_bytes_corrected" in cs:
-                    traffic, tsrc = round(cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0)), "profiles/r04_config5_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)"
+                    traffic, tsrc = round(cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0)), "profiles/r0x_config5_pmc.json, the newest committed (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)"
         except (OSError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": "k_mv_test: the one-pass multi-view meshlet test (launches of one step summed)", "achieved": kt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
@@ -549,12 +553,13 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
                                + ("" if world == 1 else f", the mesh-instance range sharded {world} ways (contiguous ranges, one per rank), per-view counts all-gathered every step"),
                    "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "views": views, "views_per_call": vb, "calls_per_step": launches_per_step,
                    "implicit_meshlet_instances": int(implicit_main and groups[0][0] > 1),
+                   "meshlet_instance_lists": "implicit runs (extension)" if (implicit_main and groups[0][0] > 1) else "explicit records (the reference's cull_meshes output)",
                    "candidate_meshlet_views_per_step": n_meshlets * views, "processed_meshlet_views_per_step": processed,
                    "world_processed_meshlet_views_per_step": world_processed, "world_visible_per_step": world_visible, "value_counts_from": counts_source,
                    "counts_all_gather_bytes_per_rank_per_step": (16 * min(vb, views) * len(groups)) if world > 1 else 0,
                    "per_view_processed": [t for t, _ in per_view], "per_view_visible": [v for _, v in per_view]},
         "bit_match": bit_match, "bit_match_sample": f"per-view list lengths and visible counts of all {views} views; the visible lists of views {[v for v, _ in got_lists][:1]}..{[v for v, _ in got_lists][-1:]} byte for byte",
-        "explicit_lists_variant": variant, "hip_graph_replay_variant": graph_variant, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
+        ("implicit_lists_variant" if not implicit_main else "explicit_lists_variant"): variant, "hip_graph_replay_variant": graph_variant, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline}
     if nested:
         del base, lanes
         torch.cuda.empty_cache()
