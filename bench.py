@@ -93,6 +93,11 @@ def parse():
                          "(5.6 MB at level 2) and every rank builds the lower levels from its own copy of the prior-frame depth image; 'whole' = rank 0 "
                          "broadcasts every level (89.5 MB; assumes nothing about the other ranks).  Same pyramid bytes on every rank either way.")
     ap.add_argument("--hiz-top-level", type=int, default=2)
+    ap.add_argument("--one-scene", action="store_true", help="N > 1: the ranks cull the shards of ONE spatially coherent scene (every rank's instances are placed where the whole "
+                                                             "scene's grid puts their global indices) instead of one independent scene each, so that visibility skew between the shards "
+                                                             "shows (per_rank_visible beside per_rank_ms_per_frame)")
+    ap.add_argument("--shard-block", type=int, default=0, help="with --one-scene: 0 = contiguous instance ranges (default), B > 0 = interleaved blocks of B mesh instances "
+                                                                "(SURVEY 8e: 64 instances x 1000 meshlets = 64k meshlets)")
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: run the two exchanges (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
                          "(oxc_exchange_counts / oxc_broadcast_hiz) instead of torch.distributed; the rendezvous stays torch.distributed")
@@ -352,8 +357,28 @@ def bench_config3(args, e):
         if st != L.OXC_OK:
             raise RuntimeError(lib.oxc_last_error(ctxp).decode())
 
+    shard_desc = None
+    world_meshlets = n_meshlets * world  # meshlets all ranks cull per frame
     with torch.cuda.stream(stream):
-        scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2 + rank, tris_per_meshlet=args.tris), dev)
+        if args.one_scene and world > 1:
+            # ONE scene of M x world instances, sharded: contiguous ranges of the instance index (= slabs of the scene's grid, far to near) or
+            # interleaved blocks (oxylus_amd/shard.py shard_ranges); a rank generates only its own instances, placed by their global indices
+            from oxylus_amd.shard import shard_ranges
+
+            M_total = M * world
+            mine = shard_ranges(M_total, world, args.shard_block)[rank]
+            mine = [mine] if args.shard_block <= 0 else mine
+            gids = torch.cat([torch.arange(a, b, dtype=torch.int64) for a, b in mine]) if mine else torch.zeros(0, dtype=torch.int64)
+            assert gids.numel() > 0, "a rank without instances: fewer blocks than ranks"
+            M = int(gids.numel())
+            n_meshlets = M * K
+            scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2 + rank, tris_per_meshlet=args.tris), dev,
+                               global_ids=gids, global_total=M_total)
+            world_meshlets = M_total * K
+            shard_desc = {"one_scene": True, "scene_mesh_instances": M_total, "shard_block_instances": args.shard_block,
+                          "assignment": "contiguous instance ranges" if args.shard_block <= 0 else f"interleaved blocks of {args.shard_block} instances", "this_rank_ranges": len(mine)}
+        else:
+            scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2 + rank, tris_per_meshlet=args.tris), dev)
         r.reserve(M, n_meshlets)
         frame = PreparedFrame.create(scene, with_triangles=True, max_tris=128 if wide else 64)
         depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))  # the same image on every rank
@@ -558,9 +583,14 @@ def bench_config3(args, e):
     ramp_clocks(e)
     elapsed = timed_steps(e, run_step, args.steps, args.warmup)
     per_rank_ms_per_frame = [round(t * 1e3 / (args.steps * inner), 6) for t in PER_RANK_SECONDS]
+    per_rank_visible = None
+    if world > 1:  # the all-gathered counters of the last frame: {emitted by the late call, early, late, index_count} per rank
+        torch.cuda.synchronize()
+        gcpu = gathered.cpu().view(world, 4)
+        per_rank_visible = [int(gcpu[k, 1] + gcpu[k, 2]) for k in range(world)]
     frames = args.steps * inner
     ms_per_frame = elapsed * 1e3 / frames
-    value = n_meshlets * world * frames / elapsed
+    value = world_meshlets * frames / elapsed
     sum_main = outputs_checksum()
 
     # ---- the same frames under other schedulings, short runs: (a) async_triangles flipped -- the triangle stage of a call on the context's
@@ -576,7 +606,7 @@ def bench_config3(args, e):
         el = timed_steps(e, run_step, ab_steps, 1)
         return {"async_triangles": async_on, "hiz_one_frame_ahead_on_second_stream": ahead_on, "share_pass_tests": share_on, "unordered_output": use_unord[0],
                 "ms_per_frame": round(el * 1e3 / (ab_steps * inner), 6),
-                "value": round(n_meshlets * world * ab_steps * inner / el, 1), "frames_timed": ab_steps * inner, "outputs_match_main_line": outputs_checksum() == sum_main}
+                "value": round(world_meshlets * ab_steps * inner / el, 1), "frames_timed": ab_steps * inner, "outputs_match_main_line": outputs_checksum() == sum_main}
 
     main_async, main_ahead, main_share, main_unord = use_async[0], use_overlap[0], use_share[0], use_unord[0]
     variants = []
@@ -853,7 +883,7 @@ def bench_config3(args, e):
             "workload": ("configs[2]: 10M meshlets + 4096^2 prior-frame HiZ (13 mips, built from an 8192^2 depth): HiZ build + early/late occlusion cull + "
                          "per-triangle cull + compaction into the indirect-draw buffers (" + ("unordered_output = 1: slots allocated by atomic_add as in the reference, lists "
                          "compared sorted" if main_unord else "ascending lists") + ")" if world == 1 else
-                         f"configs[3]: {n_meshlets * world} meshlets sharded {world} ways by contiguous range (the configs[2] pipeline per rank): rank 0 builds the "
+                         f"configs[3]: {world_meshlets} meshlets sharded {world} ways by " + ("contiguous range" if not (shard_desc and shard_desc["shard_block_instances"] > 0) else shard_desc["assignment"]) + (" of ONE scene" if shard_desc else " (an independent scene per rank)") + " (the configs[2] pipeline per rank): rank 0 builds the "
                          "4096^2 pyramid and broadcasts it over RCCL/xGMI, per-rank counters all-gathered every frame, shard-local ids and outputs"),
             "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris, "verts_per_meshlet": 64,
             "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
@@ -861,7 +891,9 @@ def bench_config3(args, e):
             "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
                                                          "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if xmode["top"] else "whole pyramid broadcast from rank 0"),
                                                          "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": use_overlap[0],
-                                                         "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame, "hiz_exchange_ab": exchange_ab},
+                                                         "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame,
+                                                         "per_rank_visible": per_rank_visible, "scene": shard_desc or {"one_scene": False, "note": "an independent scene per rank (seed + rank): no visibility skew between ranks by construction; --one-scene shards one scene"},
+                                                         "hiz_exchange_ab": exchange_ab},
             "async_triangles": bool(use_async[0]), "share_pass_tests": bool(use_share[0]), "unordered_output": main_unord,
         },
         "bit_match": bit_match, "bit_match_detail": bit_detail if rank == 0 else None, "hiz_bit_match": hiz_match, "bit_match_sample": f"first {min(args.cpu_prefix, M) * K} meshlet instances: visible lists, packed triangle indices, mask words, both passes",

@@ -269,7 +269,11 @@ def _quat_to_mat(q: torch.Tensor) -> torch.Tensor:
     return r
 
 
-def make_scene(spec: SceneSpec, device="cpu") -> Scene:
+def make_scene(spec: SceneSpec, device="cpu", global_ids=None, global_total: int = 0) -> Scene:
+    """global_ids / global_total (multi-GPU "one scene" form): this scene is the shard of a scene of `global_total` mesh instances
+    that holds the instances with these global indices (int64 [n_mesh_instances]) -- they are PLACED where the whole scene's grid puts those
+    indices (so the union of the ranks' shards is one spatially coherent scene and contiguous index ranges are slabs of it), everything else
+    (geometry, rotation, scale, jitter) comes from this shard's own seed."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(spec.seed)
@@ -380,9 +384,11 @@ def make_scene(spec: SceneSpec, device="cpu") -> Scene:
 
     # ---- instances ----
     D = spec.scene_depth
-    n_side = max(1, int(math.ceil(M ** (1.0 / 3.0))))
+    n_side = max(1, int(math.ceil((global_total if global_ids is not None else M) ** (1.0 / 3.0))))
     ids = torch.arange(M, device=dev, dtype=torch.int64)
-    gx, gy, gz = ids % n_side, (ids // n_side) % n_side, ids // (n_side * n_side)
+    place = ids if global_ids is None else torch.as_tensor(global_ids, dtype=torch.int64, device=dev)
+    assert place.numel() == M
+    gx, gy, gz = place % n_side, (place // n_side) % n_side, place // (n_side * n_side)
     cell = torch.stack([gx, gy, gz], 1).to(torch.float32)
     jitter = rand(M, 3)
     u = (cell + jitter) / float(n_side)
