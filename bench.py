@@ -1193,7 +1193,8 @@ def line_summary(line: dict) -> dict:
     if "configs4" in line:
         c4 = line["configs4"]
         sm["configs4"] = {"ms_per_step": g(c4, "ms_per_step", nd=4), "value": g(c4, "value"), "frac": g(c4, "roofline", "frac"), "stage_frac": g(c4, "stage", "stage_frac"),
-                          "lists": g(c4, "config", "meshlet_instance_lists"), "bit_match": c4.get("bit_match")}
+                          "lists": g(c4, "config", "meshlet_instance_lists"), "implicit_lists_ms_per_step": g(c4, "implicit_lists_variant", "ms_per_step", nd=4),
+                          "implicit_lists_match": g(c4, "implicit_lists_variant", "outputs_match_main_line"), "bit_match": c4.get("bit_match")}
     if "configs0" in line:
         sm["configs0"] = {"entities_per_s": g(line, "configs0", "value"), "cores": g(line, "configs0", "config", "threads"), "one_core": g(line, "configs0", "single_thread_value"),
                           "ms_per_update_one_thread": g(line, "configs0", "ms_per_update_one_thread")}

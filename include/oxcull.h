@@ -599,7 +599,8 @@ uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
  * the overflow paths with a small scene. */
 enum { OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU = 0, OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU = 1, OXC_TUNE_RASTER_BIG_CAPACITY = 2,
        OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */,
-       OXC_TUNE_FUSED_SELECT = 4 /* 0: the HiZ meshlet stage keeps its emit launch in front of the fused triangle kernel (default 1: the fused kernel finds its ids itself) */ };
+       OXC_TUNE_FUSED_SELECT = 4 /* 0: the HiZ meshlet stage keeps its emit launch in front of the fused triangle kernel (default 1: the fused kernel finds its ids itself) */,
+       OXC_TUNE_MV_EXPAND_ASYNC = 5 /* 0: the multi-view batch writes its MeshletInstance records in order on the caller's stream (default 1: on the context's own stream beside the meshlet stage, joined at the end of the call) */ };
 oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value);
 
 /* Measurement aid: counters_dptr != NULL -- the HiZ calls (use_hiz + OXC_CULL_TEST_OCCLUSION) that follow on this context run counting

@@ -90,6 +90,9 @@ struct oxc_ctx {
   // tri[k % kTriRing] describes the stage of lane-0 call number k (call_seq) while it may still be in flight.
   hipStream_t side = nullptr;
   hipEvent_t fork_event = nullptr;
+  hipStream_t mv_side = nullptr;
+  hipEvent_t mv_fork = nullptr, mv_join = nullptr;  // multi-view batch: the MeshletInstance expansion on `side` beside the meshlet stage
+  uint32_t mv_expand_async = 4;                      // blocks per CU the side-stream expansion takes; oxc_debug_set_tuning(OXC_TUNE_MV_EXPAND_ASYNC, 0): in order on the caller's stream (A/B aid)
   struct TriPending {
     hipEvent_t done = nullptr;
     bool valid = false;
@@ -462,6 +465,9 @@ void oxc_destroy(oxc_ctx* ctx) {
   if (ctx->slots) (void)hipFree(ctx->slots);
   if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
   if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+  if (ctx->mv_side) (void)hipStreamDestroy(ctx->mv_side);
+  if (ctx->mv_fork) (void)hipEventDestroy(ctx->mv_fork);
+  if (ctx->mv_join) (void)hipEventDestroy(ctx->mv_join);
   for (auto& tp : ctx->tri)
     if (tp.done) (void)hipEventDestroy(tp.done);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -963,6 +969,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t max_grid = ctx->num_cus * 8;
   const bool do_meshes = ci[0].do_meshes, do_meshlets = ci[0].do_meshlets, do_tris = ci[0].do_tris;
+  bool mv_expand_async = false;
   BatchCore cores[kMaxBatch];
   std::memset(cores, 0, sizeof cores);
   uint32_t g_prep = 1, g_expand = 1, g_test = 1, g_emit = 1, g_ttest = 1, g_temit = 1;
@@ -1059,8 +1066,31 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       launch_scan_batch(ctx->batch_dev, count, s);
     }
     if (!implicit_lists) {  // (implicit: the records have no reader in this call; the runs are written by k_mv_group)
-      KernelTimer t(ctx, OXC_K_MESHES_EXPAND, s);
-      launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, cap), s);
+      // Round 5: in the multi-view form nothing of this call reads the MeshletInstance records (k_mv_test walks the instances' bounds), so their
+      // expansion -- a pure store stream, 466 MB per 16 views of a 10 M-meshlet scene -- runs on the context's side stream beside the
+      // latency-bound set-up launches and the VALU-bound test of the meshlet stage, and is joined at the end of the call (fork / join by
+      // events, capturable like async_triangles).  A triangle stage in the call reads the records: in order then.
+      mv_expand_async = multiview && do_meshlets && !do_tris && ctx->mv_expand_async != 0;
+      hipStream_t es = s;
+      if (mv_expand_async) {
+        if (!ctx->mv_side) {  // its own stream, at the lowest priority: the store stream yields wave slots to the meshlet stage's launches
+          int lo = 0, hi = 0;
+          OXC_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+          OXC_HIP(ctx, hipStreamCreateWithPriority(&ctx->mv_side, hipStreamNonBlocking, lo));
+        }
+        if (!ctx->mv_fork) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->mv_fork, hipEventDisableTiming));
+        if (!ctx->mv_join) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->mv_join, hipEventDisableTiming));
+        OXC_HIP(ctx, hipEventRecord(ctx->mv_fork, s));
+        OXC_HIP(ctx, hipStreamWaitEvent(ctx->mv_side, ctx->mv_fork, 0));
+        es = ctx->mv_side;
+      }
+      {
+        KernelTimer t(ctx, OXC_K_MESHES_EXPAND, es);
+        // (beside the meshlet stage the expansion takes mv_expand_async blocks per CU, not every wave slot: the small set-up launches queue behind it otherwise)
+        const uint32_t ecap = mv_expand_async ? std::max(1u, ctx->num_cus * ctx->mv_expand_async / count) : cap;
+        launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, ecap), es);
+      }
+      if (mv_expand_async) OXC_HIP(ctx, hipEventRecord(ctx->mv_join, es));
     }
   }
   if (do_meshlets && multiview) {
@@ -1148,8 +1178,11 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
       launch_mv_test(ma, ctx->num_cus, s);
     }
-    KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
-    launch_mv_emit(ma, max_vchunks, max_grid, s);
+    {
+      KernelTimer t(ctx, OXC_K_MESHLETS_EMIT, s);
+      launch_mv_emit(ma, max_vchunks, max_grid, s);
+    }
+    if (mv_expand_async) OXC_HIP(ctx, hipStreamWaitEvent(s, ctx->mv_join, 0));  // join: the records are part of what the call leaves behind on `s`
   } else if (do_meshlets) {
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
@@ -1714,6 +1747,7 @@ oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
       ctx->tri_blocks_per_cu = value;
       return OXC_OK;
     case OXC_TUNE_FUSED_SELECT: ctx->fused_select = value ? 1u : 0u; return OXC_OK;
+    case OXC_TUNE_MV_EXPAND_ASYNC: ctx->mv_expand_async = value; return OXC_OK;
     case OXC_TUNE_RASTER_BIG_CAPACITY:
       if (ctx->raster_scratch) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the raster scratch is allocated by the first oxc_draw_visbuffer; set its capacity before");
       ctx->raster_capacity_request = value;
