@@ -629,8 +629,8 @@ def bench_config3(args, e):
                               "unordered_output": main_unord, "ms_per_frame": round(ms_per_frame, 6)},
                 "variants": variants,
                 "note": "unordered_output (include/oxcull.h): 0 = ascending lists, test + ordered emit per stage; 1 = the triangle stage as ONE launch that appends behind an "
-                        "atomic_add on index_count per 128-meshlet span (cull_triangles.slang:71-88) and finds the ids of its spans from the meshlet test's ballots (no meshlet emit "
-                        "launch; the visible list it writes is the ascending one) -- variants are compared with the main line as sorted sets.  library_defaults = ordered + unshared.  "
+                        "atomic_add on index_count per 128-meshlet span (cull_triangles.slang:71-88), the last partial round of spans handed out in 64-meshlet chunks by ticket; the HiZ "
+                        "meshlet stage keeps its ordered emit -- variants are compared with the main line as sorted sets.  library_defaults = ordered + unshared.  "
                         "share_pass_tests: the late call of a frame reads the early call's frustum + cone results (one bit per meshlet) instead of testing again -- a cache "
                         "inside liboxcull, valid because both calls of a frame have the same camera, transforms and list (RendererInstance.cpp:842-884); the variant that flips it is "
                         "the frame with every call testing on its own.  async_triangles: hipStreamWaitEvent fork / join inside liboxcull (include/oxcull.h); one frame ahead: bench-side second stream + second context with "
@@ -708,8 +708,8 @@ def bench_config3(args, e):
                 "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
                 "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
                 "cull_meshlets_emit": ["oxc::k_cull_meshlets_emit<true, false>"], "cull_meshlets_emit_late": ["oxc::k_cull_meshlets_emit<true, true>"],
-                "cull_triangles_test": [f"oxc::k_cull_triangles_fused_select<false, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<false, {str(wide).lower()}, false>"],
-                "cull_triangles_test_late": [f"oxc::k_cull_triangles_fused_select<true, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<true, {str(wide).lower()}, false>"],
+                "cull_triangles_test": [f"oxc::k_cull_triangles_fused<false, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<false, {str(wide).lower()}, false>"],
+                "cull_triangles_test_late": [f"oxc::k_cull_triangles_fused<true, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<true, {str(wide).lower()}, false>"],
                 "cull_triangles_emit": ["oxc::k_cull_triangles_emit<false, false>"], "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit<true, false>"]}
     kernels, frame_alg, frame_kernel_us = {}, 0.0, 0.0
     for name, k in kern.items():
@@ -736,9 +736,9 @@ def bench_config3(args, e):
         dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
         dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        dom_name = "k_cull_triangles_fused_select" if main_unord else "k_cull_triangles_test"
+        dom_name = "k_cull_triangles_fused" if main_unord else "k_cull_triangles_test"
         traffic, traffic_src, traffic_same = pmc_traffic(prof_names, lambda k: dom_name in k) if prof_names else (None, None, None)
-        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + (f"; ids from the meshlet test's ballots, test + expansion in one launch: {tri_bytes_per_meshlet} B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
+        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + (f"; test + expansion in one launch: {tri_bytes_per_meshlet} B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
                     "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_profile_is_of_this_device_code": traffic_same, "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),

@@ -191,9 +191,7 @@ typedef struct oxc_cull_geometry_context {
    *   1 = unordered where that is the faster form on this part: the triangle stage is ONE launch (a block tests a span of visible
    *       meshlets -- implementation-defined, currently 128 -- and appends its packed indices behind one atomic_add on index_count);
    *       the plain meshlet stage (no use_hiz / use_hpb) is one launch (one atomic_add on cull_triangles_cmd.x per 1024 meshlets).
-   *       The HiZ / HPB meshlet stages keep their ASCENDING visible list; when the triangle stage of the same in-order call follows
-   *       a HiZ meshlet stage, no meshlet emit kernel is launched either -- the fused triangle kernel finds the ids of its spans from
-   *       the meshlet test's ballots and writes that ascending list itself (same bytes).
+   *       The HiZ / HPB meshlet stages keep the ordered two-launch form and their ascending visible list.
    *   Any other value returns OXC_INVALID_ARG.  (Rounds 4 built "2": the HiZ meshlet tests appending with one atomic_add pair per
    *   256-meshlet wave step, the reference's literal scheme aggregated through the ballot -- 150 / 154 us per launch against 79 + 11 /
    *   66 + 11 for test + ordered emit, every step queueing on two addresses that retire ~88 atomics per microsecond; removed in round 5,
@@ -599,8 +597,7 @@ uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
  * the overflow paths with a small scene. */
 enum { OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU = 0, OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU = 1, OXC_TUNE_RASTER_BIG_CAPACITY = 2,
        OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */,
-       OXC_TUNE_FUSED_SELECT = 4 /* 0: the HiZ meshlet stage keeps its emit launch in front of the fused triangle kernel (default 1: the fused kernel finds its ids itself) */,
-       OXC_TUNE_MV_EXPAND_ASYNC = 5 /* 0: the multi-view batch writes its MeshletInstance records in order on the caller's stream (default 1: on the context's own stream beside the meshlet stage, joined at the end of the call) */ };
+       OXC_TUNE_MV_EXPAND_ASYNC = 5 /* multi-view batch: blocks per CU of the MeshletInstance expansion on the context's own low-priority stream beside the meshlet stage (default 4); 0: in order on the caller's stream */ };
 oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value);
 
 /* Measurement aid: counters_dptr != NULL -- the HiZ calls (use_hiz + OXC_CULL_TEST_OCCLUSION) that follow on this context run counting

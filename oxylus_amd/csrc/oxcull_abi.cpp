@@ -131,7 +131,6 @@ struct oxc_ctx {
   uint32_t async_mtest_per_cu = kAsyncMeshletBlocksPerCU, async_tri_per_cu = kAsyncTriangleBlocksPerCU;
   uint32_t tri_blocks_per_cu = kTriangleBlocksPerCU;  // grid cap of the triangle kernels (blocks walk their chunks with a grid stride)
   uint32_t* dbg_occlusion = nullptr;  // oxc_debug_count_occlusion_candidates: 256 strided counters the counting instantiations of the HiZ meshlet tests add to
-  uint32_t fused_select = 1;  // oxc_debug_set_tuning(OXC_TUNE_FUSED_SELECT, 0): keep the meshlet emit launches in front of the fused triangle kernel (A/B aid)
   // profiling (oxc_profile_begin/end)
   bool profiling = false;
   struct Rec {
@@ -661,7 +660,6 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
 
   const uint32_t max_grid = ctx->num_cus * 8;
   const uint32_t m_chunks = cdiv(std::max(N, 1u), kMeshletChunk), t_chunks = cdiv(std::max(N, 1u), kTriChunk);
-  bool select_ids = false;  // (decided at the meshlet stage)
 
   // --- prepare (+ cull_meshes test): CullGeometry.cpp:69-117
   PrepareArgs pa;
@@ -806,10 +804,6 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
         KernelTimer t(ctx, late ? OXC_K_MESHLETS_TEST_LATE : OXC_K_MESHLETS_TEST, s);
         launch_meshlets_test(ta, c->use_hiz != 0, occl, late, std::min(m_chunks, max_grid), ctx->num_cus, mtest_limit, s);
       }
-      // Round 5: with the fused triangle stage behind it (unordered_output, same call, in order) the HiZ meshlet stage launches NO emit
-      // kernel -- k_cull_triangles_fused_select finds the ids of its spans from the ballots and counts and writes the ascending visible
-      // list and the counters itself (TriTestArgs::m_bits).
-      select_ids = c->use_hiz && unord_tris && !async && ctx->fused_select && cdiv(cdiv(std::max(N, 1u), 64u * kHizGroupsPerWave), kChunksPerSuper) <= 1024u;
       MeshletEmitArgs ea;
       ea.n_host = n_host;
       ea.n_cap = N;
@@ -824,10 +818,8 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
         oxc_status wst = wait_for_visible_list(vis);
         if (wst != OXC_OK) return wst;
       }
-      if (!select_ids) {
-        KernelTimer t(ctx, late ? OXC_K_MESHLETS_EMIT_LATE : OXC_K_MESHLETS_EMIT, s);
-        launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
-      }
+      KernelTimer t(ctx, late ? OXC_K_MESHLETS_EMIT_LATE : OXC_K_MESHLETS_EMIT, s);
+      launch_meshlets_emit(ea, c->use_hiz != 0, late, std::min(cdiv(std::max(N, 1u), kMeshletSpan), max_grid), s);
     }
   }
 
@@ -855,18 +847,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.draw_cmd = draw_cmd;
     tt.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     tt.ticket = t_supers;  // (zeroed by this call's prepare kernel; the fused form has no other use for the accumulators)
-    tt.m_bits = nullptr;
-    tt.m_chunk_counts = tt.m_supers = nullptr;
-    tt.n_host = n_host;
-    tt.n_cap = N;
-    tt.visible_w = static_cast<uint32_t*>(f->visible_meshlet_instances_indices_buffer.dptr);
-    tt.vis_w = vis;
-    tt.tri_cmd_w = tri_cmd;
-    if (select_ids) {
-      tt.m_bits = ctx->lane[0].bits;
-      tt.m_chunk_counts = ctx->lane[0].m_chunk_counts;
-      tt.m_supers = m_supers;
-    }
+    tt.ticket_count = std::max(pa.n_supers_tris, 1u);
     if (unord_tris) {  // one launch: test + expansion per span of 256 visible meshlets
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
       launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap), ts);
@@ -1746,7 +1727,6 @@ oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
       if (value == 0) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the triangle grid needs at least one block per CU");
       ctx->tri_blocks_per_cu = value;
       return OXC_OK;
-    case OXC_TUNE_FUSED_SELECT: ctx->fused_select = value ? 1u : 0u; return OXC_OK;
     case OXC_TUNE_MV_EXPAND_ASYNC: ctx->mv_expand_async = value; return OXC_OK;
     case OXC_TUNE_RASTER_BIG_CAPACITY:
       if (ctx->raster_scratch) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the raster scratch is allocated by the first oxc_draw_visbuffer; set its capacity before");

@@ -1386,18 +1386,7 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 #define OXC_EMIT_WIDE_NT 1
 #endif
 constexpr uint32_t kEmitRun = OXC_EMIT_RUN;  // dwords a wave stages between flushes (>= 384 + 3: one WIDE slot)
-#ifndef OXC_FUSED_RUN
-#define OXC_FUSED_RUN 768
-#endif
-// ... and in the select form of the fused triangle kernel, whose block also holds the prefix of the meshlet stage's sums (4 KB): 8 blocks per CU
-// have 20 KB of LDS each.  (Run length 512 / 1024 / 2048 dwords measured in round 4: 549 / 548 / 544 us per frame.)
-constexpr uint32_t kFusedRun = OXC_FUSED_RUN;
-static_assert(kFusedRun >= 384u + 3u && kFusedRun % 4u == 0u, "a run holds at least one WIDE slot; rows stay 16-byte aligned");
-#ifndef OXC_FUSED_TICKETS
-#define OXC_FUSED_TICKETS 1  // fused triangle kernel: the spans of the last, partial round of the grid are drawn from TriTestArgs::ticket (tris_test_body)
-#endif
-constexpr uint32_t kSelectMaxSupers = 1024;  // FMODE 3: per-64-step sums a block can scan (4 per thread): 2^24 meshlet instances
-template <int H, uint32_t kCornerBits, uint32_t kRunLen = kEmitRun>
+template <int H, uint32_t kCornerBits>
 OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int first_slot, int nslots, uint32_t g0, uint32_t* __restrict__ out, uint32_t* run, int lane) {
   typedef uint32_t u4v __attribute__((ext_vector_type(4)));
   constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
@@ -1435,7 +1424,7 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
     }
     const uint32_t n3 = cnt * 3u;
     if (n3 == 0u) continue;                      // (wave-uniform)
-    if (filled + n3 > kRunLen) flush();         // (wave-uniform; same wave, in-order LDS: the flush has read the run before it is rewritten)
+    if (filled + n3 > kEmitRun) flush();         // (wave-uniform; same wave, in-order LDS: the flush has read the run before it is rewritten)
     uint32_t* at = run + pad + filled;
     uint32_t before = 0;
 #pragma unroll
@@ -1453,135 +1442,6 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
     filled += n3;
   }
   if (filled) flush();
-}
-
-// ------------------------------------------------------------------------------------------
-// The "select" form of the fused triangle kernel (round 5): the id at position `slot` of the (ascending) visible list, found from what the HiZ
-// meshlet test left -- per 64 candidates a ballot word, per 64 wave steps (16 384 candidates) their survivor sum (prefix P in LDS) -- i.e. what
-// k_cull_meshlets_emit computes for every position, computed for the 64 consecutive positions of a wave.  Called by whole waves (every lane
-// with a valid slot < P[last]); scratch: 64 + 512 words of LDS owned by the wave, 16-byte aligned.
-//   super S: the last one with P[S] <= slot (empty supers are skipped by the search);  step: first c of S whose inclusive count > r;
-//   word j of the step's four and the n-th set bit of it by popcount narrowing.
-// ------------------------------------------------------------------------------------------
-OXC_DEV uint32_t select_visible_id(const uint64_t* __restrict__ bits, const uint32_t* P, uint32_t nwords, uint32_t slot, uint32_t* scratch, int lane) {
-  static_assert(kHizGroupsPerWave == 4, "four ballot words (256 candidates) per counted step");
-  uint32_t lo = 0, hi = kSelectMaxSupers;  // P[hi] > slot (P[kSelectMaxSupers] = V)
-#pragma unroll
-  for (int it = 0; it < 10; it++) {  // 2^10 = kSelectMaxSupers
-    const uint32_t mid = (lo + hi) >> 1;
-    const bool le = P[mid] <= slot;
-    lo = le ? mid : lo;
-    hi = le ? hi : mid;
-  }
-  const uint32_t S = lo;
-  const uint32_t r = slot - P[S];
-  // One round per distinct super among the wave's 64 positions (usually one, rarely more than two): lane k loads the four ballot words of
-  // step k of the super -- 2 KB per wave, one hop; the per-step counts the meshlet test also left are their popcounts -- the wave scans the
-  // counts, every lane finds its step in the scan and takes that step's four words out of the wave's LDS scratch.
-  uint32_t* const incl64 = scratch;                                   // [64]
-  uint4* const words = reinterpret_cast<uint4*>(scratch + 64);         // [64][2]: 16-byte aligned (the scratch row is)
-  uint32_t word0 = 0, rr = 0;
-  uint4 w01 = make_uint4(0u, 0u, 0u, 0u), w23 = w01;
-  uint64_t todo = ~0ull;
-  while (todo) {
-    const uint32_t Su = readlane_u(S, __ffsll((unsigned long long)todo) - 1);
-    const uint32_t wi = (Su * kChunksPerSuper + (uint32_t)lane) * 4u;  // first ballot word of this lane's step
-    const uint32_t last = nwords - 1u;
-    uint4 a01 = load_global_u4(reinterpret_cast<uint64_t>(bits), min(wi, last & ~3u) >> 1);
-    uint4 a23 = load_global_u4(reinterpret_cast<uint64_t>(bits), (min(wi, last & ~3u) >> 1) + 1u);
-    // words at or beyond nwords were not written by this call's test kernel (stale): they count nothing
-    if (wi + 0u > last) a01.x = a01.y = 0u;
-    if (wi + 1u > last) a01.z = a01.w = 0u;
-    if (wi + 2u > last) a23.x = a23.y = 0u;
-    if (wi + 3u > last) a23.z = a23.w = 0u;
-    const uint32_t c = (uint32_t)__popc(a01.x) + (uint32_t)__popc(a01.y) + (uint32_t)__popc(a01.z) + (uint32_t)__popc(a01.w) + (uint32_t)__popc(a23.x) +
-                       (uint32_t)__popc(a23.y) + (uint32_t)__popc(a23.z) + (uint32_t)__popc(a23.w);
-    const uint32_t incl = wave_incl_scan(c, lane);
-    incl64[lane] = incl;
-    words[lane * 2 + 0] = a01;
-    words[lane * 2 + 1] = a23;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS hand-off
-    const bool mine = S == Su;
-    uint32_t a0 = 0, b0 = 63;  // first index whose inclusive count exceeds r (exists: r < the super's sum)
-#pragma unroll
-    for (int it = 0; it < 6; it++) {
-      const uint32_t mid = (a0 + b0) >> 1;
-      const bool gt = incl64[mid] > r;
-      b0 = gt ? mid : b0;
-      a0 = gt ? a0 : min(mid + 1u, 63u);
-    }
-    const uint32_t before = a0 ? incl64[a0 - 1u] : 0u;
-    const uint4 m01 = words[a0 * 2 + 0], m23 = words[a0 * 2 + 1];
-    if (mine) {
-      word0 = (Su * kChunksPerSuper + a0) * 4u;
-      rr = r - before;
-      w01 = m01;
-      w23 = m23;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are rewritten by the next round
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
-  }
-  const uint64_t w0 = (uint64_t)w01.x | ((uint64_t)w01.y << 32), w1 = (uint64_t)w01.z | ((uint64_t)w01.w << 32);
-  const uint64_t w2 = (uint64_t)w23.x | ((uint64_t)w23.y << 32), w3 = (uint64_t)w23.z | ((uint64_t)w23.w << 32);
-  const uint32_t p0 = (uint32_t)__popcll((unsigned long long)w0), p1 = (uint32_t)__popcll((unsigned long long)w1), p2 = (uint32_t)__popcll((unsigned long long)w2);
-  uint32_t j = 0;
-  uint64_t w = w0;
-  if (rr >= p0) {
-    rr -= p0, j = 1, w = w1;
-    if (rr >= p1) {
-      rr -= p1, j = 2, w = w2;
-      if (rr >= p2) rr -= p2, j = 3, w = w3;
-    }
-  }
-  uint32_t pos = 0;
-#pragma unroll
-  for (uint32_t sh = 32; sh >= 1u; sh >>= 1) {  // the rr-th set bit (0-based) of w
-    const uint32_t below = (uint32_t)__popcll((unsigned long long)(w & ((1ull << sh) - 1ull)));
-    if (rr >= below) {
-      rr -= below;
-      w >>= sh;
-      pos += sh;
-    }
-  }
-  return (word0 + j) * 64u + pos;
-}
-
-// The prefix select_visible_id searches: every block scans the meshlet stage's per-64-step sums once (<= kSelectMaxSupers of them, 4 per
-// thread of a 256-thread block) into P (LDS, kSelectMaxSupers + 1 words; P[kSelectMaxSupers] = the pass's visible count, returned), and
-// block 0 stores what the emit kernel's last span would have stored (cull_meshlets_hiz.slang:67-78).  Ends with a block barrier.
-template <bool LATE>
-OXC_DEV uint32_t build_select_prefix(const TriTestArgs& a, uint32_t* P, uint32_t* s_red4, uint32_t* nwords_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t N = a.n_host ? a.n_host : min(gptr(a.vis)[0], a.n_cap);
-  const uint32_t nsteps = (N + 255u) / 256u;  // wave steps of the HiZ meshlet test that published a count (64 * kHizGroupsPerWave candidates each)
-  const uint32_t n_supers = (nsteps + kChunksPerSuper - 1) / kChunksPerSuper;
-  uint32_t v[4], t = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < 4u; k++) {
-    const uint32_t i = threadIdx.x * 4u + k;
-    v[k] = gptr(a.m_supers)[min(i, n_supers ? n_supers - 1u : 0u) * kSuperStride];
-    v[k] = i < n_supers ? v[k] : 0u;
-    t += v[k];
-  }
-  const uint32_t incl = wave_incl_scan(t, lane);
-  if (lane == 63) s_red4[wave] = incl;
-  __syncthreads();
-  uint32_t run = incl - t;
-  for (int k = 0; k < wave; k++) run += s_red4[k];
-#pragma unroll
-  for (uint32_t k = 0; k < 4u; k++) {
-    P[threadIdx.x * 4u + k] = run;
-    run += v[k];
-  }
-  if (threadIdx.x == 255) P[kSelectMaxSupers] = run;
-  __syncthreads();
-  const uint32_t V = P[kSelectMaxSupers];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    gptr(a.tri_cmd_w)[0] = V;         // cull_triangles_cmd.x
-    gptr(a.vis_w)[LATE ? 2 : 1] = V;  // visibility.early / .late
-  }
-  *nwords_out = (N + 63u) / 64u;
-  return V;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1617,14 +1477,9 @@ OXC_DEV uint32_t build_select_prefix(const TriTestArgs& a, uint32_t* P, uint32_t
 // (cull_triangles.slang:71-88 does that per 64-thread workgroup; a single address retires ~88 atomics per microsecond here, hence the
 // span), and the four waves write it the way tris_emit_body does.  No pass masks, chunk counts or visible ids go through memory and
 // no emit launch follows; the runs land in arrival order (ascending inside a span).
-// SELECT (round 5, with FUSED): no k_cull_meshlets_emit ran -- the block finds the ids of its span itself (select_visible_id) and writes
-// them to visible_meshlet_instances_indices as a by-product.
-template <bool LATE, bool WIDE, bool SMALL, bool FUSED = false, bool SELECT = false>
-OXC_DEV void tris_test_body(const TriTestArgs& a) {
-  static_assert(!SELECT || FUSED, "the select form is a form of the fused kernel");
-  set_half_denorm_flush();
-  constexpr int H = WIDE ? 2 : 1;
-  constexpr int S = 16;  // slots per wave per chunk
+// The two bodies of the triangle stage share the per-chunk pipeline (oxcull_tri_stages.inc / oxcull_tri_slots.inc):
+//   tris_test_body  -- ordered form: pass masks + per-chunk counts to memory, k_cull_triangles_emit follows;
+//   tris_fused_body -- unordered_output: the block also expands what it tested (FUSED above).
 #ifndef OXC_TRI_IDX_AHEAD
 #define OXC_TRI_IDX_AHEAD 2  // measured on config 3 (us per launch): 2/1 -> 123, 3/2 -> 125 (SGPR spills), 6 waves/SIMD with 3/2 or 4/3 -> 139-143; the loop version: 160
 #define OXC_TRI_POS_AHEAD 1
@@ -1633,16 +1488,6 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 #define OXC_TRI_WIDE_IDX_AHEAD OXC_TRI_IDX_AHEAD
 #define OXC_TRI_WIDE_POS_AHEAD OXC_TRI_POS_AHEAD
 #endif
-  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;  // position gathers (need the vertex ids) run this many slots ahead of the decision
-  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;  // vertex / micro index loads
-  constexpr int kRecAhead = kIdxAhead + 1;      // scalar: Meshlet record
-  constexpr int kRowAhead = kIdxAhead + 2;      // scalar: LOD pointers out of the InstCache row
-  typedef const uint32_t __attribute__((address_space(4))) * k32;
-  __shared__ uint32_t s_red[4];
-  constexpr uint32_t kFSpan = kFusedTriSpan;                // FUSED: visible meshlets per span = per atomic_add (64, 128 or 256)
-  constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;    // a block takes whole spans, chunk after chunk
-  static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
-  constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
 #ifndef OXC_TRI_LDS_VERTS
 // The corners of a triangle: nine ds_bpermute (36 B of LDS crossbar traffic per lane and pass) or, with the slot's transformed vertices written to
 // LDS once, three 16-byte reads per pass (64 B).  T = 64 (one pass per slot): the reads lose outright, fused kernels 99 / 209 -> 112 / 266 us.  WIDE
@@ -1650,51 +1495,28 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 // kept as a ballot: 136.5 / 262.6.  1 = WIDE only (default), 2 = every instantiation, 0 = ds_bpermute everywhere.
 #define OXC_TRI_LDS_VERTS 1
 #endif
+template <bool LATE, bool WIDE, bool SMALL>
+OXC_DEV void tris_test_body(const TriTestArgs& a) {
+  set_half_denorm_flush();
+  constexpr int H = WIDE ? 2 : 1;
+  constexpr int S = 16;  // slots per wave per chunk
+  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;  // position gathers (need the vertex ids) run this many slots ahead of the decision
+  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;  // vertex / micro index loads
+  constexpr int kRecAhead = kIdxAhead + 1;      // scalar: Meshlet record
+  constexpr int kRowAhead = kIdxAhead + 2;      // scalar: LOD pointers out of the InstCache row
+  typedef const uint32_t __attribute__((address_space(4))) * k32;
+  __shared__ uint32_t s_red[4];
   constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
   __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];  // per wave: the transformed vertices of the slot in hand (same-wave LDS traffic is in order)
-  __shared__ uint32_t f_off[FUSED ? kFSpan : 1];
-  __shared__ uint64_t f_mask[FUSED ? kFSpan * H : 1];
-  __shared__ uint32_t f_id[FUSED ? kFSpan : 1];
-  constexpr uint32_t kRun = SELECT ? kFusedRun : kEmitRun;  // (SELECT: the block also holds the prefix of the meshlet stage's sums; 8 blocks per CU have 20 KB each)
-  __shared__ __attribute__((aligned(16))) uint32_t f_run[FUSED ? 4 * (kRun + 8u) : 4];
-  __shared__ uint32_t f_base;
-  __shared__ uint32_t f_next;
-  constexpr bool kTickets = FUSED && OXC_FUSED_TICKETS != 0;
-  __shared__ uint32_t s_P[SELECT ? kSelectMaxSupers + 1u : 1u];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t nwords_m = 0;  // SELECT: ballot words the meshlet test wrote
-  (void)nwords_m;
-  const uint32_t V = [&]() -> uint32_t {
-    if constexpr (SELECT)
-      return build_select_prefix<LATE>(a, s_P, s_red, &nwords_m);
-    else
-      return a.tri_cmd[0];
-  }();
+  const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
-  const uint32_t nchunks = FUSED ? (V + kFSpan - 1) / kFSpan * kChunksPerSpan : (V + kTriChunk - 1) / kTriChunk;  // (FUSED: whole spans; a chunk beyond V re-does the last slot and leaves empty masks)
-  // kTickets: the spans of the first max(2, whole) rounds of the grid go by block index (span = block + round * grid), what is left of the
-  // last, partial round is drawn from a counter in arrival order -- only blocks that have a second span behind them draw, spread out in
-  // time (2 048 blocks drawing at the end of their FIRST span queue on the one address: early launch 99 -> 103 us)
-  const uint32_t static_spans = kTickets ? max(2u, nchunks / kChunksPerSpan / gridDim.x) * gridDim.x : 0u;
-  (void)static_spans;
-  for (uint32_t chunk = FUSED ? blockIdx.x * kChunksPerSpan : blockIdx.x; chunk < nchunks;
-       chunk = !FUSED ? chunk + gridDim.x : ((chunk % kChunksPerSpan) != kChunksPerSpan - 1u ? chunk + 1u : chunk - (kChunksPerSpan - 1u) + gridDim.x * kChunksPerSpan)) {
+  const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     // ---- lanes 0..15 fetch the MeshletInstance of this wave's 16 slots; everything that is uniform per
     // slot from there on (LOD pointers, Meshlet record, mvp) travels through scalar loads into SGPRs
     uint2 h_rec;
-    if constexpr (SELECT) {
-      if (chunk % kChunksPerSpan == 0u) {  // (block-uniform) first chunk of a span: its ids, by the waves that own a slot of it
-        if (threadIdx.x < kFSpan) {
-          const uint32_t raw = (chunk / kChunksPerSpan) * kFSpan + threadIdx.x;
-          const uint32_t id = select_visible_id(a.m_bits, s_P, nwords_m, min(raw, V - 1u), f_run + wave * (kRun + 8u), lane);
-          if (raw < V) gptr(a.visible_w)[first + raw] = id;
-          f_id[threadIdx.x] = id;
-        }
-        __syncthreads();
-      }
-      const uint32_t mli = f_id[(chunk % kChunksPerSpan) * kTriChunk + (uint32_t)(lane & 15) * 4 + wave];
-      h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
-    } else {
+    {
       const uint32_t slot = min(chunk * kTriChunk + (uint32_t)(lane & 15) * 4 + wave, V - 1u);
       const uint32_t mli = a.visible[first + slot];
       h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
@@ -1715,58 +1537,6 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 #define OXC_TRI_SLOT0 (chunk * kTriChunk)
 #include "oxcull_tri_slots.inc"
 #undef OXC_TRI_SLOT0
-    if constexpr (FUSED) {
-      (void)cnt;
-      const uint32_t c4 = chunk % kChunksPerSpan;
-      if (lane < S) {  // slot (chunk, j = lane, wave) sits at c4 * 64 + j * 4 + wave of the span (a slot beyond V left an empty mask)
-#pragma unroll
-        for (int h = 0; h < H; h++) f_mask[(c4 * kTriChunk + (uint32_t)lane * 4 + wave) * H + h] = (uint64_t)mlo[h] | ((uint64_t)mhi[h] << 32);
-      }
-      if (c4 != kChunksPerSpan - 1u) continue;  // (block-uniform)
-      __syncthreads();
-      // ---- the span is tested: allocate its run and expand it (tris_emit_body with the base taken from the counter itself)
-      const uint32_t slot = (chunk / kChunksPerSpan) * kFSpan + threadIdx.x;
-      const bool in_span = threadIdx.x < kFSpan;
-      uint32_t c = 0;
-#pragma unroll
-      for (int h = 0; h < H; h++) c += in_span ? (uint32_t)__popcll((unsigned long long)f_mask[(in_span ? threadIdx.x : 0u) * H + h]) : 0u;
-      uint32_t id = 0u;
-      if constexpr (!SELECT) id = (in_span && slot < V) ? a.visible[first + slot] : 0u;
-      (void)slot;
-      const uint32_t incl = wave_incl_scan(c, lane);
-      if (lane == 63) s_red[wave] = incl;
-      __syncthreads();
-      uint32_t woff = 0;
-      for (int k = 0; k < wave; k++) woff += s_red[k];
-      if (in_span) {
-        f_off[threadIdx.x] = woff + incl - c;
-        if constexpr (!SELECT) f_id[threadIdx.x] = id;  // (SELECT: the span's ids have been there since its first chunk)
-      }
-      if (threadIdx.x == 255) {
-        const uint32_t total3 = (woff + incl) * 3u;
-        uint32_t base = 0u, tk = 0u;
-        if (total3) base = __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // DrawIndexedIndirect.index_count
-        if constexpr (kTickets) {  // the span after this one, when it is a drawn one (both round trips overlap)
-          const uint32_t span_now = chunk / kChunksPerSpan;
-          if (span_now + gridDim.x >= static_spans && static_spans < nchunks / kChunksPerSpan)
-            tk = __hip_atomic_fetch_add(gptr(a.ticket), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          f_next = tk;
-        }
-        f_base = base;
-      }
-      __syncthreads();
-      expand_slots_wide<H, kCornerBits, kRun>(f_mask, f_id, wave * (int)(kFSpan / 4), (int)(kFSpan / 4), f_base + f_off[wave * (kFSpan / 4)] * 3u, a.out,
-                                              f_run + wave * (kRun + 8u), lane);
-      __syncthreads();  // the span's LDS rows are rewritten by the block's next span
-      if constexpr (kTickets) {
-        // (the loop header adds one grid of spans to the span just done: hand it the span before the drawn one, or one past everything)
-        const uint32_t nspans_all = nchunks / kChunksPerSpan;
-        const uint32_t span_now = chunk / kChunksPerSpan;
-        const uint32_t nxt = span_now + gridDim.x < static_spans ? span_now + gridDim.x : static_spans + f_next;
-        chunk = (nxt < nspans_all ? nxt - gridDim.x : nspans_all) * kChunksPerSpan + (kChunksPerSpan - 1u);
-        __syncthreads();  // (f_next is rewritten at the next span's end: every wave has read it)
-      }
-    } else {
     {
       const uint32_t slot = chunk * kTriChunk + (uint32_t)lane * 4 + wave;
       if (lane < S && slot < V) {
@@ -1782,6 +1552,131 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
       a.chunk_counts[chunk] = c;
       if (c) __hip_atomic_fetch_add(gptr(a.supers) + (chunk / kChunksPerSuper) * kSuperStride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+}
+
+// Work distribution of the fused kernel (round 5).  A work item is a run of 64-slot chunks of the pass's visible list that one block tests,
+// allocates with ONE atomic_add on index_count and expands: a SPAN (kFusedTriSpan slots, two chunks) or, at the end of the launch, a single
+// chunk.  The spans of the first max(1, whole) rounds of the grid go by block index (span = block + round * grid); what is left of the
+// last, partial round is handed out in CHUNKS, in arrival order, from kTriTicketCounters counters (counter x = block % K hands out the
+// chunks congruent to x mod K: 2 048 blocks drawing at the end of their first span would queue for 26 us on ONE address).  The early
+// launch of configs[2] is 2 524 spans on 2 048 resident blocks: with whole spans only, 476 blocks run a second span on a nearly empty
+// machine.  Measured on the configs[2] frame (tools/kbench.py, profiles/r05_ab): fused kernels 98.5 / 205.6 -> 97.1 / 200.5 us, frame
+// 511 -> 505 us with the emit launches in front; dynamic at span granularity gave half of it, a whole dynamic round more was worse.
+#ifndef OXC_FUSED_DYNAMIC
+#define OXC_FUSED_DYNAMIC 1  // 0: every span by block index (round 4)
+#endif
+constexpr uint32_t kTriTicketCounters = 16;
+template <bool LATE, bool WIDE, bool SMALL>
+OXC_DEV void tris_fused_body(const TriTestArgs& a) {
+  set_half_denorm_flush();
+  constexpr int H = WIDE ? 2 : 1;
+  constexpr int S = 16;  // slots per wave per chunk
+  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;
+  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;
+  constexpr int kRecAhead = kIdxAhead + 1;
+  constexpr int kRowAhead = kIdxAhead + 2;
+  typedef const uint32_t __attribute__((address_space(4))) * k32;
+  __shared__ uint32_t s_red[4];
+  constexpr uint32_t kFSpan = kFusedTriSpan;                // visible meshlets per span (64, 128 or 256)
+  constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;
+  static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
+  constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
+  constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
+  constexpr bool kDynamic = OXC_FUSED_DYNAMIC != 0 && kChunksPerSpan > 1u;
+  __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];
+  __shared__ uint32_t f_off[kFSpan];
+  __shared__ uint64_t f_mask[kFSpan * H];
+  __shared__ uint32_t f_id[kFSpan];
+  __shared__ __attribute__((aligned(16))) uint32_t f_run[4 * (kEmitRun + 8u)];
+  __shared__ uint32_t f_base;
+  __shared__ uint32_t f_next;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t V = a.tri_cmd[0];
+  const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
+  const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;  // 64-slot chunks of the list (a chunk's slots beyond V re-do the last slot and leave empty masks)
+  const uint32_t nspans = (nchunks + kChunksPerSpan - 1) / kChunksPerSpan;
+  // chunks [0, static_chunks): whole spans by block index; [static_chunks, nchunks): single chunks by ticket
+  const uint32_t static_chunks = kDynamic ? min(max(1u, nspans / gridDim.x) * gridDim.x * kChunksPerSpan, nchunks) : nchunks;
+  const uint32_t Kc = max(1u, min(min(kTriTicketCounters, gridDim.x), a.ticket_count)), kx = blockIdx.x % Kc;
+  uint32_t item = blockIdx.x * kChunksPerSpan;  // first chunk of the work item in hand ...
+  uint32_t item_n = kChunksPerSpan;             // ... and its length in chunks (block-uniform)
+  while (item < nchunks) {
+    const uint32_t item_slot0 = item * kTriChunk;  // first slot of the item; LDS rows are indexed relative to it
+    for (uint32_t c4 = 0; c4 < item_n; c4++) {
+      const uint32_t chunk = item + c4;
+      // ---- lanes 0..15 fetch the MeshletInstance of this wave's 16 slots; everything that is uniform per
+      // slot from there on (LOD pointers, Meshlet record, mvp) travels through scalar loads into SGPRs
+      uint2 h_rec;
+      {
+        const uint32_t slot = min(chunk * kTriChunk + (uint32_t)(lane & 15) * 4 + wave, V - 1u);
+        const uint32_t mli = a.visible[first + slot];
+        h_rec = reinterpret_cast<const uint2*>(a.meshlet_instances)[mli];
+      }
+#include "oxcull_tri_stages.inc"
+#pragma unroll
+      for (int j = 0; j < kRowAhead; j++) stage_row(j);
+#pragma unroll
+      for (int j = 0; j < kRecAhead; j++) stage_rec(j);
+#pragma unroll
+      for (int j = 0; j < kIdxAhead; j++) stage_idx(j);
+#pragma unroll
+      for (int j = 0; j < kPosAhead; j++) stage_pos(j);
+      uint32_t cnt = 0;
+      uint32_t mlo[H], mhi[H];  // lane j: pass mask(s) of slot j
+#pragma unroll
+      for (int h = 0; h < H; h++) mlo[h] = mhi[h] = 0;
+#define OXC_TRI_SLOT0 (chunk * kTriChunk)
+#include "oxcull_tri_slots.inc"
+#undef OXC_TRI_SLOT0
+      (void)cnt;
+      if (lane < S) {  // slot (chunk c4, j = lane, wave) sits at c4 * 64 + j * 4 + wave of the item (a slot beyond V left an empty mask)
+#pragma unroll
+        for (int h = 0; h < H; h++) f_mask[(c4 * kTriChunk + (uint32_t)lane * 4 + wave) * H + h] = (uint64_t)mlo[h] | ((uint64_t)mhi[h] << 32);
+      }
+    }
+    if (item_n < kChunksPerSpan && threadIdx.x >= item_n * kTriChunk && threadIdx.x < kFSpan) {  // a single chunk: the rest of the span's rows are empty
+#pragma unroll
+      for (int h = 0; h < H; h++) f_mask[threadIdx.x * H + h] = 0ull;
+    }
+    __syncthreads();
+    // ---- the item is tested: allocate its run and expand it (tris_emit_body with the base taken from the counter itself)
+    const uint32_t slot = item_slot0 + threadIdx.x;
+    const bool in_span = threadIdx.x < kFSpan;
+    uint32_t c = 0;
+#pragma unroll
+    for (int h = 0; h < H; h++) c += in_span ? (uint32_t)__popcll((unsigned long long)f_mask[(in_span ? threadIdx.x : 0u) * H + h]) : 0u;
+    const uint32_t id = (threadIdx.x < item_n * kTriChunk && slot < V) ? a.visible[first + slot] : 0u;
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) s_red[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wave; k++) woff += s_red[k];
+    if (in_span) {
+      f_off[threadIdx.x] = woff + incl - c;
+      f_id[threadIdx.x] = id;
+    }
+    // the block's next item: the span one grid further while that is a static one, a drawn chunk after that
+    const uint32_t next_static = item + gridDim.x * kChunksPerSpan;
+    const bool draw = kDynamic && static_chunks < nchunks && (item_n < kChunksPerSpan || next_static >= static_chunks);  // (block-uniform)
+    if (threadIdx.x == 255) {
+      const uint32_t total3 = (woff + incl) * 3u;
+      uint32_t base = 0u, tk = 0u;
+      if (total3) base = __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // DrawIndexedIndirect.index_count
+      if (draw) tk = __hip_atomic_fetch_add(gptr(a.ticket) + kx * kSuperStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (both round trips overlap)
+      f_next = tk;
+      f_base = base;
+    }
+    __syncthreads();
+    expand_slots_wide<H, kCornerBits>(f_mask, f_id, wave * (int)(kFSpan / 4), (int)(kFSpan / 4), f_base + f_off[wave * (kFSpan / 4)] * 3u, a.out,
+                                      f_run + wave * (kEmitRun + 8u), lane);
+    const uint32_t tk = f_next;
+    __syncthreads();  // the item's LDS rows (and f_next) are rewritten by the block's next item
+    if (draw) {
+      item = static_chunks + tk * Kc + kx;
+      item_n = 1u;
+    } else {
+      item = (kDynamic && next_static >= static_chunks) ? nchunks : next_static;
     }
   }
 }
@@ -2104,12 +1999,7 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
 }
 template <bool LATE, bool WIDE, bool SMALL>
 __global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused(TriTestArgs a) {
-  tris_test_body<LATE, WIDE, SMALL, true>(a);
-}
-// ... and the form that finds its ids itself (TriTestArgs::m_bits != null): no k_cull_meshlets_emit launch precedes it
-template <bool LATE, bool WIDE, bool SMALL>
-__global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused_select(TriTestArgs a) {
-  tris_test_body<LATE, WIDE, SMALL, true, true>(a);
+  tris_fused_body<LATE, WIDE, SMALL>(a);
 }
 
 // Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
@@ -2612,19 +2502,6 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_tri
 void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
   const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
-  if (a.m_bits) {
-    switch (v) {
-      case 0: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, false, false>), g, b, 0, s, a); break;
-      case 1: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, false, true>), g, b, 0, s, a); break;
-      case 2: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, true, false>), g, b, 0, s, a); break;
-      case 3: hipLaunchKernelGGL((k_cull_triangles_fused_select<false, true, true>), g, b, 0, s, a); break;
-      case 4: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, false, false>), g, b, 0, s, a); break;
-      case 5: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, false, true>), g, b, 0, s, a); break;
-      case 6: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, true, false>), g, b, 0, s, a); break;
-      default: hipLaunchKernelGGL((k_cull_triangles_fused_select<true, true, true>), g, b, 0, s, a); break;
-    }
-    return;
-  }
   switch (v) {
     case 0: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, false>), g, b, 0, s, a); break;
     case 1: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, true>), g, b, 0, s, a); break;

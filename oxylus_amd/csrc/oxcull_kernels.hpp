@@ -121,19 +121,10 @@ struct TriTestArgs {
   // cull_triangles.slang:71-88 does per workgroup) writes the packed indices and the draw command itself
   uint32_t* draw_cmd;
   uint32_t* out;  // reordered_indices
-  // round 5, fused kernel: spans beyond the grid are drawn from this counter (zeroed by the prepare kernel: the ordered form's
-  // first triangle super-chunk accumulator, which the fused form does not use)
+  // round 5, fused kernel: the chunks of the last, partial round of the grid are drawn from these counters (tris_fused_body; zeroed by the
+  // prepare kernel: the ordered form's triangle super-chunk accumulators, which the fused form does not use)
   uint32_t* ticket;
-  // round 5, "select" form (m_bits != null; HiZ meshlet stage of the same call, in order): no meshlet emit kernel ran -- the kernel finds
-  // the ids of its spans from the meshlet test's ballots (m_bits: one word per 64 candidates), per-step counts and per-64-step sums,
-  // and writes visible_meshlet_instances_indices, cull_triangles_cmd.x and visibility.early / .late itself
-  const uint64_t* m_bits;
-  const uint32_t* m_chunk_counts;
-  const uint32_t* m_supers;
-  uint32_t n_host, n_cap;  // as MeshletTestArgs: the list length (host-known or vis[0] clamped)
-  uint32_t* visible_w;
-  uint32_t* vis_w;
-  uint32_t* tri_cmd_w;
+  uint32_t ticket_count;  // counters behind `ticket` (stride kSuperStride words), >= 1
 };
 
 struct TriEmitArgs {
@@ -303,10 +294,7 @@ inline void expand_batch_core(const BatchCore& c, BatchElem& e) {
   tt.resolution[1] = c.cam.resolution[1];
   tt.draw_cmd = tt.out = nullptr;
   tt.ticket = nullptr;
-  tt.m_bits = nullptr;
-  tt.m_chunk_counts = tt.m_supers = nullptr;
-  tt.n_host = tt.n_cap = 0;
-  tt.visible_w = tt.vis_w = tt.tri_cmd_w = nullptr;
+  tt.ticket_count = 0;
   TriEmitArgs& te = e.temit;
   te.tri_masks = c.tri_masks;
   te.visible = c.visible_out;
@@ -383,7 +371,7 @@ void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool la
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
 void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s);
-// unordered_output: test + expansion in one launch (a.draw_cmd / a.out set); grid in 256-meshlet spans
+// unordered_output: test + expansion in one launch (a.draw_cmd / a.out set); grid in kFusedTriSpan-meshlet spans
 void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
 void launch_hiz(const HizArgs& a, uint32_t num_cus, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch

@@ -1,6 +1,6 @@
 """GPU: unordered_output (include/oxcull.h) -- the reference's own slot allocation (atomic_add on the counter: cull_meshlets.slang:55-70,
-cull_triangles.slang:71-88), aggregated per block through the ballots, one launch per stage; the HiZ meshlet stage keeps its ascending list
-and, in front of the fused triangle kernel, launches no emit kernel (the triangle kernel finds its ids from the ballots and writes the list).
+cull_triangles.slang:71-88), aggregated per block through the ballots, one launch per stage; the HiZ meshlet stage keeps its ordered emit and
+its ascending list.
 
 SURVEY 8c(1): "counts equal and sorted index arrays byte-identical".  The ordered form emits ascending lists (packed triangle indices
 ascend with (meshlet instance, triangle, corner)), so every list of an unordered call, sorted, must be the checker's bytes; the mask does
@@ -65,7 +65,6 @@ def test_plain_pipeline_unordered_is_the_ordered_set(renderer, oracle_lib, m, k,
         assert want["visible"].size > 64
 
 
-@pytest.mark.parametrize("select", [True, False], ids=["triangle-kernel-finds-its-ids", "meshlet-emit-kept"])
 @pytest.mark.parametrize("m,k,hw,p_mask,seed,share", [
     (300, 1000, 1024, 0.3, 11, False),  # the bench's shape
     (300, 1000, 1024, 0.3, 11, True),   # ... with the late call reusing the early call's camera tests
@@ -74,32 +73,43 @@ def test_plain_pipeline_unordered_is_the_ordered_set(renderer, oracle_lib, m, k,
     (3, 70, 256, 1.0, 14, False),       # less than one step, everything visible last frame
     (40, 1000, 1024, 0.0, 15, False),   # nothing visible last frame: the early call emits nothing
 ], ids=["bench-shape", "bench-shape-shared", "many-instances-per-step", "ragged-shared", "tiny", "cold-mask"])
-def test_two_pass_hiz_frame_unordered_is_the_ordered_set(renderer, oracle_lib, select, m, k, hw, p_mask, seed, share):
-    """Round 5: the fused triangle kernel behind a HiZ meshlet stage finds the ids of its spans itself from the ballots + counts and writes
-    the ascending visible list and the counters as a by-product -- no k_cull_meshlets_emit launch (select); OXC_TUNE_FUSED_SELECT = 0 keeps
-    the emit launch in front of it.  Same bytes either way."""
+def test_two_pass_hiz_frame_unordered_is_the_ordered_set(renderer, oracle_lib, m, k, hw, p_mask, seed, share):
     spec = SceneSpec(n_mesh_instances=m, meshlets_per_mesh=k, with_geometry=True, seed=seed)
     cpu, gpu, hiz, ohiz, mask = _hiz_setup(renderer, spec, hw, p_mask, seed)
     want = oracle_frame(cpu, use_hiz=True, hiz=ohiz, mask=mask, two_pass=True)
-    renderer.debug_set_tuning(L.TUNE_FUSED_SELECT, 1 if select else 0)
+    renderer.profile_begin()
+    got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=1, share_pass_tests=share)
+    ran = renderer.profile_end()["kernels"]
+    # the fused triangle kernel ran (no triangle emit launch); the HiZ meshlet stage keeps its ordered emit
+    assert "cull_triangles_emit" not in ran and "cull_triangles_emit_late" not in ran, sorted(ran)
+    assert "cull_meshlets_emit" in ran and "cull_meshlets_emit_late" in ran, sorted(ran)
+    assert_same(want, sorted_lists(got), HIZ_KEYS)
+    for tag in ("early", "late"):
+        if got[f"{tag}_indices"].size:
+            assert_triangles_adjacent(got[f"{tag}_indices"])
+    assert_same(want, got, ["early_visible", "late_visible"])  # the visible lists are ascending as they stand
+    assert got["share_modes"] == ([1, 3] if share else [0, 0])
+    # a second frame on the same seeded context re-zeroes what the appending kernels add to
+    again = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=1, share_pass_tests=share)
+    assert_same(want, sorted_lists(again), HIZ_KEYS)
+
+
+def test_fused_triangle_kernel_with_more_spans_than_blocks_draws_its_last_chunks(renderer, oracle_lib):
+    """Round 5: the chunks of the last, partial round of the fused kernel's grid are handed out by ticket (tris_fused_body).  With the
+    grid capped at ONE block per CU (OXC_TUNE_TRI_BLOCKS_PER_CU) a small scene has several rounds of spans and a drawn remainder; the
+    list, sorted, must still be the ordered form's."""
+    spec = SceneSpec(n_mesh_instances=400, meshlets_per_mesh=1000, with_geometry=True, seed=41)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    want = oracle_frame(cpu)
+    renderer.debug_set_tuning(L.TUNE_TRI_BLOCKS_PER_CU, 1)
     try:
-        renderer.profile_begin()
-        got = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=1, share_pass_tests=share)
-        ran = renderer.profile_end()["kernels"]
-        assert ("cull_meshlets_emit" in ran) == (not select) and ("cull_meshlets_emit_late" in ran) == (not select), sorted(ran)
-        assert "cull_triangles_emit" not in ran and "cull_triangles_emit_late" not in ran, sorted(ran)
-        assert_same(want, sorted_lists(got), HIZ_KEYS)
-        for tag in ("early", "late"):
-            if got[f"{tag}_indices"].size:
-                assert_triangles_adjacent(got[f"{tag}_indices"])
-        # the visible lists are ascending as they stand (written by the emit kernel or by the triangle kernel)
-        assert_same(want, got, ["early_visible", "late_visible"])
-        assert got["share_modes"] == ([1, 3] if share else [0, 0])
-        # a second frame on the same seeded context re-zeroes what the appending kernels add to
-        again = gpu_frame(renderer, gpu, use_hiz=True, hiz=hiz, mask=mask, two_pass=True, unordered_output=1, share_pass_tests=share)
-        assert_same(want, sorted_lists(again), HIZ_KEYS)
+        got = gpu_frame(renderer, gpu, unordered_output=1)
     finally:
-        renderer.debug_set_tuning(L.TUNE_FUSED_SELECT, 1)
+        renderer.debug_set_tuning(L.TUNE_TRI_BLOCKS_PER_CU, 8)
+    assert want["visible"].size > 3 * 256 * 128  # more spans than three rounds of one block per CU
+    assert_same(want, sorted_lists(got), ["visible", "indices"])
+    assert_triangles_adjacent(got["indices"])
 
 
 def test_unordered_output_values_other_than_0_and_1_are_refused(renderer):
