@@ -850,11 +850,17 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.ticket_count = std::max(pa.n_supers_tris, 1u);
     if (unord_tris) {  // one launch: test + expansion per span of 256 visible meshlets
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
-      launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap), ts);
+      // (the default cap is "one resident round": of the instantiation that runs, which the launcher knows; a cap set by hand stands)
+      const bool default_cap = !(async && ctx->async_tri_per_cu) && ctx->tri_blocks_per_cu == kTriangleBlocksPerCU;
+      launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap),
+                        default_cap ? ctx->num_cus : 0u, ts);
     } else {
     {
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
-      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, tri_grid_cap), ts);
+      // (the ordered test kernel walks 64-meshlet chunks with a grid stride: with the default cap it takes four resident rounds of blocks and
+      //  lets the dispatcher balance them -- late launch 149.6 -> 140.3 us on the configs[2] frame; a cap set by hand stands)
+      const bool default_cap = !(async && ctx->async_tri_per_cu) && ctx->tri_blocks_per_cu == kTriangleBlocksPerCU;
+      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, (default_cap && !c->wide_triangle_index) ? ctx->num_cus * 32u : tri_grid_cap), ts);  // (WIDE, 4 waves per SIMD: 8 per CU measured better than 32)
     }
     TriEmitArgs te;
     te.tri_masks = ctx->lane[0].tri_masks;

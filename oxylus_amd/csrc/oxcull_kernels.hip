@@ -2499,19 +2499,31 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_tri
     default: hipLaunchKernelGGL((k_cull_triangles_test<true, true, true>), g, b, 0, s, a); break;
   }
 }
-void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s) {
-  dim3 g(grid), b(256);
+// resident_cus != 0: the grid is also capped at the blocks of THIS instantiation that are resident at once on that many CUs (occupancy
+// query).  The fused kernel hands out its work by rounds of the grid (tris_fused_body): a grid of two resident rounds -- the WIDE
+// instantiations run 4 waves per SIMD, the generic cap was 8 blocks per CU -- cost the 8 M x 124-triangle frame 33 us (0.562 -> 0.529 ms).
+void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, uint32_t resident_cus, hipStream_t s) {
+  dim3 b(256);
   const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
-  switch (v) {
-    case 0: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, false>), g, b, 0, s, a); break;
-    case 1: hipLaunchKernelGGL((k_cull_triangles_fused<false, false, true>), g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_cull_triangles_fused<false, true, false>), g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_cull_triangles_fused<false, true, true>), g, b, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_cull_triangles_fused<true, false, false>), g, b, 0, s, a); break;
-    case 5: hipLaunchKernelGGL((k_cull_triangles_fused<true, false, true>), g, b, 0, s, a); break;
-    case 6: hipLaunchKernelGGL((k_cull_triangles_fused<true, true, false>), g, b, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_cull_triangles_fused<true, true, true>), g, b, 0, s, a); break;
+#define OXC_FUSED_CASE(i, L_, W_, S_)                                                                              \
+  case i: {                                                                                                        \
+    static const uint32_t per_cu = resident_grid(k_cull_triangles_fused<L_, W_, S_>, 256, 1);                      \
+    const uint32_t g = resident_cus ? std::min(grid, per_cu * resident_cus) : grid;                                \
+    hipLaunchKernelGGL((k_cull_triangles_fused<L_, W_, S_>), dim3(std::max(g, 1u)), b, 0, s, a);                   \
+    break;                                                                                                         \
   }
+  switch (v) {
+    OXC_FUSED_CASE(0, false, false, false)
+    OXC_FUSED_CASE(1, false, false, true)
+    OXC_FUSED_CASE(2, false, true, false)
+    OXC_FUSED_CASE(3, false, true, true)
+    OXC_FUSED_CASE(4, true, false, false)
+    OXC_FUSED_CASE(5, true, false, true)
+    OXC_FUSED_CASE(6, true, true, false)
+    default:
+      OXC_FUSED_CASE(7, true, true, true)
+  }
+#undef OXC_FUSED_CASE
 }
 void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);

@@ -5,7 +5,7 @@
 # counter_collection CSVs, cut down to this library's kernels -- are kept gzipped under gpurun_out/profiles_out/raw/ (round 3 kept
 # only the summaries: they could not be re-derived).  Copy both into profiles/ afterwards.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 rm -rf gpurun_out/raw; mkdir -p gpurun_out/raw gpurun_out/profiles_out/raw
@@ -21,7 +21,7 @@ keep_raw() {  # keep_raw <name> <trace dir> <pmc dir>
 ./tools/profile_trace.sh gpurun_out/raw/trace_c3 --steps 3 --warmup 1 > /dev/null
 BENCH_ARGS="--steps 1 --warmup 1 --inner-reps 8" ./tools/pmc_passes.sh gpurun_out/raw/pmc_c3 > /dev/null
 python tools/summarize_profiles.py ${TAG}_config3_pmc --stats $(find gpurun_out/raw/trace_c3 -name t_kernel_stats.csv | head -1) --pmc gpurun_out/raw/pmc_c3 \
-  --note "bench.py default (configs[2]: 10M meshlets + 4096^2 HiZ, full path, share_pass_tests + unordered_output 1), --steps 3 --warmup 1 (kernel trace, inner_reps 48) / --steps 1 --warmup 1 --inner-reps 8 (PMC passes); kernel_trace_stats from rocprofv3 --kernel-trace --stats, pmc from separate --pmc passes; raw CSVs: profiles/raw/${TAG}_config3_*.csv.gz"
+  --note "bench.py default (configs[2]: 10M meshlets + 4096^2 HiZ, full path, share_pass_tests + unordered_output 1: fused triangle kernel with the last partial round handed out in chunks), --steps 3 --warmup 1 (kernel trace, inner_reps 48) / --steps 1 --warmup 1 --inner-reps 8 (PMC passes); kernel_trace_stats from rocprofv3 --kernel-trace --stats, pmc from separate --pmc passes; raw CSVs: profiles/raw/${TAG}_config3_*.csv.gz"
 cp gpurun_out/raw/trace_c3/bench.json gpurun_out/profiles_out/${TAG}_config3_trace_bench.json
 keep_raw config3 gpurun_out/raw/trace_c3 gpurun_out/raw/pmc_c3
 # the ordered form of the same frame (the library's default list layout): kernel trace only
@@ -38,18 +38,21 @@ keep_raw config2 gpurun_out/raw/trace_c2 gpurun_out/raw/pmc_c2
 ./tools/profile_trace.sh gpurun_out/raw/trace_c5 --workload config5 > /dev/null
 BENCH_ARGS="--workload config5 --steps 8 --warmup 2" ./tools/pmc_passes.sh gpurun_out/raw/pmc_c5 > /dev/null
 python tools/summarize_profiles.py ${TAG}_config5_pmc --stats $(find gpurun_out/raw/trace_c5 -name t_kernel_stats.csv | head -1) --pmc gpurun_out/raw/pmc_c5 \
-  --note "bench.py --workload config5 (configs[4]: 10M meshlets x 16 cascade views, implicit MeshletInstance lists); rocprofv3 --kernel-trace --stats + separate --pmc passes; raw CSVs: profiles/raw/${TAG}_config5_*.csv.gz"
+  --note "bench.py --workload config5 (configs[4]: 10M meshlets x 16 cascade views, explicit MeshletInstance lists written on the side stream); rocprofv3 --kernel-trace --stats + separate --pmc passes; raw CSVs: profiles/raw/${TAG}_config5_*.csv.gz"
 keep_raw config5 gpurun_out/raw/trace_c5 gpurun_out/raw/pmc_c5
 ./tools/profile_trace.sh gpurun_out/raw/trace_t124 --tris 124 --steps 3 --warmup 1 > /dev/null
-python tools/summarize_profiles.py ${TAG}_tris124_trace --stats $(find gpurun_out/raw/trace_t124 -name t_kernel_stats.csv | head -1) \
-  --note "bench.py --tris 124 (8M meshlets x 124 triangles, wide_triangle_index), --steps 3 --warmup 1; rocprofv3 --kernel-trace --stats"
+# (round 5: the WIDE kernels get their HBM counters too -- FETCH_SIZE / WRITE_SIZE passes only)
+mkdir -p gpurun_out/raw/pmc_t124
+( cd /tmp && export TMPDIR=/tmp && for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed s/_size//); rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/gpurun_out/raw/pmc_t124/$d" -o p -- python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab --no-configs0 --tris 124 --steps 1 --warmup 1 --inner-reps 8 > /dev/null 2> "$ROOT/gpurun_out/raw/pmc_t124/$d.log"; done )
+python tools/summarize_profiles.py ${TAG}_tris124_pmc --stats $(find gpurun_out/raw/trace_t124 -name t_kernel_stats.csv | head -1) --pmc gpurun_out/raw/pmc_t124 \
+  --note "bench.py --tris 124 (8M meshlets x 124 triangles, wide_triangle_index), --steps 3 --warmup 1 (kernel trace) / --steps 1 --warmup 1 --inner-reps 8 (FETCH_SIZE and WRITE_SIZE passes); rocprofv3 --kernel-trace --stats + separate --pmc passes"
 cp gpurun_out/raw/trace_t124/bench.json gpurun_out/profiles_out/${TAG}_tris124_trace_bench.json
-keep_raw tris124 gpurun_out/raw/trace_t124 /nonexistent
+keep_raw tris124 gpurun_out/raw/trace_t124 gpurun_out/raw/pmc_t124
 ./tools/profile_trace.sh gpurun_out/raw/trace_vsm --workload vsm > /dev/null
 python tools/summarize_profiles.py ${TAG}_vsm_trace --stats $(find gpurun_out/raw/trace_vsm -name t_kernel_stats.csv | head -1) \
   --note "bench.py --workload vsm (10M meshlets x 10 dirty clipmap views, generate_hpb + cull_meshes + cull_meshlets_hpb); rocprofv3 --kernel-trace --stats"
 keep_raw vsm gpurun_out/raw/trace_vsm /nonexistent
 mv profiles/${TAG}_vsm_trace.json gpurun_out/profiles_out/ 2>/dev/null
-mv profiles/${TAG}_config2_pmc.json profiles/${TAG}_config3_pmc.json profiles/${TAG}_config5_pmc.json profiles/${TAG}_config3_ordered_trace.json profiles/${TAG}_tris124_trace.json gpurun_out/profiles_out/ 2>/dev/null
+mv profiles/${TAG}_config2_pmc.json profiles/${TAG}_config3_pmc.json profiles/${TAG}_config5_pmc.json profiles/${TAG}_config3_ordered_trace.json profiles/${TAG}_tris124_pmc.json gpurun_out/profiles_out/ 2>/dev/null
 rm -rf gpurun_out/raw
 ls -la gpurun_out/profiles_out gpurun_out/profiles_out/raw; du -sh gpurun_out/profiles_out

@@ -5,5 +5,5 @@ OUT=${1:-gpurun_out/trace}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT" -o t -- python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab "$@" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/err.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT" -o t -- python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab --no-configs0 "$@" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/err.log"
 head -c 600 "$ROOT/$OUT/bench.json"; echo; ls "$ROOT/$OUT"
