@@ -304,7 +304,11 @@ oxc_status wait_triangles(oxc_ctx* ctx, hipStream_t s, Pred needed, bool retire 
   for (auto& tp : ctx->tri) {
     if (!tp.valid) continue;
     if (tp.capture_id != cid) {
-      if (cid == 0) tp.valid = false;
+      // An entry of another capture is forgotten by an un-captured call only once that capture has ENDED (the graph orders the stage at
+      // every replay).  While it is still open -- the side stream joined it through the fork event and stays in capture mode until the
+      // stage is joined -- the entry must survive an un-captured call made in between: the oxc_join_triangles inside the capture still
+      // has to find it (round-4 advisor finding).
+      if (cid == 0 && !(ctx->side && stream_capture_id(ctx->side) == tp.capture_id)) tp.valid = false;
       continue;
     }
     if (!needed(tp)) continue;
@@ -848,7 +852,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     tt.ticket = t_supers;  // (zeroed by this call's prepare kernel; the fused form has no other use for the accumulators)
     tt.ticket_count = std::max(pa.n_supers_tris, 1u);
-    if (unord_tris) {  // one launch: test + expansion per span of 256 visible meshlets
+    if (unord_tris) {  // one launch: test + expansion per work item (a span of kFusedTriSpan visible meshlets, or a chunk of it)
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
       // (the default cap is "one resident round": of the instantiation that runs, which the launcher knows; a cap set by hand stands)
       const bool default_cap = !(async && ctx->async_tri_per_cu) && ctx->tri_blocks_per_cu == kTriangleBlocksPerCU;

@@ -1472,11 +1472,11 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
 // SMALL (extension, include/oxcull.h small_triangle_cull): after the two reference tests, drop a triangle whose
 // screen-space bounding box covers no pixel centre.  The screen position is computed once per vertex (lane = vertex,
 // two IEEE divisions) and fetched per corner like the clip coordinates; with SMALL off none of it is compiled in.
-// FUSED (unordered_output, include/oxcull.h): the block also expands what it tested -- per span of 256 visible meshlets (four chunks)
-// the pass masks stay in LDS, ONE returning atomic_add on DrawIndexedIndirect.index_count allocates the span's run of packed indices
-// (cull_triangles.slang:71-88 does that per 64-thread workgroup; a single address retires ~88 atomics per microsecond here, hence the
-// span), and the four waves write it the way tris_emit_body does.  No pass masks, chunk counts or visible ids go through memory and
-// no emit launch follows; the runs land in arrival order (ascending inside a span).
+// FUSED (unordered_output, include/oxcull.h; tris_fused_body): the block also expands what it tested -- per work item (a span of kFusedTriSpan =
+// 128 visible meshlets, two chunks, or a single chunk at the end of the launch) the pass masks stay in LDS, ONE returning atomic_add on
+// DrawIndexedIndirect.index_count allocates the item's run of packed indices (cull_triangles.slang:71-88 does that per 64-thread workgroup; a
+// single address retires ~88 atomics per microsecond here, hence the span), and the four waves write it the way tris_emit_body does.  No
+// pass masks, chunk counts or visible ids go through memory and no emit launch follows; the runs land in arrival order (ascending inside an item).
 // The two bodies of the triangle stage share the per-chunk pipeline (oxcull_tri_stages.inc / oxcull_tri_slots.inc):
 //   tris_test_body  -- ordered form: pass masks + per-chunk counts to memory, k_cull_triangles_emit follows;
 //   tris_fused_body -- unordered_output: the block also expands what it tested (FUSED above).

@@ -117,7 +117,7 @@ struct TriTestArgs {
   uint32_t* chunk_counts;
   uint32_t* supers;
   float resolution[2];  // cull_camera.resolution: read by the small-triangle variants only
-  // unordered_output: the fused kernel (test + expansion of a 256-meshlet span in one launch; slots by atomic_add on index_count, as
+  // unordered_output: the fused kernel (test + expansion of a kFusedTriSpan-meshlet span in one launch; slots by atomic_add on index_count, as
   // cull_triangles.slang:71-88 does per workgroup) writes the packed indices and the draw command itself
   uint32_t* draw_cmd;
   uint32_t* out;  // reordered_indices
