@@ -387,6 +387,11 @@ class RendererInstance:
         """Harness knobs (L.TUNE_*): async stage grid caps, the raster queues' capacity (before the first draw)."""
         self._check(self._lib.oxc_debug_set_tuning(self._ctx, knob, value))
 
+    def debug_count_occlusion_candidates(self, counters):
+        """Measurement aid (include/oxcull.h): `counters` = int32 CUDA tensor of 256 * 64 zeros (or None to switch it off); the HiZ calls that follow
+        run the counting instantiations of their meshlet test, which add the candidates that reach test_occlusion to it (sum = the count)."""
+        self._check(self._lib.oxc_debug_count_occlusion_candidates(self._ctx, C.c_void_p(counters.data_ptr()) if counters is not None else None))
+
     def debug_shared_tests_mode(self) -> int:
         """What share_pass_tests did in the last cull_geometry call: 0 tested on its own, 1 early call that published, 2 late call that reused,
         3 late call that reused and needed no prepare kernel."""

@@ -223,3 +223,55 @@ def test_in_hip_graphs(oracle_lib):
         g2.replay()
         check(e, l, f"late alone, replay {rep}")
     r.close()
+
+
+@pytest.mark.parametrize("share", [False, True], ids=["each-call-tests", "share_pass_tests"])
+def test_occlusion_candidate_count_is_the_camera_test_survivors(renderer, oracle_lib, share):
+    """oxc_debug_count_occlusion_candidates (round 5: SURVEY 8d's f in the bench's rooflines): the counting instantiations of the HiZ meshlet tests
+    add the candidates that REACH test_occlusion -- in the late call every meshlet that passes frustum and cone (cull_meshlets_hiz.slang:53-65), in
+    the early call those of them that were visible last frame -- and leave every output as it is."""
+    import oracle
+    from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame
+    from oxylus_amd.synth import make_depth
+
+    spec = SceneSpec(n_mesh_instances=260, meshlets_per_mesh=700, with_geometry=True, seed=77)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    hw = 512
+    depth = make_depth(2 * hw, 2 * hw, 48, seed=9, device="cuda")
+    hiz = ImageAttachment.hiz(hw, hw, "cuda")
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth), hiz))
+    want_hiz, levels, offs = oracle_hiz(depth.cpu(), hw, hw)
+    n = cpu.n_meshlet_instances
+    g = torch.Generator().manual_seed(5)
+    bits = (torch.rand(((n + 31) // 32, 32), generator=g) < 0.4).to(torch.int64)
+    mask = (bits << torch.arange(32)).sum(1).to(torch.int32)
+    want = oracle_frame(cpu, use_hiz=True, hiz={"data": want_hiz, "w": hw, "h": hw, "levels": levels, "offs": offs}, mask=mask, two_pass=True)
+    # the camera tests alone (frustum + cone) through the plain checker: the late call's candidates; the early call's are those with their mask bit set
+    cam_pass = oracle.cull_meshlets(cpu, cpu.cull_camera(), cpu.meshlet_instances).numpy().astype(np.int64)
+    was = ((mask.numpy().view(np.uint32)[cam_pass >> 5] >> (cam_pass & 31).astype(np.uint32)) & 1).astype(bool)
+    frame = PreparedFrame.create(gpu, with_triangles=True)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), hiz_attachment=hiz, stages=L.STAGE_ALL,
+                              share_pass_tests=share)
+    renderer.seed_meshlet_instances(ctx, n)
+    frame.meshlet_instance_visibility_mask_buffer.copy_(mask.cuda())
+    counts = []
+    try:
+        for tag, flags in (("early", L.CULL_TEST_ALL), ("late", L.CULL_TEST_ALL | L.CULL_LATE_PASS)):
+            cnt = torch.zeros(256 * 64, dtype=torch.int32, device="cuda")
+            renderer.debug_count_occlusion_candidates(cnt)
+            ctx.cull_flags = flags
+            renderer.cull_geometry(ctx)
+            c = renderer.read_counters(ctx)
+            counts.append(int(cnt.to(torch.int64).sum().item()))
+            first = c.early_visible_meshlet_instances if tag == "late" else 0
+            vis = frame.visible_meshlet_instances_indices_buffer[first:first + c.cull_triangles_cmd_x].cpu().numpy()
+            assert np.array_equal(vis, want[f"{tag}_visible"]), tag
+            idx = frame.reordered_indices_buffer[:c.draw_index_count].cpu().numpy()
+            assert np.array_equal(idx.view(np.uint32), want[f"{tag}_indices"].view(np.uint32)), tag
+    finally:
+        renderer.debug_count_occlusion_candidates(None)
+    assert np.array_equal(frame.meshlet_instance_visibility_mask_buffer.cpu().numpy(), want["mask"])
+    assert counts == [int(was.sum()), int(cam_pass.size)], (counts, int(was.sum()), int(cam_pass.size))
+    assert 0 < counts[0] < counts[1] < n

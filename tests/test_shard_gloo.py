@@ -159,6 +159,39 @@ def test_two_rank_multiview_shards_union_equals_single(tmp_path, oracle_lib):
     assert seen > 30  # (the small cascades see little of a 23-instance scene; the wide ones most of it)
 
 
+@pytest.mark.parametrize("block", [0, 8], ids=["contiguous", "blocks-of-8"])
+def test_one_scene_shards_are_placed_on_the_whole_scenes_grid(block):
+    """bench.py --one-scene: a rank generates only its own instances but PLACES them where the whole scene's grid puts their global indices
+    (make_scene(global_ids, global_total)): every instance of every shard sits in the grid cell of its global index, the cells of all ranks
+    together are all cells, and contiguous ranges are depth slabs (the generator's grid runs far to near with the index)."""
+    import math
+
+    from oxylus_amd.shard import shard_ranges
+    from oxylus_amd.synth import SceneSpec, make_scene
+
+    M, world, D = 216, 4, 200.0
+    n_side = math.ceil(M ** (1.0 / 3.0))
+    seen, mean_z = [], []
+    for rank in range(world):
+        mine = shard_ranges(M, world, block)[rank]
+        mine = [mine] if block <= 0 else mine
+        gids = torch.cat([torch.arange(a, b, dtype=torch.int64) for a, b in mine])
+        sc = make_scene(SceneSpec(n_mesh_instances=int(gids.numel()), meshlets_per_mesh=4, with_geometry=False, seed=11 + rank, scene_depth=D), "cpu",
+                        global_ids=gids, global_total=M)
+        pos = sc.transforms.view(-1, 4, 4)[:, 3, 0:3]
+        u = torch.stack([pos[:, 0] / D + 0.5, pos[:, 1] / D + 0.5, (pos[:, 2] + D) / (1.1 * D)], 1) * n_side
+        cell = torch.floor(u).to(torch.int64).clamp_(0, n_side - 1)
+        want = torch.stack([gids % n_side, (gids // n_side) % n_side, gids // (n_side * n_side)], 1)
+        assert torch.equal(cell, want), f"rank {rank}"
+        seen.append(gids)
+        mean_z.append(float(pos[:, 2].mean()))
+    assert torch.equal(torch.sort(torch.cat(seen))[0], torch.arange(M))
+    if block == 0:
+        assert all(mean_z[k] < mean_z[k + 1] for k in range(world - 1))  # slabs, far to near
+    else:
+        assert max(mean_z) - min(mean_z) < 0.25 * D                        # interleaved blocks: every rank spans the depth range
+
+
 def test_interleaved_shard_ranges_cover_and_disjoint():
     from oxylus_amd.shard import shard_ranges
 
