@@ -14,8 +14,9 @@ given prior-visibility mask):
 A frame takes well under a millisecond, so a STEP is `inner_reps` frames (stated in config) -- 20 steps are >= 0.5 s of GPU
 work and `value` is not launch latency.  All inputs are generated in HBM; the ABI takes device pointers (no PCIe in the loop).
 
-N > 1 = configs[3]: the meshlet-instance array shards by contiguous range, 12.5M per rank ("100M sharded 8 ways"; weak
-scaling), shard-local ids and outputs.  Rank 0 builds the pyramid and broadcasts its top (levels >= 2, 5.6 MB; `--hiz-exchange whole`:
+N > 1 = configs[3]: ONE scene of N x 12.5M meshlets ("100M sharded 8 ways"; weak scaling) whose mesh instances are dealt to the ranks
+in interleaved blocks of 64 instances (SURVEY 8e's mitigation; --shard-block 0: contiguous ranges, which are depth slabs of this scene and
+skewed -- a short nested run times that form too, "assignment_ab"; --independent-scenes: rounds 1-4's one scene per rank), shard-local ids and outputs.  Rank 0 builds the pyramid and broadcasts its top (levels >= 2, 5.6 MB; `--hiz-exchange whole`:
 all 89.5 MB) over RCCL/xGMI, the other ranks build levels 0-1 from their copy of the depth image; the per-rank counters
 {emitted, early, late, index_count} are all-gathered every frame.  The HiZ a frame culls against is the PRIOR frame's, so its
 build + broadcast run one frame ahead on a second stream (double-buffered pyramid) and overlap the cull.
@@ -93,11 +94,13 @@ def parse():
                          "(5.6 MB at level 2) and every rank builds the lower levels from its own copy of the prior-frame depth image; 'whole' = rank 0 "
                          "broadcasts every level (89.5 MB; assumes nothing about the other ranks).  Same pyramid bytes on every rank either way.")
     ap.add_argument("--hiz-top-level", type=int, default=2)
-    ap.add_argument("--one-scene", action="store_true", help="N > 1: the ranks cull the shards of ONE spatially coherent scene (every rank's instances are placed where the whole "
-                                                             "scene's grid puts their global indices) instead of one independent scene each, so that visibility skew between the shards "
-                                                             "shows (per_rank_visible beside per_rank_ms_per_frame)")
-    ap.add_argument("--shard-block", type=int, default=0, help="with --one-scene: 0 = contiguous instance ranges (default), B > 0 = interleaved blocks of B mesh instances "
-                                                                "(SURVEY 8e: 64 instances x 1000 meshlets = 64k meshlets)")
+    ap.add_argument("--independent-scenes", action="store_true", help="N > 1: every rank generates a scene of its own (rounds 1-4's form: no visibility skew between ranks by construction) "
+                                                                      "instead of culling its shard of ONE spatially coherent scene (the default since round 5: every rank's instances are placed where "
+                                                                      "the whole scene's grid puts their global indices; per_rank_visible beside per_rank_ms_per_frame)")
+    ap.add_argument("--one-scene", action="store_true", help="(the default for N > 1 since round 5; kept for older command lines)")
+    ap.add_argument("--shard-block", type=int, default=64, help="N > 1, one scene: B > 0 = interleaved blocks of B mesh instances dealt round robin (default 64: SURVEY 8e's 64 instances x 1000 "
+                                                                 "meshlets = 64k meshlets), 0 = contiguous instance ranges (depth slabs of the synthetic scene: skewed)")
+    ap.add_argument("--no-assignment-ab", action="store_true", help="N > 1, one scene: skip the nested short run with the OTHER assignment (contiguous ranges <-> interleaved blocks)")
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: run the two exchanges (counter all-gather, HiZ broadcast) through the C ABI's RCCL entry points "
                          "(oxc_exchange_counts / oxc_broadcast_hiz) instead of torch.distributed; the rendezvous stays torch.distributed")
@@ -360,7 +363,7 @@ def bench_config3(args, e):
     shard_desc = None
     world_meshlets = n_meshlets * world  # meshlets all ranks cull per frame
     with torch.cuda.stream(stream):
-        if args.one_scene and world > 1:
+        if world > 1 and not args.independent_scenes:
             # ONE scene of M x world instances, sharded: contiguous ranges of the instance index (= slabs of the scene's grid, far to near) or
             # interleaved blocks (oxylus_amd/shard.py shard_ranges); a rank generates only its own instances, placed by their global indices
             from oxylus_amd.shard import shard_ranges
@@ -1181,6 +1184,13 @@ def line_summary(line: dict) -> dict:
             sm[key] = round(v["ms_per_frame"], 4)
             sm.setdefault("variants_match", True)
             sm["variants_match"] = bool(sm["variants_match"] and v["outputs_match_main_line"])
+    sh = g(line, "config", "sharding")
+    if isinstance(sh, dict):  # N > 1
+        sm["sharding"] = {"assignment": g(sh, "scene", "assignment") or "an independent scene per rank", "per_rank_visible": sh.get("per_rank_visible"),
+                          "per_rank_ms_per_frame": sh.get("per_rank_ms_per_frame")}
+        if "assignment_ab" in line:
+            ab = line["assignment_ab"]
+            sm["sharding"]["other_assignment"] = {k: ab[k] for k in ("assignment", "value", "ms_per_frame", "per_rank_visible")}
     if "tris124" in line:
         sm["tris124"] = {"ms_per_frame": g(line, "tris124", "ms_per_frame", nd=4), "frac": g(line, "tris124", "roofline", "frac"), "stage_frac": g(line, "tris124", "stage", "stage_frac"),
                          "traffic": g(line, "tris124", "roofline", "traffic"), "bit_match": g(line, "tris124", "bit_match")}
@@ -1238,6 +1248,21 @@ def main():
 
         stage_note("configs[2] main line")
         line = bench_config3(args, e)
+        if e.world > 1 and not args.independent_scenes and not args.no_assignment_ab:
+            # the OTHER assignment of the same scene, a short run: contiguous instance ranges (the north star's wording; depth slabs of this
+            # synthetic scene, i.e. skewed) beside the interleaved blocks of the main line, or the reverse -- per_rank_visible tells them apart
+            import copy
+
+            a3 = copy.copy(args)
+            a3.shard_block = 0 if args.shard_block > 0 else 64
+            a3.steps, a3.warmup = max(2, args.steps // 4), 1
+            a3.no_scheduling_ab, a3.no_cpu_baseline, a3.no_exchange_ab, a3.cpu_prefix = True, True, True, min(args.cpu_prefix, 100)
+            stage_note("assignment_ab")
+            t = bench_config3(a3, e)
+            if e.rank == 0:
+                sh = t["config"]["sharding"]
+                line["assignment_ab"] = {"assignment": sh["scene"]["assignment"], "value": t["value"], "ms_per_frame": t["config"]["ms_per_frame"], "frames_timed": t["config"]["frames_timed"],
+                                         "per_rank_visible": sh["per_rank_visible"], "per_rank_ms_per_frame": sh["per_rank_ms_per_frame"], "bit_match": t["bit_match"]}
         if e.world == 1 and not args.no_tris124 and args.tris == 64 and not args.meshlets:
             # BASELINE's stated meshlet shape -- 64 vertices / 124 triangles -- does not fit the reference's 24 + 8 bit packed index: the same
             # frame with the wide index extension ((id << 9) | corner, two 64-lane triangle passes, at most 2^23 ids: 8 M meshlets), a short run
