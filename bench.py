@@ -42,12 +42,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))
 
 from oxylus_amd import lib as L  # noqa: E402
 from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, PreparedFrame, RendererInstance  # noqa: E402
 from oxylus_amd.synth import SceneSpec, make_depth, make_scene  # noqa: E402
+from bench_line import emit  # noqa: E402  (tools/bench_line.py: full record -> gpurun_out/bench_full.json, compact headline -> stdout)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUNDS = ("r06", "r05")  # committed rocprofv3 summaries under profiles/, newest first: the second clock and the PMC traffic of the line
 K_MESHLETS_PER_MESH = 1000
 
 
@@ -326,6 +329,12 @@ def pmc_traffic(profile_names, match) -> tuple:
         return None, None, None
     same = pm.get("kernel_source_sha16") == kernel_source_sha16() if pm.get("kernel_source_sha16") else None
     return round(sum(vals) / len(vals)), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch)", same
+
+
+def pmc_read_written(profile_names) -> dict:
+    """{kernel: (HBM bytes read, written) per launch} of the committed --pmc summary (FETCH_SIZE x 1024 x 2 / WRITE_SIZE x 1024)."""
+    _, pm = committed_profile([profile_names] if isinstance(profile_names, str) else profile_names)
+    return {k: (cs["hbm_read_bytes_corrected"], cs.get("hbm_write_bytes", 0)) for k, cs in (pm or {}).get("pmc", {}).items() if "hbm_read_bytes_corrected" in cs}
 
 
 def rocprof_kernel_us(profile_names) -> dict:
@@ -704,9 +713,10 @@ def bench_config3(args, e):
     # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
     # (the committed profiles are of the default workload: T = 64, ordered lists; any other shape has no counters of its own and says so)
     std_shape = not args.small_triangle_cull and main_unord == 1 and main_share
-    prof_names = (["r05_config3_pmc.json", "r04_config3_pmc.json"] if (std_shape and not wide and n_meshlets == 10_000_000) else
-                  ["r05_tris124_pmc.json"] if (std_shape and wide and n_meshlets == 8_000_000) else [])
+    prof_names = ([f"{t}_config3_pmc.json" for t in PROFILE_ROUNDS] if (std_shape and not wide and n_meshlets == 10_000_000) else
+                  [f"{t}_tris124_pmc.json" for t in PROFILE_ROUNDS] if (std_shape and wide and n_meshlets == 8_000_000) else [])
     rp = rocprof_kernel_us(prof_names) if prof_names else {}
+    pmc_rw = pmc_read_written(prof_names) if prof_names else {}
     rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
                 "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
                 "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
@@ -723,6 +733,9 @@ def bench_config3(args, e):
         ent = {"launches_per_frame": round(per_frame, 3), "launches_timed": k["launches"], "avg_us": round(k["avg_us"], 3)}
         if all(n in rp for n in rp_names.get(name, ["?"])):
             ent["kernel_avg_us_rocprof"] = round(sum(rp[n] for n in rp_names[name]), 3)
+        if all(n in pmc_rw for n in rp_names.get(name, ["?"])):  # HBM bytes per launch by the PMC counters of the committed profile (read x 2 correction applied, + written)
+            ent["traffic"] = round(sum(sum(pmc_rw[n]) for n in rp_names[name]))
+            ent["traffic_read_written"] = [round(sum(pmc_rw[n][0] for n in rp_names[name])), round(sum(pmc_rw[n][1] for n in rp_names[name]))]
         b = alg.get(name)
         if b is not None:
             ent["algorithmic_bytes_per_launch"] = round(b)
@@ -730,6 +743,13 @@ def bench_config3(args, e):
             ent["frac"] = round(b / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
             frame_alg += b * per_frame
         frame_kernel_us += k["avg_us"] * per_frame
+        if b is not None and name in ("cull_meshlets_test", "cull_meshlets_test_late"):
+            ent["traffic_over_algorithmic"] = round(ent["traffic"] / b, 3) if "traffic" in ent else None
+        if name == "hiz" and "traffic" in ent:
+            ent["traffic_over_algorithmic"] = round(ent["traffic"] / b, 3)
+            ent["achieved_traffic_GBps"] = round(ent["traffic"] / (k["avg_us"] * 1e-6) / 1e9, 1)
+            ent["note"] = ("parity mode: the reference's mip-0 point sample at (2x+2, 2y+2) (hiz.slang:92-95) touches every line of every other depth row and uses half of it: "
+                           "the read side fetches ~2.6x the sampled texels; frac is on SURVEY 8d's algorithmic bytes, achieved_traffic_GBps is what the memory system moved")
         kernels[name] = ent
     # dominant kernel: the triangle test (both instantiations: early + late launch of a frame)
     tt = [kern[n] for n in ("cull_triangles_test", "cull_triangles_test_late") if n in kern]
@@ -744,11 +764,23 @@ def bench_config3(args, e):
         roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + (f"; test + expansion in one launch: {tri_bytes_per_meshlet} B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
                     "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_over_algorithmic": round(traffic / dom_bytes, 3) if traffic else None,
                     "traffic_profile_is_of_this_device_code": traffic_same, "algorithmic_bytes_per_launch": round(dom_bytes), "kernel_avg_us": round(dom_us, 3),
                     "launches_averaged": sum(k["launches"] for k in tt), "measured_stream_read_GBps": round(stream_gbps, 1),
                     "frac_of_measured_stream_read": round(achieved / stream_gbps, 4)}
+        rpn = rp_names["cull_triangles_test"] + rp_names["cull_triangles_test_late"]
+        if all(n in rp for n in rpn):  # the committed rocprofv3 --kernel-trace --stats average of the same two instantiations
+            roofline["kernel_avg_us_rocprof"] = round(sum(rp[n] for n in rpn) / 2.0, 3)
+    # The same frame charged with the bytes THIS design needs (weak #4 of the round-5 review): with share_pass_tests the late meshlet test reads the early
+    # call's pass bit and the mask word for every meshlet (0.375 B) but the MeshletInstance record + bounds (24 B) only of meshlets that passed the camera
+    # tests (= its occlusion candidates, counted) -- the reference's flow charges 24.25 B for every meshlet.
+    needed_late = None
+    if main_share and occl_candidates["late"] is not None and "cull_meshlets_test_late" in kern:
+        needed_late = n_meshlets * 0.375 + (24.0 + 16.0) * occl_candidates["late"]
+    frame_needed = frame_alg - ((alg["cull_meshlets_test_late"] - needed_late) if needed_late is not None else 0.0)
     stage = {"algorithmic_bytes_per_frame": round(frame_alg), "ms_per_frame": round(ms_per_frame, 6),
              "achieved_GBps": round(frame_alg / (ms_per_frame * 1e-3) / 1e9, 1), "stage_frac": round(frame_alg / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "needed_bytes_per_frame": round(frame_needed), "stage_frac_needed_bytes": round(frame_needed / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
              "sum_of_kernel_us_per_frame": round(frame_kernel_us, 1),
              "occlusion_candidates": occl_candidates,
              "note": "whole frame (HiZ build + early + late, every kernel) against the 8 TB/s peak; bytes = SURVEY 8d per-kernel figures incl. 16 B of pyramid taps per occlusion candidate (counted).  "
@@ -1068,7 +1100,7 @@ def bench_config2(args, e, steps: int, warmup: int, with_cpu: bool):
         bytes_per_launch = n_meshlets * batch * (24.0 + 212.0 / K + 0.125)
         us = kern["cull_meshlets_test"]["avg_us"]
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
-        traffic, src, traffic_same = pmc_traffic(["r05_config2_pmc.json", "r04_config2_pmc.json"], lambda k: "k_cull_meshlets_test_batch" in k)
+        traffic, src, traffic_same = pmc_traffic([f"{t}_config2_pmc.json" for t in PROFILE_ROUNDS], lambda k: "k_cull_meshlets_test_batch" in k)
         roofline = {"bound": "hbm", "kernel": f"k_cull_meshlets_test_batch ({batch} frames per launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, "traffic_profile_is_of_this_device_code": traffic_same,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
@@ -1161,7 +1193,7 @@ def measure_config1(args, seconds: float) -> dict:
 
 
 def bench_config1(args):
-    print(json.dumps(measure_config1(args, args.cpu_seconds)))
+    emit(measure_config1(args, args.cpu_seconds))
 
 
 def line_summary(line: dict) -> dict:
@@ -1174,8 +1206,12 @@ def line_summary(line: dict) -> dict:
             d = d[k]
         return round(d, nd) if (nd is not None and isinstance(d, float)) else d
 
-    sm = {"ms_per_frame": g(line, "config", "ms_per_frame", nd=4), "stage_frac": g(line, "stage", "stage_frac"), "roofline_frac": g(line, "roofline", "frac"),
-          "bit_match": line.get("bit_match"), "hiz_bit_match": line.get("hiz_bit_match")}
+    sm = {"ms_per_frame": g(line, "config", "ms_per_frame", nd=4), "stage_frac": g(line, "stage", "stage_frac"), "stage_frac_needed_bytes": g(line, "stage", "stage_frac_needed_bytes"),
+          "roofline_frac": g(line, "roofline", "frac"), "bit_match": line.get("bit_match"), "hiz_bit_match": line.get("hiz_bit_match")}
+    kn = line.get("kernels") or {}
+    sm["kernel_us"] = {k: round(v["avg_us"], 1) for k, v in kn.items() if isinstance(v, dict) and "avg_us" in v}
+    if "hiz" in kn:
+        sm["hiz"] = {k: kn["hiz"].get(k) for k in ("frac", "traffic", "traffic_over_algorithmic", "achieved_traffic_GBps")}
     for v in g(line, "scheduling_ab", "variants") or []:
         key = ("defaults_ms_per_frame" if v.get("library_defaults") else
                "ordered_shared_ms" if (v["unordered_output"] == 0 and v["share_pass_tests"] and not v["async_triangles"] and not v["hiz_one_frame_ahead_on_second_stream"]) else
@@ -1232,7 +1268,7 @@ def main():
         res = bench_config2(args, e, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)
         if e.rank == 0:
             b = res["batched"]
-            print(json.dumps({
+            emit({
                 "metric": "meshlets/s culled", "value": b["value"], "unit": "meshlets/s", "n_gpus": e.world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(b["seconds"] * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic", "config": {"workload": res["workload"], "inner_reps": b["frames_timed"] // args.steps, **{k: res[k] for k in
@@ -1240,7 +1276,7 @@ def main():
                                                 "frames_per_launch": b["frames_per_launch"], "streams": b["streams"]},
                 "bit_match": res["bit_match"], "batched": b, "one_call_per_frame": res["one_call_per_frame"], "one_call_per_frame_unordered": res["one_call_per_frame_unordered"],
                 "kernels": res["kernels"], "roofline": res["roofline"],
-                "cpu_baseline": res["cpu_baseline"]}))
+                "cpu_baseline": res["cpu_baseline"]})
     else:
         def stage_note(what):  # progress on stderr: which part of the default line is running (a fault names no kernel)
             if e.rank == 0:
@@ -1298,8 +1334,8 @@ def main():
             stage_note("configs0")
             line["configs0"] = measure_config1(args, min(args.cpu_seconds, 2.0))  # BASELINE configs[0]: CPU only by definition, milliseconds per update
         if e.rank == 0:
-            line["summary"] = line_summary(line)  # LAST key: lands in the tail of stdout
-            print(json.dumps(line))
+            line["summary"] = line_summary(line)
+            emit(line)  # full record -> gpurun_out/bench_full.json; stdout: ONE compact line (<= 4 KB) the driver parses
     if e.dist is not None:
         e.dist.destroy_process_group()
     e.r.close()

@@ -10,6 +10,7 @@ import torch
 from oxylus_amd import lib as L
 from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame
 from oxylus_amd.synth import SceneSpec, make_scene
+from bench_line import emit  # tools/bench_line.py (bench.py puts tools/ on sys.path)
 
 HBM_PEAK_GBPS = 8000.0
 
@@ -109,7 +110,7 @@ def bench_bounds(args, r, dev, stream, rank, world, dist):
                         "sample": f"{reps} passes over the first {n} meshlets of the same arrays, oracle/oxcull_oracle.c orc_build_meshlet_bounds "
                                   f"(sequential), {dtc:.1f} s; GPU records of that range byte-identical: {ok}"}
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "meshlets/s bounded (asset-side producer)", "value": round(value, 1), "unit": "meshlets/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -118,7 +119,7 @@ def bench_bounds(args, r, dev, stream, rank, world, dist):
             "roofline": {"bound": "hbm", "kernel": "build_meshlet_bounds (quantize_positions + meshlet_bounds + mesh fold)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_meshlet": bytes_per_meshlet},
-            "cpu_baseline": cpu_baseline}))
+            "cpu_baseline": cpu_baseline})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -193,14 +194,14 @@ def bench_loop(args, r, dev, stream, rank, world, dist):
     prof = r.profile_end()
     per_frame_us = {k: round(v["total_ms"] / 10 * 1e3, 1) for k, v in prof["kernels"].items() if not k.startswith("_")}
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "meshlets/s through the closed two-pass frame (cull + draw + HiZ)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SURVEY 8f-2 loop: early cull -> draw -> depth -> HiZ -> late cull -> draw, static scene, steady state",
                        "meshlets_per_gpu": n_meshlets, "target": [W, H], "hiz": [W // 2, H // 2], "tris_per_meshlet": 64,
                        "steady_state_counts": counts, "covered_pixel_fraction": round(covered, 4), "per_frame_us": per_frame_us},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": None, "cpu_baseline": None})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -266,14 +267,14 @@ def bench_vsm(args, r, dev, stream, rank, world, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "meshlets/s culled against 10 clipmap views (VSM page pyramid)", "value": round(n_meshlets * world * steps / dt, 1), "unit": "meshlets/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SURVEY 8a-14 + 8f-3: generate_hpb + cull_meshes + cull_meshlets_hpb, 10 dirty clipmaps of 64x64 pages, 15 % pages wanted",
                        "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "after_cull_meshes": c.total_visible_meshlet_instances,
                        "visible": c.cull_triangles_cmd_x},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": None, "cpu_baseline": None})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -567,7 +568,7 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
         torch.cuda.empty_cache()
         return res
     if rank == 0:
-        print(json.dumps(res))
+        emit(res)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -9,7 +9,9 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke"
 timeout 600 python bench.py --steps 20 --warmup 5 2> gpurun_out/bench_default.err | tail -1 > gpurun_out/bench_default.json; echo "bench rc=$?"
 python - <<'PY'
 import json
-d = json.load(open("gpurun_out/bench_default.json"))
+h = json.load(open("gpurun_out/bench_default.json"))  # the compact headline (stdout); the full record is in gpurun_out/bench_full.json
+d = json.load(open("gpurun_out/bench_full.json"))
+print("headline:", len(json.dumps(h)), "bytes, roofline", h["roofline"]["frac"], "cpu cores", h["cpu_baseline"]["cores"])
 print("default:", d["value"], "meshlets/s", d["config"]["ms_per_frame"], "ms/frame bit_match", d["bit_match"], d["hiz_bit_match"], "stage_frac", d["stage"]["stage_frac"],
       "roofline", d["roofline"]["frac"], "configs1", d["configs1"]["batched"]["value"], d["configs1"]["one_call_per_frame"]["value"])
 PY

@@ -7,6 +7,7 @@ OUT=${1:-gpurun_out/pmc}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
+export OXC_BENCH_FULL=/tmp/pmc_bench_full.json
 CMD="python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab --no-configs0 ${BENCH_ARGS:---steps 1 --warmup 1 --inner-reps 8}"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
   --kernel-trace --output-format csv -d "$ROOT/$OUT/sq1" -o p -- $CMD > /dev/null 2> "$ROOT/$OUT/sq1.log"

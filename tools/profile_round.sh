@@ -5,7 +5,7 @@
 # counter_collection CSVs, cut down to this library's kernels -- are kept gzipped under gpurun_out/profiles_out/raw/ (round 3 kept
 # only the summaries: they could not be re-derived).  Copy both into profiles/ afterwards.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 rm -rf gpurun_out/raw; mkdir -p gpurun_out/raw gpurun_out/profiles_out/raw
@@ -43,7 +43,7 @@ keep_raw config5 gpurun_out/raw/trace_c5 gpurun_out/raw/pmc_c5
 ./tools/profile_trace.sh gpurun_out/raw/trace_t124 --tris 124 --steps 3 --warmup 1 > /dev/null
 # (round 5: the WIDE kernels get their HBM counters too -- FETCH_SIZE / WRITE_SIZE passes only)
 mkdir -p gpurun_out/raw/pmc_t124
-( cd /tmp && export TMPDIR=/tmp && for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed s/_size//); rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/gpurun_out/raw/pmc_t124/$d" -o p -- python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab --no-configs0 --tris 124 --steps 1 --warmup 1 --inner-reps 8 > /dev/null 2> "$ROOT/gpurun_out/raw/pmc_t124/$d.log"; done )
+( cd /tmp && export TMPDIR=/tmp OXC_BENCH_FULL=/tmp/pmc_bench_full.json && for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed s/_size//); rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/gpurun_out/raw/pmc_t124/$d" -o p -- python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab --no-configs0 --tris 124 --steps 1 --warmup 1 --inner-reps 8 > /dev/null 2> "$ROOT/gpurun_out/raw/pmc_t124/$d.log"; done )
 python tools/summarize_profiles.py ${TAG}_tris124_pmc --stats $(find gpurun_out/raw/trace_t124 -name t_kernel_stats.csv | head -1) --pmc gpurun_out/raw/pmc_t124 \
   --note "bench.py --tris 124 (8M meshlets x 124 triangles, wide_triangle_index), --steps 3 --warmup 1 (kernel trace) / --steps 1 --warmup 1 --inner-reps 8 (FETCH_SIZE and WRITE_SIZE passes); rocprofv3 --kernel-trace --stats + separate --pmc passes"
 cp gpurun_out/raw/trace_t124/bench.json gpurun_out/profiles_out/${TAG}_tris124_trace_bench.json
