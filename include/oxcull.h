@@ -144,7 +144,15 @@ typedef struct oxc_cull_geometry_context {
   uint32_t vsm_clipmap_count;                /* <= 16 */
   /* Extension (no reference behaviour): 0 = the reference's packed index (id << 8) | (3t+k),
    * 64 triangles per meshlet; 1 = wide index (id << 9) | (3t+k) for meshlets of up to 128 triangles
-   * (at most 2^23 meshlet instances per call, reordered_indices_buffer >= N*128*3*4 bytes). */
+   * (at most 2^23 meshlet instances per call, reordered_indices_buffer >= N*128*3*4 bytes);
+   * 2 = SURVEY A.7's form for larger shards: every index is the PAIR {u32 meshlet_instance_index, u32 3t+k}
+   * (8 bytes, little endian, id first), meshlets of up to 128 triangles, no id limit below 2^32,
+   * reordered_indices_buffer >= N*128*3*8 bytes, same order of entries as the packed forms.  The decode of
+   * visbuffer.slang:9-14 becomes instance = pair.x, corner = pair.y (oxc_draw_visbuffer does that).
+   * DrawIndexedIndirect.index_count stays the number of INDICES (3 per triangle) and stays a u32: a call that
+   * emits more than 2^32 - 1 of them (possible only when N*384 >= 2^32, i.e. N > 11 184 810, and then only if
+   * nearly every triangle passes) sets instanceCount = 0 -- the command draws nothing -- and oxc_read_counters
+   * of that call returns OXC_INVALID_ARG; every write stays inside the buffer. */
   uint32_t wide_triangle_index;
   /* Extension named by the north star ("per-triangle backface + small-triangle cull"); the reference has only the
    * clip-z and backface tests (cull_triangles.slang:68-69, cull.slang:169-171).  0 (default) = reference behaviour,

@@ -268,11 +268,15 @@ def triangle_small(clip3x4, resolution) -> bool:
 
 
 def cull_triangles(scene, cam, meshlet_instances: torch.Tensor, visible: torch.Tensor, first: int, count: int, nthreads: int = 1,
-                   stats: MarginStats = None, wide: bool = False, small_triangle_cull: bool = False) -> torch.Tensor:
-    out = torch.zeros(max(count, 1) * (384 if wide else 192), dtype=torch.int32)
-    if small_triangle_cull:
+                   stats: MarginStats = None, wide=False, small_triangle_cull: bool = False) -> torch.Tensor:
+    """wide: include/oxcull.h wide_triangle_index -- False / 0, True / 1, or 2 = {id, corner} pairs (the result then holds two words per index)."""
+    wide = int(wide)
+    out = torch.zeros(max(count, 1) * (768 if wide == 2 else 384 if wide else 192), dtype=torch.int32)
+    if small_triangle_cull or wide == 2:
         n = lib().orc_cull_triangles_flags(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
-                                           _p(cam), _p(out), int(wide), 1)
+                                           _p(cam), _p(out), wide, int(small_triangle_cull))
+        if wide == 2:
+            n *= 2
     elif wide:
         n = lib().orc_cull_triangles_wide(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(visible), first, count,
                                           _p(cam), _p(out))
@@ -402,12 +406,13 @@ def cull_terrain(world_min, world_size, patch_count, base_height: float, height_
 
 
 def draw_visbuffer(scene, meshlet_instances: torch.Tensor, indices: torch.Tensor, projection_view, width: int, height: int, visdepth: torch.Tensor,
-                   wide: bool = False):
-    """Rasterises `indices` (cull_triangles output) into visdepth (int64 [h, w], accumulated)."""
+                   wide=False):
+    """Rasterises `indices` (cull_triangles output) into visdepth (int64 [h, w], accumulated).  wide = 2: `indices` holds {id, corner} pairs."""
     pv = f32a(projection_view)
     idx = indices.contiguous()
-    lib().orc_draw_visbuffer(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(idx), idx.numel(), _p(pv),
-                             width, height, 9 if wide else 8, _p(visdepth))
+    wide = int(wide)
+    lib().orc_draw_visbuffer(_p(scene.meshes), _p(scene.transforms), _p(scene.mesh_instances), _p(meshlet_instances), _p(idx), idx.numel() // (2 if wide == 2 else 1), _p(pv),
+                             width, height, 0 if wide == 2 else 9 if wide else 8, _p(visdepth))
 
 
 def draw_clipped_count() -> int:

@@ -692,7 +692,10 @@ static uint32_t cull_triangles_impl(const orc_mesh* meshes, const float* transfo
                                     const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                     uint32_t count, const orc_cull_camera* cam, uint32_t* out, orc_margin_stats* stats,
                                     uint32_t max_tris, uint32_t corner_bits, int small_triangle_cull) {
-  const uint32_t corner_mask = (1u << corner_bits) - 1u;
+  /* corner_bits == 0: SURVEY A.7's pair form (include/oxcull.h wide_triangle_index = 2) -- every index is {u32 meshlet_instance_index, u32 3t+k},
+   * two words of `out`; the return value stays the number of indices */
+  const int pair = corner_bits == 0u;
+  const uint32_t corner_mask = pair ? 0xFFFFFFFFu : (1u << corner_bits) - 1u;
   uint32_t n = 0;
   for (uint32_t s = 0; s < count; s++) {
     uint32_t mli_index = visible[first + s];
@@ -722,7 +725,13 @@ static uint32_t cull_triangles_impl(const orc_mesh* meshes, const float* transfo
       passed = passed && !backface_m(cp, stats ? &nr : NULL);
       if (passed && small_triangle_cull) passed = !orc_test_triangle_small(cp, cam->resolution);
       if (stats && nr) stats->triangles_near_threshold++;
-      if (passed) {
+      if (passed && pair) {
+        for (uint32_t k = 0; k < 3u; k++) {
+          out[2u * (size_t)(n + k)] = mli_index;
+          out[2u * (size_t)(n + k) + 1u] = t * 3u + k;
+        }
+        n += 3;
+      } else if (passed) {
         uint32_t base = mli_index << corner_bits; /* MESHLET_PRIMITIVE_BITS = 8 in the reference */
         out[n + 0] = base | ((t * 3u + 0u) & corner_mask);
         out[n + 1] = base | ((t * 3u + 1u) & corner_mask);
@@ -761,8 +770,9 @@ int orc_test_triangle_small(const float* cp, const float* resolution) {
 uint32_t orc_cull_triangles_flags(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                   const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                   uint32_t count, const orc_cull_camera* cam, uint32_t* out, int wide, int small_triangle_cull) {
+  /* wide: include/oxcull.h wide_triangle_index -- 0 packed 24 + 8, 1 packed 23 + 9, 2 {id, corner} pairs (`out` holds two words per index) */
   return cull_triangles_impl(meshes, transforms, mesh_instances, meshlet_instances, visible, first, count, cam, out, NULL, wide ? 128u : 64u,
-                             wide ? 9u : 8u, small_triangle_cull);
+                             wide == 2 ? 0u : wide ? 9u : 8u, small_triangle_cull);
 }
 
 /* Which triangles of the visible slots sit in the BOUNDARY SET of cull_triangles' two tests: the ones whose decision a
@@ -1275,15 +1285,17 @@ uint32_t orc_draw_clipped_count(void) { return g_draw_clipped; }
 void orc_draw_visbuffer(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                         const orc_meshlet_instance* meshlet_instances, const uint32_t* indices, uint32_t index_count, const float* pv, uint32_t W,
                         uint32_t H, uint32_t corner_bits, uint64_t* visdepth) {
-  const uint32_t corner_mask = (1u << corner_bits) - 1u;
+  const int pair = corner_bits == 0u; /* {id, corner} pairs: `indices` holds two words per index, index_count counts indices */
+  const uint32_t corner_mask = pair ? 0xFFFFFFFFu : (1u << corner_bits) - 1u;
   g_draw_clipped = 0;
   for (uint32_t i = 0; i + 2 < index_count; i += 3) {
     float poly[2][9][4];
     uint32_t vis_out = 0;
     for (int k = 0; k < 3; k++) {
       /* vs_main, visbuffer_encode.slang:24-49 */
-      uint32_t data = indices[i + k];
-      uint32_t mli_index = (data >> corner_bits) & (0xFFFFFFFFu >> corner_bits), corner = data & corner_mask;
+      uint32_t data = pair ? 0u : indices[i + k];
+      uint32_t mli_index = pair ? indices[2u * (size_t)(i + k)] : (data >> corner_bits) & (0xFFFFFFFFu >> corner_bits);
+      uint32_t corner = pair ? indices[2u * (size_t)(i + k) + 1u] : data & corner_mask;
       const orc_meshlet_instance* mli = &meshlet_instances[mli_index];
       const orc_mesh_instance* inst = &mesh_instances[mli->mesh_instance_index];
       const orc_mesh* mesh = &meshes[inst->mesh_index];

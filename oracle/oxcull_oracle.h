@@ -214,6 +214,8 @@ uint32_t orc_cull_triangles_wide(const orc_mesh* meshes, const float* transforms
 /* The opt-in small-triangle cull (include/oxcull.h: oxc_cull_geometry_context::small_triangle_cull; no reference
  * behaviour, the north star names it).  orc_test_triangle_small: 1 = dropped. */
 int orc_test_triangle_small(const float* clip3x4, const float* resolution2);
+/* wide: include/oxcull.h wide_triangle_index -- 0 = 24 + 8 bit packed index, 1 = 23 + 9 bits, 2 = SURVEY A.7's pairs
+ * {u32 meshlet_instance_index, u32 t*3+k}: reordered_out then holds two words per index, the return value stays the index count. */
 uint32_t orc_cull_triangles_flags(const orc_mesh* meshes, const float* transforms, const orc_mesh_instance* mesh_instances,
                                   const orc_meshlet_instance* meshlet_instances, const uint32_t* visible, uint32_t first,
                                   uint32_t count, const orc_cull_camera* cam, uint32_t* reordered_out, int wide,

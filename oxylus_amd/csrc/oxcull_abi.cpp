@@ -374,11 +374,13 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
   if (do_meshlets && N && (!f->visible_meshlet_instances_indices_buffer.dptr || f->visible_meshlet_instances_indices_buffer.bytes < (uint64_t)N * 4))
     return fail(ctx, OXC_INVALID_ARG, "cull_geometry: visible_meshlet_instances_indices_buffer missing or < 4*N bytes");
   if (do_tris && N) {
-    const uint64_t tris_per_meshlet = c->wide_triangle_index ? 128u : 64u;
-    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * tris_per_meshlet * 3 * 4)
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes (N*128*3*4 with wide_triangle_index)");
-    if (N > (c->wide_triangle_index ? kMaxPackedInstances / 2 : kMaxPackedInstances))
-      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: too many meshlet instances for the packed index (2^24, visbuffer.slang:9-14; 2^23 with wide_triangle_index)");
+    if (c->wide_triangle_index > 2u) return fail(ctx, OXC_INVALID_ARG, "cull_geometry: wide_triangle_index must be 0, 1 or 2");
+    const uint64_t tris_per_meshlet = c->wide_triangle_index ? 128u : 64u, index_bytes = c->wide_triangle_index == 2u ? 8u : 4u;
+    if (!f->reordered_indices_buffer.dptr || f->reordered_indices_buffer.bytes < (uint64_t)N * tris_per_meshlet * 3 * index_bytes)
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: reordered_indices_buffer missing or < N*64*3*4 bytes (N*128*3*4 with wide_triangle_index = 1, N*128*3*8 with 2)");
+    // (wide_triangle_index = 2, {id, corner} pairs: no id limit below 2^32 -- N is a u32)
+    if (c->wide_triangle_index != 2u && N > (c->wide_triangle_index ? kMaxPackedInstances / 2 : kMaxPackedInstances))
+      return fail(ctx, OXC_INVALID_ARG, "cull_geometry: too many meshlet instances for the packed index (2^24, visbuffer.slang:9-14; 2^23 with wide_triangle_index = 1; pairs, wide_triangle_index = 2, have no limit)");
   }
   const bool occl = (c->cull_flags & OXC_CULL_TEST_OCCLUSION) != 0;
   const bool late = (c->cull_flags & OXC_CULL_LATE_PASS) != 0;
@@ -856,7 +858,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
       // (the default cap is "one resident round": of the instantiation that runs, which the launcher knows; a cap set by hand stands)
       const bool default_cap = !(async && ctx->async_tri_per_cu) && ctx->tri_blocks_per_cu == kTriangleBlocksPerCU;
-      launch_tris_fused(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap),
+      launch_tris_fused(tt, late, c->wide_triangle_index, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap),
                         default_cap ? ctx->num_cus : 0u, ts);
     } else {
     {
@@ -877,7 +879,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     te.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     {
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_EMIT_LATE : OXC_K_TRIANGLES_EMIT, ts);
-      launch_tris_emit(te, late, c->wide_triangle_index != 0, std::min(cdiv(std::max(N, 1u), kTriSpan), tri_grid_cap), ts);
+      launch_tris_emit(te, late, c->wide_triangle_index, std::min(cdiv(std::max(N, 1u), kTriSpan), tri_grid_cap), ts);
     }
     }
     if (async) {
@@ -1215,6 +1217,10 @@ oxc_status oxc_read_counters(oxc_ctx* ctx, const oxc_cull_geometry_context* c, o
   out->cull_meshlets_cmd_x = mc[0];
   out->cull_triangles_cmd_x = tc[0];
   out->draw_index_count = dc[0];
+  // wide_triangle_index = 2 only: a call that emitted more indices than VkDrawIndexedIndirectCommand.indexCount can count zeroed instanceCount
+  // (the command draws nothing); every other path leaves the 1 this library initialises it with
+  if (c->draw_geometry_cmd_buffer.dptr && c->wide_triangle_index == 2u && (!c->stages || (c->stages & OXC_STAGE_TRIANGLES)) && dc[1] == 0u)
+    return fail(ctx, OXC_INVALID_ARG, "read_counters: the call emitted more than 2^32 - 1 indices (pairs): draw_index_count wrapped, instanceCount was set to 0; cull fewer meshlets per call");
   return OXC_OK;
 }
 
@@ -1493,6 +1499,7 @@ oxc_status oxc_draw_visbuffer(oxc_ctx* ctx, const oxc_prepared_frame* f, const o
   if (!ctx) return OXC_INVALID_ARG;
   if (!f || !d || d->struct_size != sizeof(oxc_draw_context)) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: bad frame / context / struct_size");
   if (d->width == 0 || d->height == 0 || d->width > 16384 || d->height > 16384) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: extent must be 1..16384");
+  if (d->wide_triangle_index > 2u) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: wide_triangle_index must be 0, 1 or 2");
   const uint64_t n = (uint64_t)d->width * d->height;
   if (!d->visdepth_buffer.dptr || d->visdepth_buffer.bytes < n * 8u) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: visdepth_buffer smaller than width*height u64");
   if (!d->draw_geometry_cmd_buffer.dptr) return fail(ctx, OXC_INVALID_ARG, "draw_visbuffer: draw_geometry_cmd_buffer is null (run oxc_cull_geometry with the triangle stage first)");

@@ -1382,14 +1382,17 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 #ifndef OXC_EMIT_RUN
 #define OXC_EMIT_RUN 1024
 #endif
-#ifndef OXC_EMIT_WIDE_NT
-#define OXC_EMIT_WIDE_NT 1
-#endif
 constexpr uint32_t kEmitRun = OXC_EMIT_RUN;  // dwords a wave stages between flushes (>= 384 + 3: one WIDE slot)
-template <int H, uint32_t kCornerBits>
-OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int first_slot, int nslots, uint32_t g0, uint32_t* __restrict__ out, uint32_t* run, int lane) {
+// PAIR (wide_triangle_index = 2, SURVEY A.7's form for shards beyond 2^23 ids): an index is the pair {u32 meshlet_instance_index, u32 corner} -- 8 bytes,
+// six dwords per triangle, no id limit below 2^32.  g0 and the run count in DWORDS either way (the callers double the index offset); the offset is 64-bit
+// in this form: 2^32 - 1 indices are 8.6e9 dwords.
+template <int H, uint32_t kCornerBits, bool PAIR = false>
+OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int first_slot, int nslots, typename std::conditional<PAIR, uint64_t, uint32_t>::type g0,
+                               uint32_t* __restrict__ out, uint32_t* run, int lane) {
   typedef uint32_t u4v __attribute__((ext_vector_type(4)));
   constexpr uint32_t kCornerMask = (1u << kCornerBits) - 1u;
+  constexpr uint32_t kDw = PAIR ? 6u : 3u;  // dwords per emitted triangle
+  static_assert(kEmitRun >= 128u * kDw + 3u || (!PAIR && H == 1), "a run holds at least one slot");
   uint32_t pad = (uint32_t)((reinterpret_cast<uint64_t>(out + g0) >> 2) & 3u);  // the run's first dword inside its 16-byte granule
   uint32_t filled = 0;
   auto flush = [&]() {
@@ -1401,10 +1404,7 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
     uint32_t* dst = out + g0 + head;
     for (uint32_t c = (uint32_t)lane; c < nch; c += 64u) {
       const u4v v = *reinterpret_cast<const u4v*>(src + 4u * c);
-      if (OXC_EMIT_WIDE_NT)
-        __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(dst + 4u * c));
-      else
-        *reinterpret_cast<u4v*>(dst + 4u * c) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(dst + 4u * c));
     }
     const uint32_t done = head + 4u * nch, tail = filled - done;
     if ((uint32_t)lane < tail) out[g0 + done + (uint32_t)lane] = run[pad + done + (uint32_t)lane];
@@ -1422,7 +1422,7 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
       m[h] = masks[s * H + h];
       cnt += (uint32_t)__popcll((unsigned long long)m[h]);
     }
-    const uint32_t n3 = cnt * 3u;
+    const uint32_t n3 = cnt * kDw;
     if (n3 == 0u) continue;                      // (wave-uniform)
     if (filled + n3 > kEmitRun) flush();         // (wave-uniform; same wave, in-order LDS: the flush has read the run before it is rewritten)
     uint32_t* at = run + pad + filled;
@@ -1431,11 +1431,20 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
     for (int h = 0; h < H; h++) {
       if ((m[h] >> lane) & 1ull) {
         const uint32_t rank = before + (uint32_t)__popcll((unsigned long long)(m[h] & ((1ull << lane) - 1ull)));
-        const uint32_t packed = ids[s] << kCornerBits;
         const uint32_t t3 = ((uint32_t)lane + 64u * (uint32_t)h) * 3u;
-        at[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
-        at[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
-        at[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
+        if (PAIR) {
+          const uint32_t id = ids[s];
+#pragma unroll
+          for (uint32_t c = 0; c < 3u; c++) {
+            at[rank * 6u + 2u * c] = id;
+            at[rank * 6u + 2u * c + 1u] = t3 + c;
+          }
+        } else {
+          const uint32_t packed = ids[s] << kCornerBits;
+          at[rank * 3u + 0] = packed | ((t3 + 0u) & kCornerMask);
+          at[rank * 3u + 1] = packed | ((t3 + 1u) & kCornerMask);
+          at[rank * 3u + 2] = packed | ((t3 + 2u) & kCornerMask);
+        }
       }
       before += (uint32_t)__popcll((unsigned long long)m[h]);
     }
@@ -1567,8 +1576,9 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 #define OXC_FUSED_DYNAMIC 1  // 0: every span by block index (round 4)
 #endif
 constexpr uint32_t kTriTicketCounters = 16;  // (4 / 16 / 64 counters: the same frame time)
-template <bool LATE, bool WIDE, bool SMALL>
+template <bool LATE, bool WIDE, bool SMALL, bool PAIR = false>
 OXC_DEV void tris_fused_body(const TriTestArgs& a) {
+  static_assert(!PAIR || WIDE, "the pair form is the form of the 128-triangle meshlets");
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
   constexpr int S = 16;  // slots per wave per chunk
@@ -1663,6 +1673,9 @@ OXC_DEV void tris_fused_body(const TriTestArgs& a) {
       const uint32_t total3 = (woff + incl) * 3u;
       uint32_t base = 0u, tk = 0u;
       if (total3) base = __hip_atomic_fetch_add(gptr(a.draw_cmd), total3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // DrawIndexedIndirect.index_count
+      // (pairs have no id limit, so a call CAN be asked for more than the 2^32 - 1 indices a VkDrawIndexedIndirectCommand counts: the run that wraps the
+      //  counter zeroes instanceCount -- the draw becomes a no-op and oxc_read_counters reports it; include/oxcull.h, wide_triangle_index = 2)
+      if (PAIR && base + total3 < base) gptr(a.draw_cmd)[1] = 0u;
       if (draw) tk = __hip_atomic_fetch_add(gptr(a.ticket) + kx * kSuperStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (both round trips overlap)
       f_next = tk;
       f_base = base;
@@ -1671,7 +1684,10 @@ OXC_DEV void tris_fused_body(const TriTestArgs& a) {
     {  // every wave expands a quarter of the ITEM's slots (a drawn chunk is 64 slots: 16 per wave instead of 32 for two waves and none for
        // the other two: early launch 99.7 -> 96.5 us, frame -3.5 us)
       const int per_wave = (int)(item_n * kTriChunk / 4u);
-      expand_slots_wide<H, kCornerBits>(f_mask, f_id, wave * per_wave, per_wave, f_base + f_off[wave * per_wave] * 3u, a.out, f_run + wave * (kEmitRun + 8u), lane);
+      if (PAIR)
+        expand_slots_wide<H, kCornerBits, true>(f_mask, f_id, wave * per_wave, per_wave, ((uint64_t)f_base + (uint64_t)f_off[wave * per_wave] * 3u) * 2u, a.out, f_run + wave * (kEmitRun + 8u), lane);
+      else
+        expand_slots_wide<H, kCornerBits, false>(f_mask, f_id, wave * per_wave, per_wave, f_base + f_off[wave * per_wave] * 3u, a.out, f_run + wave * (kEmitRun + 8u), lane);
     }
     const uint32_t tk = f_next;
     __syncthreads();  // the item's LDS rows (and f_next) are rewritten by the block's next item
@@ -1688,8 +1704,9 @@ OXC_DEV void tris_fused_body(const TriTestArgs& a) {
 // Triangle stage, emit kernel: ordered expansion of the pass masks into packed indices
 // (visbuffer.slang:13-14, cull_triangles.slang:82-88) and DrawIndexedIndirect.index_count.
 // ------------------------------------------------------------------------------------------
-template <bool LATE, bool WIDE>
+template <bool LATE, bool WIDE, bool PAIR = false>
 OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
+  static_assert(!PAIR || WIDE, "the pair form is the form of the 128-triangle meshlets");
   constexpr int H = WIDE ? 2 : 1;
   constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;  // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
   __shared__ uint32_t s_red[4];
@@ -1727,10 +1744,14 @@ OXC_DEV void tris_emit_body(const TriEmitArgs& a) {
     s_id[threadIdx.x] = id;
     if (threadIdx.x == 255 && span == nspans - 1) {
       a.draw_cmd[0] = (base + woff + incl) * 3u;  // DrawIndexedIndirect.index_count
+      if (PAIR && (uint64_t)(base + woff + incl) * 3u > 0xFFFFFFFFull) a.draw_cmd[1] = 0u;  // (more indices than the command can count: see tris_fused_body)
     }
     __syncthreads();
     // each wave expands its 64 slots: one contiguous run of the index list (expand_slots_wide above)
-    expand_slots_wide<H, kCornerBits>(s_mask, s_id, wave * 64, 64, (base + s_off[wave * 64]) * 3u, a.out, s_run + wave * (kEmitRun + 8u), lane);
+    if (PAIR)
+      expand_slots_wide<H, kCornerBits, true>(s_mask, s_id, wave * 64, 64, (uint64_t)(base + s_off[wave * 64]) * 6u, a.out, s_run + wave * (kEmitRun + 8u), lane);
+    else
+      expand_slots_wide<H, kCornerBits, false>(s_mask, s_id, wave * 64, 64, (base + s_off[wave * 64]) * 3u, a.out, s_run + wave * (kEmitRun + 8u), lane);
     __syncthreads();
   }
 }
@@ -2003,6 +2024,15 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
 template <bool LATE, bool WIDE, bool SMALL>
 __global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused(TriTestArgs a) {
   tris_fused_body<LATE, WIDE, SMALL>(a);
+}
+// wide_triangle_index = 2: the WIDE instantiations writing {id, corner} pairs (kernels of their own name: the profiles key on the names above)
+template <bool LATE, bool SMALL>
+__global__ __launch_bounds__(256, OXC_TRI_WIDE_WAVES) void k_cull_triangles_fused_pairs(TriTestArgs a) {
+  tris_fused_body<LATE, true, SMALL, true>(a);
+}
+template <bool LATE>
+__global__ __launch_bounds__(256) void k_cull_triangles_emit_pairs(TriEmitArgs a) {
+  tris_emit_body<LATE, true, true>(a);
 }
 
 // Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
@@ -2505,15 +2535,27 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_tri
 // resident_cus != 0: the grid is also capped at the blocks of THIS instantiation that are resident at once on that many CUs (occupancy
 // query).  The fused kernel hands out its work by rounds of the grid (tris_fused_body): a grid of two resident rounds -- the WIDE
 // instantiations run 4 waves per SIMD, the generic cap was 8 blocks per CU -- cost the 8 M x 124-triangle frame 33 us (0.562 -> 0.529 ms).
-void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, uint32_t resident_cus, hipStream_t s) {
+void launch_tris_fused(const TriTestArgs& a, bool late, uint32_t wide, bool small_triangle_cull, uint32_t grid, uint32_t resident_cus, hipStream_t s) {
   dim3 b(256);
   const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
-#define OXC_FUSED_CASE(i, L_, W_, S_)                                                                              \
-  case i: {                                                                                                        \
-    static const uint32_t per_cu = resident_grid(k_cull_triangles_fused<L_, W_, S_>, 256, 1);                      \
+#define OXC_FUSED_LAUNCH(K_)                                                                                       \
+  {                                                                                                                \
+    static const uint32_t per_cu = resident_grid(K_, 256, 1);                                                      \
     const uint32_t g = resident_cus ? std::min(grid, per_cu * resident_cus) : grid;                                \
-    hipLaunchKernelGGL((k_cull_triangles_fused<L_, W_, S_>), dim3(std::max(g, 1u)), b, 0, s, a);                   \
-    break;                                                                                                         \
+    hipLaunchKernelGGL(K_, dim3(std::max(g, 1u)), b, 0, s, a);                                                     \
+  }
+#define OXC_FUSED_CASE(i, L_, W_, S_)                                                                              \
+  case i:                                                                                                          \
+    OXC_FUSED_LAUNCH((k_cull_triangles_fused<L_, W_, S_>))                                                         \
+    break;
+  if (wide == 2u) {  // {id, corner} pairs
+    switch (v & 5) {
+      case 0: OXC_FUSED_LAUNCH((k_cull_triangles_fused_pairs<false, false>)) break;
+      case 1: OXC_FUSED_LAUNCH((k_cull_triangles_fused_pairs<false, true>)) break;
+      case 4: OXC_FUSED_LAUNCH((k_cull_triangles_fused_pairs<true, false>)) break;
+      default: OXC_FUSED_LAUNCH((k_cull_triangles_fused_pairs<true, true>)) break;
+    }
+    return;
   }
   switch (v) {
     OXC_FUSED_CASE(0, false, false, false)
@@ -2527,10 +2569,15 @@ void launch_tris_fused(const TriTestArgs& a, bool late, bool wide, bool small_tr
       OXC_FUSED_CASE(7, true, true, true)
   }
 #undef OXC_FUSED_CASE
+#undef OXC_FUSED_LAUNCH
 }
-void launch_tris_emit(const TriEmitArgs& a, bool late, bool wide, uint32_t grid, hipStream_t s) {
+void launch_tris_emit(const TriEmitArgs& a, bool late, uint32_t wide, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
-  if (late && wide)
+  if (wide == 2u && late)
+    hipLaunchKernelGGL((k_cull_triangles_emit_pairs<true>), g, b, 0, s, a);
+  else if (wide == 2u)
+    hipLaunchKernelGGL((k_cull_triangles_emit_pairs<false>), g, b, 0, s, a);
+  else if (late && wide)
     hipLaunchKernelGGL((k_cull_triangles_emit<true, true>), g, b, 0, s, a);
   else if (late)
     hipLaunchKernelGGL((k_cull_triangles_emit<true, false>), g, b, 0, s, a);

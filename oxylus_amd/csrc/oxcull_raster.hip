@@ -182,9 +182,41 @@ __global__ __launch_bounds__(256) void k_draw_rows(DrawArgs a) {
 // vs_main (visbuffer_encode.slang:24-49) for the three corners of a triangle given its three index-buffer entries: clip coordinates +
 // the encoded vis value.
 // first_mli: the MeshletInstance record of idx[0]'s instance when the caller has fetched it already (k_draw_setup, a step ahead).
-OXC_DEV void tri_clip_coords(const DrawArgs& a, const uint32_t (&idx)[3], float (&clip)[3][4], uint32_t& vis_out, const uint2* first_mli = nullptr) {
-  const uint32_t corner_bits = a.wide ? 9u : 8u;
-  const uint32_t corner_mask = (1u << corner_bits) - 1u;
+// An index-buffer entry: the packed u32 of visbuffer.slang:9-14 ((id << 8) | corner; << 9 with wide_triangle_index = 1) or, PAIR
+// (wide_triangle_index = 2), the 8-byte pair {u32 meshlet_instance_index, u32 corner}.
+template <bool PAIR>
+struct IdxEntry {
+  uint32_t d;
+};
+template <>
+struct IdxEntry<true> {
+  uint32_t id, corner;
+};
+template <bool PAIR>
+OXC_DEV IdxEntry<PAIR> load_entry(const DrawArgs& a, uint32_t i) {
+  if constexpr (PAIR) {
+    const uint2 v = reinterpret_cast<const uint2*>(a.indices)[i];
+    return IdxEntry<true>{v.x, v.y};
+  } else {
+    return IdxEntry<false>{a.indices[i]};
+  }
+}
+template <bool PAIR>
+OXC_DEV uint32_t entry_instance(const DrawArgs& a, const IdxEntry<PAIR>& e) {
+  if constexpr (PAIR)
+    return e.id;
+  else
+    return e.d >> (a.wide ? 9u : 8u);
+}
+template <bool PAIR>
+OXC_DEV uint32_t entry_corner(const DrawArgs& a, const IdxEntry<PAIR>& e) {
+  if constexpr (PAIR)
+    return e.corner;
+  else
+    return e.d & ((1u << (a.wide ? 9u : 8u)) - 1u);
+}
+template <bool PAIR>
+OXC_DEV void tri_clip_coords(const DrawArgs& a, const IdxEntry<PAIR> (&idx)[3], float (&clip)[3][4], uint32_t& vis_out, const uint2* first_mli = nullptr) {
   // The three indices of a triangle written by cull_triangles name the same meshlet instance, so everything up to
   // the Meshlet record and the world matrix is fetched once and reused while the instance id repeats (vs_main
   // decodes every index on its own; an index list that mixes instances inside a triangle still works, slower).
@@ -194,8 +226,7 @@ OXC_DEV void tri_clip_coords(const DrawArgs& a, const uint32_t (&idx)[3], float 
   float w[12] = {0};  // rows 0..2 of world
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const uint32_t data = idx[k];
-    const uint32_t mli_index = data >> corner_bits, corner = data & corner_mask;
+    const uint32_t mli_index = entry_instance<PAIR>(a, idx[k]), corner = entry_corner<PAIR>(a, idx[k]);
     if (mli_index != cur_mli) {
       cur_mli = mli_index;
       const uint2 mli = (k == 0 && first_mli) ? *first_mli : reinterpret_cast<const uint2*>(a.meshlet_instances)[mli_index];
@@ -326,6 +357,7 @@ OXC_DEV void tri_emit(const DrawArgs& a, const TriSetup& t, uint32_t seg) {
   walk_box(a, r, r.px0, r.py0, r.px1, r.py1);
 }
 
+template <bool PAIR>
 __global__ __launch_bounds__(256, 5) void k_draw_setup(DrawArgs a) {
   set_half_denorm_flush();
   __shared__ TriLds s_tri[4][64];
@@ -333,42 +365,42 @@ __global__ __launch_bounds__(256, 5) void k_draw_setup(DrawArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   TriLds* const tl = s_tri[wave];
   uint32_t* const off = s_off[wave];
-  const uint32_t tris = a.draw_cmd[0] / 3u;  // VkDrawIndexedIndirectCommand.indexCount
+  // VkDrawIndexedIndirectCommand.indexCount (pairs: a cull call whose index count wrapped zeroed instanceCount, the draw is a no-op)
+  const uint32_t tris = (PAIR && a.draw_cmd[1] == 0u) ? 0u : a.draw_cmd[0] / 3u;
   const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)wave, nwaves = gridDim.x * 4u;
   // The fetches of a triangle hang on each other (index -> MeshletInstance -> row -> Meshlet record -> micro index -> vertex id ->
   // position) and the kernel waits for them most of its time: the index entries are fetched two steps ahead and the MeshletInstance
   // record of the first corner one step ahead, which takes the first two links out of a step's own chain.
-  const uint32_t corner_bits_pf = a.wide ? 9u : 8u;
-  uint32_t nidx[3] = {0, 0, 0}, nnidx[3] = {0, 0, 0};  // the next / next but one step's index-buffer entries
+  IdxEntry<PAIR> nidx[3] = {}, nnidx[3] = {};            // the next / next but one step's index-buffer entries
   uint2 nmli = make_uint2(0u, 0u);                       // the next step's MeshletInstance record (of its first corner)
   if (wave_id * 64u + (uint32_t)lane < tris) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) nidx[k] = a.indices[(wave_id * 64u + (uint32_t)lane) * 3u + (uint32_t)k];
-    nmli = reinterpret_cast<const uint2*>(a.meshlet_instances)[nidx[0] >> corner_bits_pf];
+    for (int k = 0; k < 3; k++) nidx[k] = load_entry<PAIR>(a, (wave_id * 64u + (uint32_t)lane) * 3u + (uint32_t)k);
+    nmli = reinterpret_cast<const uint2*>(a.meshlet_instances)[entry_instance<PAIR>(a, nidx[0])];
   }
   if ((wave_id + nwaves) * 64u + (uint32_t)lane < tris) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) nnidx[k] = a.indices[((wave_id + nwaves) * 64u + (uint32_t)lane) * 3u + (uint32_t)k];
+    for (int k = 0; k < 3; k++) nnidx[k] = load_entry<PAIR>(a, ((wave_id + nwaves) * 64u + (uint32_t)lane) * 3u + (uint32_t)k);
   }
   for (uint32_t base = wave_id * 64u; base < tris; base += nwaves * 64u) {  // wave-uniform
     const uint32_t tri = base + (uint32_t)lane;
-    const uint32_t idx[3] = {nidx[0], nidx[1], nidx[2]};
+    const IdxEntry<PAIR> idx[3] = {nidx[0], nidx[1], nidx[2]};
     const uint2 mli0 = nmli;
     {
 #pragma unroll
       for (int k = 0; k < 3; k++) nidx[k] = nnidx[k];
-      if (tri + nwaves * 64u < tris) nmli = reinterpret_cast<const uint2*>(a.meshlet_instances)[nidx[0] >> corner_bits_pf];
+      if (tri + nwaves * 64u < tris) nmli = reinterpret_cast<const uint2*>(a.meshlet_instances)[entry_instance<PAIR>(a, nidx[0])];
       const uint32_t nt = tri + 2u * nwaves * 64u;
       if (nt < tris) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) nnidx[k] = a.indices[nt * 3u + (uint32_t)k];
+        for (int k = 0; k < 3; k++) nnidx[k] = load_entry<PAIR>(a, nt * 3u + (uint32_t)k);
       }
     }
     uint32_t count = 0;  // box pixels this lane's triangle contributes to the wave's small-triangle pass
     if (tri < tris) {
       float clip[3][4];
       uint32_t vis;
-      tri_clip_coords(a, idx, clip, vis, &mli0);
+      tri_clip_coords<PAIR>(a, idx, clip, vis, &mli0);
       const int cls = tri_clip_class(clip);
       TriSetup t;
       if (cls == 1) {  // rare: crosses the camera plane or the guard band -- clipped by k_draw_clipped, one thread per triangle
@@ -445,17 +477,17 @@ __global__ __launch_bounds__(256, 5) void k_draw_setup(DrawArgs a) {
 // not recorded, so this instantiation walks the whole index list again and clips every crossing triangle it finds.  Drawing a
 // triangle twice leaves the image unchanged (per-pixel maximum), so no bookkeeping of which ones the queue did hold is needed.
 // It returns at once when the queue did not overflow.
-template <bool RESCAN>
+template <bool RESCAN, bool PAIR>
 __global__ __launch_bounds__(64) void k_draw_clipped(DrawArgs a) {
   set_half_denorm_flush();
   if (RESCAN && *a.clip_count <= a.clip_capacity) return;
-  const uint32_t count = RESCAN ? a.draw_cmd[0] / 3u : min(*a.clip_count, a.clip_capacity);
+  const uint32_t count = RESCAN ? ((PAIR && a.draw_cmd[1] == 0u) ? 0u : a.draw_cmd[0] / 3u) : min(*a.clip_count, a.clip_capacity);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     float clip[3][4];
     uint32_t vis;
     const uint32_t tri = RESCAN ? i : a.clip_list[i];
-    const uint32_t idx[3] = {a.indices[tri * 3u], a.indices[tri * 3u + 1u], a.indices[tri * 3u + 2u]};
-    tri_clip_coords(a, idx, clip, vis);
+    const IdxEntry<PAIR> idx[3] = {load_entry<PAIR>(a, tri * 3u), load_entry<PAIR>(a, tri * 3u + 1u), load_entry<PAIR>(a, tri * 3u + 2u)};
+    tri_clip_coords<PAIR>(a, idx, clip, vis);
     if (RESCAN && tri_clip_class(clip) != 1) continue;
     float poly[2][9][4];
     int n = 3, cur = 0;
@@ -607,9 +639,15 @@ void launch_draw_visbuffer(const DrawArgs& a, bool clear, float* depth_out, uint
   if (clear) (void)hipMemsetAsync(a.visdepth, 0, n * 8u, s);
   (void)hipMemsetAsync(a.clip_count, 0, kRasterHeaderBytes, s);  // clip / tile counters and the big list's segment counters
   hipLaunchKernelGGL(k_draw_rows, dim3(std::max(1u, std::min((a.mesh_instance_count + 255u) / 256u, max_grid))), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_draw_setup, dim3(max_grid), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_draw_clipped<false>, dim3(256), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_draw_clipped<true>, dim3(max_grid), dim3(64), 0, s, a);  // (returns at once unless the id queue overflowed)
+  if (a.wide == 2u) {  // {id, corner} pairs
+    hipLaunchKernelGGL(k_draw_setup<true>, dim3(max_grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_draw_clipped<false, true>), dim3(256), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((k_draw_clipped<true, true>), dim3(max_grid), dim3(64), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_draw_setup<false>, dim3(max_grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_draw_clipped<false, false>), dim3(256), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((k_draw_clipped<true, false>), dim3(max_grid), dim3(64), 0, s, a);  // (returns at once unless the id queue overflowed)
+  }
   hipLaunchKernelGGL(k_draw_big, dim3(max_grid), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_draw_big_tiles, dim3(max_grid), dim3(256), 0, s, a);
   if (depth_out || vis_out)

@@ -72,8 +72,8 @@ struct CullGeometryContext {
   // not in the reference struct (it is a local there, CullGeometry.cpp:125-127): the indirect
   // dispatch command of cull_triangles, exposed so callers can read the visible-meshlet count
   Buffer cull_triangles_cmd_buffer = {};
-  // extension: wide packed index for meshlets of up to 128 triangles
-  bool wide_triangle_index = false;
+  // extension: 1 = wide packed index for meshlets of up to 128 triangles (<= 2^23 ids), 2 = {id, corner} pairs (no id limit)
+  uint32_t wide_triangle_index = 0;
   bool small_triangle_cull = false;  // extension named by the north star; default OFF = reference behaviour
   // extension (scheduling only): cull_triangles of this call runs on the backend's own stream beside what the caller enqueues next
   // (the next cull_geometry's meshlet stage, generate_hiz); join_triangles() before anything of the caller's reads the index list
@@ -103,7 +103,7 @@ struct MainGeometryContext {
   // and the late draw of a frame, whether this draw starts from a cleared image (the early one), and the wide-index extension
   Buffer visdepth_buffer = {};
   bool clear = true;
-  bool wide_triangle_index = false;
+  uint32_t wide_triangle_index = 0;
 };
 
 class RendererInstance {

@@ -112,14 +112,15 @@ class PreparedFrame:
     reordered_indices_buffer: Optional[torch.Tensor]
 
     @staticmethod
-    def create(scene: Scene, with_triangles: bool = True, expand: bool = True, max_tris: int = 64) -> "PreparedFrame":
+    def create(scene: Scene, with_triangles: bool = True, expand: bool = True, max_tris: int = 64, index_words: int = 1) -> "PreparedFrame":
+        """max_tris = 128 for wide_triangle_index != 0; index_words = 2 for wide_triangle_index = 2 ({id, corner} pairs, 8 bytes per index)."""
         dev = scene.device
         n = scene.n_meshlet_instances
         mli = scene.meshlet_instances.clone() if expand else torch.zeros((n, 2), dtype=torch.int32, device=dev)
         vis_idx = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         # zero-filled on (re)upload of the instances, RendererInstance.cpp:1651-1665
         mask = torch.zeros(max((n + 31) // 32, 1), dtype=torch.int32, device=dev)
-        reordered = torch.zeros(max(n, 1) * max_tris * 3, dtype=torch.int32, device=dev) if with_triangles else None
+        reordered = torch.zeros(max(n, 1) * max_tris * 3 * index_words, dtype=torch.int32, device=dev) if with_triangles else None
         return PreparedFrame(scene, n, mli, vis_idx, mask, reordered)
 
     def c(self) -> L.PreparedFrame:
@@ -150,7 +151,7 @@ class CullGeometryContext:
     vsm_clipmaps_buffer: Optional[torch.Tensor] = None            # uint8 [V*76] GPU::VirtualClipmap records
     vsm_clipmap_dirty_flags_buffer: Optional[torch.Tensor] = None  # int32 [V]
     vsm_clipmap_count: int = 0
-    wide_triangle_index: bool = False  # extension: (id << 9) | (3t+k), meshlets of up to 128 triangles
+    wide_triangle_index: int = 0  # extension: 1 / True = (id << 9) | (3t+k), meshlets of up to 128 triangles, <= 2^23 ids; 2 = {id, corner} pairs, no id limit
     small_triangle_cull: bool = False  # extension (north star): also drop triangles whose screen bbox covers no pixel centre
     async_triangles: bool = False  # extension (scheduling only): the triangle stage runs on the context's own stream; RendererInstance.join_triangles
     share_pass_tests: bool = False  # extension (caching only): the late HiZ call of a frame reuses the early call's frustum + cone results (include/oxcull.h)
@@ -363,7 +364,7 @@ class RendererInstance:
         f = self.prepared_frame.c()
         d = L.DrawContext()
         d.struct_size = C.sizeof(L.DrawContext)
-        d.wide_triangle_index = 1 if context.wide_triangle_index else 0
+        d.wide_triangle_index = int(context.wide_triangle_index)
         d.clear = 1 if clear else 0
         d.width, d.height = width, height
         for i in range(16):

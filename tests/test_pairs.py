@@ -1,0 +1,153 @@
+"""SURVEY A.7's index form for shards beyond 2^23 ids (include/oxcull.h, wide_triangle_index = 2): every index is the pair
+{u32 meshlet_instance_index, u32 3t+k}.  No reference behaviour exists for it -- the reference packs 24 + 8 bits (visbuffer.slang:9-14,
+cull_triangles.slang:84-88) -- so parity is against the oracle's statement of the same rule, and the rule is tied to the packed forms:
+a pair list is the packed list with its two fields in two words."""
+import numpy as np
+import pytest
+import torch
+
+from oxylus_amd import lib as L
+from oxylus_amd.synth import SceneSpec, make_scene
+from util import assert_same, gpu_frame, oracle_frame, pairs_as_u64
+
+SPECS = [SceneSpec(n_mesh_instances=12, meshlets_per_mesh=70, tris_per_meshlet=124, seed=111),
+         SceneSpec(n_mesh_instances=5, meshlets_per_mesh=33, tris_per_meshlet=128, seed=112, ragged=True),
+         SceneSpec(n_mesh_instances=7, meshlets_per_mesh=50, tris_per_meshlet=64, seed=113)]
+IDS = ["124tris", "ragged<=128", "64tris"]
+
+
+def _want(cpu, wide, small=False):
+    import oracle
+
+    cam = cpu.cull_camera()
+    vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances)
+    return vis, oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, vis, 0, vis.numel(), wide=wide, small_triangle_cull=small)
+
+
+@pytest.mark.parametrize("spec", SPECS, ids=IDS)
+def test_oracle_pairs_are_the_packed_index_in_two_words(oracle_lib, spec):
+    """(CPU) the checker's pair list against its own 23 + 9 bit list: same entries in the same order, id = packed >> 9, corner = packed & 0x1FF."""
+    cpu = make_scene(spec, "cpu")
+    _, packed = _want(cpu, 1)
+    _, pairs = _want(cpu, 2)
+    p = pairs.numpy().view(np.uint32).reshape(-1, 2)
+    u = packed.numpy().view(np.uint32)
+    assert p.shape[0] == u.size and u.size > 300
+    assert np.array_equal(p[:, 0], u >> 9) and np.array_equal(p[:, 1], u & 0x1FF)
+    assert np.all(np.diff(pairs_as_u64(pairs.numpy()).astype(np.int64).reshape(-1, 3), axis=1) == 1)  # a triangle's corners 3t, 3t+1, 3t+2, one instance
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", SPECS, ids=IDS)
+@pytest.mark.parametrize("unordered", [0, 1], ids=["ordered", "fused"])
+def test_pair_index_lists_match_the_oracle(renderer, oracle_lib, spec, unordered):
+    """Ordered form: byte-identical.  unordered_output = 1 (one fused launch, slots by atomic_add): identical as sorted sets, triangles whole."""
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    want_vis, want = _want(cpu, 2)
+    got = gpu_frame(renderer, gpu, unordered_output=unordered, wide_triangle_index=2, max_tris=128)
+    if unordered == 0:
+        assert np.array_equal(got["visible"], want_vis.numpy())
+        assert np.array_equal(got["indices"], want.numpy())
+    else:
+        assert np.array_equal(np.sort(got["visible"]), want_vis.numpy())
+        g = pairs_as_u64(got["indices"])
+        assert np.array_equal(np.sort(g), pairs_as_u64(want.numpy()))
+        assert np.all(np.diff(g.astype(np.int64).reshape(-1, 3), axis=1) == 1)
+    if spec.tris_per_meshlet > 85:
+        assert int(got["indices"].view(np.uint32).reshape(-1, 2)[:, 1].max()) > 255  # corners beyond the reference's 8-bit field are in play
+
+
+@pytest.mark.gpu
+def test_pair_lists_with_the_small_triangle_cull_and_a_larger_scene(renderer, oracle_lib):
+    spec = SceneSpec(n_mesh_instances=60, meshlets_per_mesh=200, with_geometry=True, seed=31, tris_per_meshlet=124)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    for small in (False, True):
+        want_vis, want = _want(cpu, 2, small)
+        got = gpu_frame(renderer, gpu, unordered_output=1, wide_triangle_index=2, small_triangle_cull=small, max_tris=128)
+        assert np.array_equal(np.sort(pairs_as_u64(got["indices"])), pairs_as_u64(want.numpy()))
+        got0 = gpu_frame(renderer, gpu, unordered_output=0, wide_triangle_index=2, small_triangle_cull=small, max_tris=128)
+        assert np.array_equal(got0["indices"], want.numpy())
+        assert want.numel() > 6000
+
+
+@pytest.mark.gpu
+def test_two_pass_frame_with_pairs(renderer, oracle_lib):
+    """The early / late sequence against a pyramid: the late list starts behind the early one; both calls in pair form, ordered and fused."""
+    import oracle
+    from oxylus_amd.renderer import ImageAttachment, MainGeometryContext
+    from oxylus_amd.synth import make_depth
+    from util import oracle_hiz
+
+    spec = SceneSpec(n_mesh_instances=40, meshlets_per_mesh=120, with_geometry=True, seed=77, tris_per_meshlet=124)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    hw = 128
+    depth = make_depth(2 * hw, 2 * hw, 24, seed=9)
+    data, levels, offs = oracle_hiz(depth, hw, hw)
+    att = ImageAttachment.hiz(hw, hw, "cuda:0")
+    renderer.generate_hiz(MainGeometryContext(ImageAttachment.depth(depth.cuda()), att))
+    g = torch.Generator().manual_seed(3)
+    mask = ((torch.rand(((cpu.n_meshlet_instances + 31) // 32, 32), generator=g) < 0.3).to(torch.int64) << torch.arange(32)).sum(1).to(torch.int32)
+    want = oracle_frame(cpu, use_hiz=True, hiz={"data": data, "w": hw, "h": hw, "levels": levels, "offs": offs}, mask=mask, two_pass=True, with_triangles=False)
+    cam = cpu.cull_camera()
+    for tag in ("early", "late"):
+        vis = torch.from_numpy(want[f"{tag}_visible"])
+        want[f"{tag}_indices"] = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, vis, 0, vis.numel(), wide=2).numpy()
+    got = gpu_frame(renderer, gpu, use_hiz=True, hiz=att, mask=mask, two_pass=True, share_pass_tests=True, wide_triangle_index=2, max_tris=128)
+    assert_same(want, got, ["early", "late", "early_visible", "late_visible", "mask"])
+    # (the index buffer of the late call continues behind the early call's entries only in the reference's draw; here each call's list starts at 0)
+    assert np.array_equal(got["early_indices"], want["early_indices"]) and np.array_equal(got["late_indices"], want["late_indices"])
+    gotu = gpu_frame(renderer, gpu, use_hiz=True, hiz=att, mask=mask, two_pass=True, share_pass_tests=True, wide_triangle_index=2, max_tris=128, unordered_output=1)
+    for tag in ("early", "late"):
+        assert np.array_equal(np.sort(pairs_as_u64(gotu[f"{tag}_indices"])), pairs_as_u64(want[f"{tag}_indices"]))
+    assert want["early_indices"].size > 1000 and want["late_indices"].size > 1000
+
+
+@pytest.mark.gpu
+def test_pairs_have_no_id_limit_and_bad_values_are_refused(renderer, oracle_lib):
+    """16.9 M meshlet instances -- beyond the 2^24 ids of the reference's packed index and twice the 2^23 of the 23 + 9 bit form -- in ONE call: the
+    tail of the pair list (largest ids) against the checker.  The packed forms refuse that frame; wide_triangle_index = 3 is refused."""
+    import oracle
+    from oxylus_amd.lib import OxcError
+    from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
+
+    K = 1000
+    spec = SceneSpec(n_mesh_instances=16900, meshlets_per_mesh=K, share_meshes=2, seed=501, scene_depth=900.0)  # 16 900 000 > 2^24 = 16 777 216
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    N = cpu.n_meshlet_instances
+    cam = cpu.cull_camera()
+    want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances, nthreads=16)
+    frame = PreparedFrame.create(gpu, max_tris=128, index_words=2)  # 52 GB
+    renderer.prepared_frame = frame
+    for unordered in (0, 1):
+        ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=2, unordered_output=unordered)
+        renderer.seed_meshlet_instances(ctx, N)
+        renderer.cull_geometry(ctx)
+        c = renderer.read_counters(ctx)
+        got_vis = frame.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu()
+        assert torch.equal(torch.sort(got_vis)[0], want_vis)
+        assert int(want_vis.max()) >= (1 << 24)  # ids that no packed form can hold are in play
+        tail = 64
+        want_tail = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, want_vis.numel() - tail, tail, wide=2).numpy()
+        if unordered == 0:
+            got_idx = frame.reordered_indices_buffer[2 * c.draw_index_count - want_tail.size: 2 * c.draw_index_count].cpu().numpy()
+            assert np.array_equal(got_idx, want_tail)
+        else:
+            allp = pairs_as_u64(frame.reordered_indices_buffer[: 2 * c.draw_index_count].cpu().numpy())
+            lo = np.uint64(int(want_vis[-tail])) << np.uint64(32)
+            assert np.array_equal(np.sort(allp[allp >= lo]), pairs_as_u64(want_tail))
+        assert want_tail.size > 0 and int(want_tail.view(np.uint32).reshape(-1, 2)[:, 0].max()) >= (1 << 24)
+    for wide in (0, 1, 3):
+        bad = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=wide)
+        renderer.seed_meshlet_instances(bad, N)
+        with pytest.raises(OxcError):
+            renderer.cull_geometry(bad)
+    small = PreparedFrame.create(gpu, max_tris=128, index_words=1)  # half the bytes the pair form needs
+    renderer.prepared_frame = small
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=2)
+    renderer.seed_meshlet_instances(ctx, N)
+    with pytest.raises(OxcError):
+        renderer.cull_geometry(ctx)

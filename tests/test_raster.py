@@ -194,9 +194,9 @@ def _gpu_vs_oracle(renderer, cpu, gpu, W, H, wide=False, max_tris=64):
     want_idx = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, 0, want_vis.numel(), wide=wide)
     vd = torch.zeros((H, W), dtype=torch.int64)
     oracle.draw_visbuffer(cpu, cpu.meshlet_instances, want_idx, pv, W, H, vd, wide=wide)
-    frame = PreparedFrame.create(gpu, max_tris=max_tris)
+    frame = PreparedFrame.create(gpu, max_tris=max_tris, index_words=2 if int(wide) == 2 else 1)
     renderer.prepared_frame = frame
-    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=wide)
+    ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=int(wide))
     renderer.seed_meshlet_instances(ctx, gpu.n_meshlet_instances)
     renderer.cull_geometry(ctx)
     got = torch.full((H, W), -1, dtype=torch.int64, device="cuda")
@@ -335,6 +335,10 @@ def test_gpu_draw_wide_index(renderer, oracle_lib):
     cpu = make_scene(spec, "cpu")
     vd = _gpu_vs_oracle(renderer, cpu, cpu.to("cuda"), 200, 200, wide=True, max_tris=128)
     assert (vd != 0).any()
+    # SURVEY A.7's pair form (wide_triangle_index = 2): instance = pair.x, corner = pair.y instead of the shifts of visbuffer.slang:9-14 -- the same
+    # triangles, so the same image (vis = (instance << 8) | corner / 3 as VisBufferData::encode either way)
+    vd2 = _gpu_vs_oracle(renderer, cpu, cpu.to("cuda"), 200, 200, wide=2, max_tris=128)
+    assert torch.equal(vd2, vd)
 
 
 @pytest.mark.gpu

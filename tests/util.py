@@ -62,7 +62,8 @@ def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hi
     """Same sequence through liboxcull.so.  Returns numpy arrays in the layout of oracle_frame.
     share_pass_tests: the flag of include/oxcull.h on every call; before_pass(i, ctx): called in front of call i (tests that change
     something between the early and the late call)."""
-    frame = PreparedFrame.create(scene_gpu, with_triangles=with_triangles, expand=not run_cull_meshes, max_tris=max_tris)
+    words = 2 if int(wide_triangle_index) == 2 else 1  # {id, corner} pairs: two words per index
+    frame = PreparedFrame.create(scene_gpu, with_triangles=with_triangles, expand=not run_cull_meshes, max_tris=max_tris, index_words=words)
     if mask is not None:
         frame.meshlet_instance_visibility_mask_buffer.copy_(mask.to(scene_gpu.device))
     renderer.prepared_frame = frame
@@ -89,7 +90,7 @@ def gpu_frame(renderer, scene_gpu, cull_flags=L.CULL_TEST_ALL, use_hiz=False, hi
         first = c.early_visible_meshlet_instances if (use_hiz and late) else 0
         emitted = c.cull_triangles_cmd_x
         vis = frame.visible_meshlet_instances_indices_buffer[first:first + emitted].cpu().numpy().copy()
-        idx = frame.reordered_indices_buffer[:c.draw_index_count].cpu().numpy().copy() if with_triangles else None
+        idx = frame.reordered_indices_buffer[:c.draw_index_count * words].cpu().numpy().copy() if with_triangles else None
         if use_hiz:
             res[f"{tag}_emitted"] = emitted
             res[f"{tag}_visible"] = vis
@@ -116,6 +117,12 @@ def sorted_lists(res: dict) -> dict:
         if isinstance(v, np.ndarray) and (k.endswith("visible") or k.endswith("indices")):
             out[k] = np.sort(v.view(np.uint32)).view(v.dtype)
     return out
+
+
+def pairs_as_u64(indices: np.ndarray) -> np.ndarray:
+    """wide_triangle_index = 2: the {u32 id, u32 corner} pairs of an index list as (id << 32) | corner -- ascending exactly when the ordered list is."""
+    u = indices.view(np.uint32).reshape(-1, 2).astype(np.uint64)
+    return (u[:, 0] << np.uint64(32)) | u[:, 1]
 
 
 def assert_triangles_adjacent(indices: np.ndarray, corner_bits: int = 8):
