@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config1", "config5", "bounds", "loop", "vsm"])
     ap.add_argument("--inner-reps", type=int, default=0, help="frames per step (default: 48 for config3, 9600 for config2)")
-    ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses the wide packed index extension (<= 8M meshlets)")
+    ap.add_argument("--tris", type=int, default=64, help="config3: triangles per meshlet; > 64 uses an index extension of SURVEY A.7, see --index-form")
+    ap.add_argument("--index-form", default="pairs", choices=["pairs", "wide"],
+                    help="config3 with --tris > 64: 'pairs' (default; wide_triangle_index = 2: every index is {u32 id, u32 corner}, no id limit -- BASELINE's 10 M x 124 "
+                         "and 12.5 M-meshlet shards) or 'wide' (wide_triangle_index = 1: (id << 9) | corner, at most 2^23 ids, so 8 M meshlets)")
     ap.add_argument("--small-triangle-cull", action="store_true", help="config3: turn the opt-in small-triangle cull on (default off = reference behaviour)")
     ap.add_argument("--views", type=int, default=16, help="config5: number of cascade views per step")
     ap.add_argument("--meshlets", type=int, default=0, help="override meshlets per GPU (default 10M; 12.5M per rank when N > 1; 1M for config2)")
@@ -86,7 +89,7 @@ def parse():
                          "(and the unordered one after sort)\": the triangle stage is one launch that allocates its output slots with an atomic_add, like the reference; "
                          "0 = ascending lists (the library's default), 2 = appending HiZ meshlet tests too.  The other forms are timed as scheduling_ab variants; "
                          "bit_match compares unordered lists sorted")
-    ap.add_argument("--no-tris124", action="store_true", help="config3: skip the nested run with BASELINE's stated meshlet shape (64 verts / 124 tris, wide index, 8M meshlets)")
+    ap.add_argument("--no-tris124", action="store_true", help="config3: skip the nested run with BASELINE's stated meshlet shape (64 verts / 124 tris, pair index form, 10 M meshlets)")
     ap.add_argument("--no-scheduling-ab", action="store_true", help="config3: skip the short timed runs of the other schedulings (profiling runs: their concurrent kernels would "
                                                                     "be averaged into the per-kernel durations of a kernel trace)")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the short timed run with the other --hiz-exchange form")
@@ -357,8 +360,11 @@ def bench_config3(args, e):
     lib, ctxp, sp = r._lib, r._ctx, C.c_void_p(stream.cuda_stream)
     K = K_MESHLETS_PER_MESH
     wide = args.tris > 64
+    pairs = wide and args.index_form == "pairs"  # {u32 id, u32 corner} pairs beyond 2^23 ids
+    W = 2 if pairs else 1                        # words per index
+    wti = 2 if pairs else (1 if wide else 0)     # wide_triangle_index of include/oxcull.h
     n_meshlets = args.meshlets or (10_000_000 if world == 1 else 12_500_000)
-    if wide:
+    if wide and not pairs:
         n_meshlets = min(n_meshlets, 8_000_000)  # 23-bit instance id of the wide index
     M = max(1, n_meshlets // K)
     n_meshlets = M * K
@@ -392,11 +398,11 @@ def bench_config3(args, e):
         else:
             scene = make_scene(SceneSpec(n_mesh_instances=M, meshlets_per_mesh=K, with_geometry=True, seed=0x0A1DE5 + 2 + rank, tris_per_meshlet=args.tris), dev)
         r.reserve(M, n_meshlets)
-        frame = PreparedFrame.create(scene, with_triangles=True, max_tris=128 if wide else 64)
+        frame = PreparedFrame.create(scene, with_triangles=True, max_tris=128 if wide else 64, index_words=W)
         depth = ImageAttachment.depth(make_depth(2 * HW, 2 * HW, 64, seed=3, device=dev))  # the same image on every rank
         hiz = [ImageAttachment.hiz(HW, HW, dev) for _ in range(2)]  # double-buffered: the pyramid of the next frame can be built beside the cull of this one
         ctx = CullGeometryContext(use_hiz=True, init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=scene.cull_camera(), hiz_attachment=hiz[0],
-                                  stages=L.STAGE_ALL, wide_triangle_index=wide, small_triangle_cull=args.small_triangle_cull)
+                                  stages=L.STAGE_ALL, wide_triangle_index=wti, small_triangle_cull=args.small_triangle_cull)
         r.prepared_frame = frame
         r.seed_meshlet_instances(ctx, n_meshlets)
         # random prior-visibility mask, p = 0.3; every frame starts from it again
@@ -548,22 +554,34 @@ def bench_config3(args, e):
         if rank == 0:
             lim = min(args.cpu_prefix, M) * K  # the checker's sample: ids below `lim` (ascending lists: a prefix of each list)
             vis = frame.visible_meshlet_instances_indices_buffer[first:first + out.cull_triangles_cmd_x]
-            shift = 9 if wide else 8
+            shift = 32 if pairs else (9 if wide else 8)
+
+            def keys(t):  # an index list as ascending-comparable int64 keys: the packed u32, or (id << 32) | corner of a pair
+                if pairs:
+                    p2 = t.view(-1, 2).to(torch.int64) & 0xFFFFFFFF
+                    return (p2[:, 0] << 32) | p2[:, 1]
+                return t.to(torch.int64) & 0xFFFFFFFF
+
+            def unkeys(k):  # ... and back to the words of the list
+                if pairs:
+                    return torch.stack([(k >> 32), k & 0xFFFFFFFF], dim=1).to(torch.int32).reshape(-1)
+                return k.to(torch.int32)
+
             if use_unord[0]:  # an unordered list is compared SORTED (the ordered form's lists ascend)
                 vis = torch.sort(vis)[0]
-                allidx = torch.sort(frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64) & 0xFFFFFFFF)[0]
+                allidx = torch.sort(keys(frame.reordered_indices_buffer[:out.draw_index_count * W]))[0]
                 nv = int(torch.searchsorted(vis, torch.tensor([lim], dtype=torch.int32, device=dev)).item())
                 ni = int(torch.searchsorted(allidx, torch.tensor([lim << shift], dtype=torch.int64, device=dev)).item())
                 snap[tag]["visible_prefix"] = vis[:nv].cpu()
-                snap[tag]["indices_prefix"] = allidx[:ni].to(torch.int32).cpu()
+                snap[tag]["indices_prefix"] = unkeys(allidx[:ni]).cpu()
                 del allidx
             else:
                 nv = int(torch.searchsorted(vis, torch.tensor([lim], dtype=torch.int32, device=dev)).item())
                 # packed (id << 8 | corner) values are u32: search an upper-bounded head of the list as int64
-                head = frame.reordered_indices_buffer[:min(out.draw_index_count, nv * (384 if wide else 192))].to(torch.int64) & 0xFFFFFFFF
+                head = keys(frame.reordered_indices_buffer[:min(out.draw_index_count, nv * (384 if wide else 192)) * W])
                 ni = int(torch.searchsorted(head, torch.tensor([lim << shift], dtype=torch.int64, device=dev)).item())
                 snap[tag]["visible_prefix"] = vis[:nv].cpu()
-                snap[tag]["indices_prefix"] = frame.reordered_indices_buffer[:ni].cpu()
+                snap[tag]["indices_prefix"] = frame.reordered_indices_buffer[:ni * W].cpu()
 
     with torch.cuda.stream(stream):
         run_frame(record)
@@ -583,10 +601,14 @@ def bench_config3(args, e):
         ne = out.early_visible_meshlet_instances
         nv = ne + out.late_visible_meshlet_instances
         vis = frame.visible_meshlet_instances_indices_buffer[:nv].to(torch.int64)
-        idx = frame.reordered_indices_buffer[:out.draw_index_count].to(torch.int64) & 0xFFFFFFFF
+        idx = frame.reordered_indices_buffer[:out.draw_index_count * W].to(torch.int64) & 0xFFFFFFFF
+        if pairs:
+            idx = (idx.view(-1, 2)[:, 0] << 32) | idx.view(-1, 2)[:, 1]
         if use_unord[0]:
             vis = torch.cat([torch.sort(vis[:ne])[0], torch.sort(vis[ne:])[0]])
             idx = torch.sort(idx)[0]
+        if pairs:
+            idx = idx % 2147483629  # (keeps the weighted sum below inside int64)
         wv = torch.arange(1, 1 + vis.numel(), device=dev, dtype=torch.int64) % 1000003
         wi = torch.arange(1, 1 + idx.numel(), device=dev, dtype=torch.int64) % 1000003
         return (out.early_visible_meshlet_instances, out.late_visible_meshlet_instances, out.draw_index_count, int((vis * wv).sum().item()),
@@ -706,24 +728,29 @@ def bench_config3(args, e):
         "cull_triangles_emit": v_early * (8.0 * H + 4.0) + 12.0 * t_early,
         "cull_triangles_emit_late": v_late * (8.0 * H + 4.0) + 12.0 * t_late,
     }
+    tri_out_bytes = 12.0 * W  # per emitted triangle: three u32 indices, or three {u32 id, u32 corner} pairs (24 B)
+    alg["cull_triangles_emit"] = v_early * (8.0 * H + 4.0) + tri_out_bytes * t_early
+    alg["cull_triangles_emit_late"] = v_late * (8.0 * H + 4.0) + tri_out_bytes * t_late
     if main_unord:  # the fused kernel tests AND expands: no pass masks or visible ids through memory (-2 x 8 H, -4 B per visible meshlet)
-        alg["cull_triangles_test"] = v_early * tri_bytes_per_meshlet + 12.0 * t_early
-        alg["cull_triangles_test_late"] = v_late * tri_bytes_per_meshlet + 12.0 * t_late
+        alg["cull_triangles_test"] = v_early * tri_bytes_per_meshlet + tri_out_bytes * t_early
+        alg["cull_triangles_test_late"] = v_late * tri_bytes_per_meshlet + tri_out_bytes * t_late
     # the second clock: the committed rocprofv3 --kernel-trace --stats averages of the same kernels (of the build the profile was taken
     # from; HIP-event spans above include ~4.5 us of event overhead per launch, reported as _empty_event_pair_us, not subtracted)
     # (the committed profiles are of the default workload: T = 64, ordered lists; any other shape has no counters of its own and says so)
     std_shape = not args.small_triangle_cull and main_unord == 1 and main_share
     prof_names = ([f"{t}_config3_pmc.json" for t in PROFILE_ROUNDS] if (std_shape and not wide and n_meshlets == 10_000_000) else
-                  [f"{t}_tris124_pmc.json" for t in PROFILE_ROUNDS] if (std_shape and wide and n_meshlets == 8_000_000) else [])
+                  [f"{t}_pairs124_pmc.json" for t in PROFILE_ROUNDS] if (std_shape and pairs and n_meshlets == 10_000_000) else
+                  [f"{t}_tris124_pmc.json" for t in PROFILE_ROUNDS] if (std_shape and wide and not pairs and n_meshlets == 8_000_000) else [])
     rp = rocprof_kernel_us(prof_names) if prof_names else {}
     pmc_rw = pmc_read_written(prof_names) if prof_names else {}
     rp_names = {"prepare_instances": ["oxc::k_prepare_instances"], "hiz": ["oxc::k_hiz_tile", "oxc::k_hiz_tail"],
                 "cull_meshlets_test": ["oxc::k_cull_meshlets_test_shared<false>" if main_share else "oxc::k_cull_meshlets_test<true, true, false, 4>"],
                 "cull_meshlets_test_late": ["oxc::k_cull_meshlets_test_shared<true>" if main_share else "oxc::k_cull_meshlets_test<true, true, true, 4>"],
                 "cull_meshlets_emit": ["oxc::k_cull_meshlets_emit<true, false>"], "cull_meshlets_emit_late": ["oxc::k_cull_meshlets_emit<true, true>"],
-                "cull_triangles_test": [f"oxc::k_cull_triangles_fused<false, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<false, {str(wide).lower()}, false>"],
-                "cull_triangles_test_late": [f"oxc::k_cull_triangles_fused<true, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<true, {str(wide).lower()}, false>"],
-                "cull_triangles_emit": ["oxc::k_cull_triangles_emit<false, false>"], "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit<true, false>"]}
+                "cull_triangles_test": ["oxc::k_cull_triangles_fused_pairs<false, false>" if (main_unord and pairs) else f"oxc::k_cull_triangles_fused<false, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<false, {str(wide).lower()}, false>"],
+                "cull_triangles_test_late": ["oxc::k_cull_triangles_fused_pairs<true, false>" if (main_unord and pairs) else f"oxc::k_cull_triangles_fused<true, {str(wide).lower()}, false>" if main_unord else f"oxc::k_cull_triangles_test<true, {str(wide).lower()}, false>"],
+                "cull_triangles_emit": ["oxc::k_cull_triangles_emit_pairs<false>" if pairs else f"oxc::k_cull_triangles_emit<false, {str(wide).lower()}>"],
+                "cull_triangles_emit_late": ["oxc::k_cull_triangles_emit_pairs<true>" if pairs else f"oxc::k_cull_triangles_emit<true, {str(wide).lower()}>"]}
     kernels, frame_alg, frame_kernel_us = {}, 0.0, 0.0
     for name, k in kern.items():
         if name.startswith("_"):
@@ -759,9 +786,9 @@ def bench_config3(args, e):
         dom_us = sum(k["avg_us"] * k["launches"] for k in tt) / sum(k["launches"] for k in tt)
         dom_bytes = (alg["cull_triangles_test"] + alg["cull_triangles_test_late"]) / 2.0
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        dom_name = "k_cull_triangles_fused" if main_unord else "k_cull_triangles_test"
+        dom_name = ("k_cull_triangles_fused_pairs" if pairs else "k_cull_triangles_fused") if main_unord else "k_cull_triangles_test"
         traffic, traffic_src, traffic_same = pmc_traffic(prof_names, lambda k: dom_name in k) if prof_names else (None, None, None)
-        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + (f"; test + expansion in one launch: {tri_bytes_per_meshlet} B read per visible meshlet + 12 B written per emitted triangle)" if main_unord else ")"),
+        roofline = {"bound": "hbm", "kernel": f"{dom_name} (early + late launch of a frame, averaged" + (f"; test + expansion in one launch: {tri_bytes_per_meshlet} B read per visible meshlet + {int(tri_out_bytes)} B written per emitted triangle)" if main_unord else ")"),
                     "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_over_algorithmic": round(traffic / dom_bytes, 3) if traffic else None,
@@ -820,7 +847,7 @@ def bench_config3(args, e):
                 n_e = oracle.cull_meshlets_hiz(sub, cam, sub.meshlet_instances, flags, hz, v, mk, out)
                 first = v.early if tag == "late" else 0
                 res[tag] = (out[first:first + n_e].clone(),
-                            oracle.cull_triangles(sub, cam, sub.meshlet_instances, out, first, n_e, wide=wide, small_triangle_cull=args.small_triangle_cull))
+                            oracle.cull_triangles(sub, cam, sub.meshlet_instances, out, first, n_e, wide=wti, small_triangle_cull=args.small_triangle_cull))
             return res, mk
 
         t_c0 = time.perf_counter()
@@ -841,7 +868,14 @@ def bench_config3(args, e):
             # change under fused multiply-adds / reciprocal divisions, and how many triangles are ill-conditioned at all.
             with oracle.variant("fast"):
                 fast, mask_fast = cpu_sequence()
-            tri1 = lambda t: (t.view(-1, 3)[:, 0].numpy().astype("int64") & 0xFFFFFFFF) if t.numel() else torch.zeros(0).numpy()  # noqa: E731
+            def tri1(t):  # one key per emitted triangle: its first index (packed u32, or the pair as id << 32 | corner)
+                if not t.numel():
+                    return torch.zeros(0).numpy()
+                if pairs:
+                    a6 = t.view(-1, 6).numpy().astype("int64") & 0xFFFFFFFF
+                    return (a6[:, 0] << 32) | a6[:, 1]
+                return t.view(-1, 3)[:, 0].numpy().astype("int64") & 0xFFFFFFFF
+
             import numpy as _np
 
             flags = oracle.triangle_boundary_flags(sub, cam, sub.meshlet_instances, want["late"][0], 0, want["late"][0].numel())
@@ -882,7 +916,7 @@ def bench_config3(args, e):
                     n_e = oracle.cull_meshlets_hiz(sub, cam, mli, flags, hz, v, mk, out)
                     first = v.early if tag == "late" else 0
                     res[tag] = (out[first:first + n_e].clone(),
-                                oracle.cull_triangles(sub, cam, mli, out, first, n_e, wide=wide, small_triangle_cull=args.small_triangle_cull))
+                                oracle.cull_triangles(sub, cam, mli, out, first, n_e, wide=wti, small_triangle_cull=args.small_triangle_cull))
                 box[slot] = res
 
             def cpu_sequence_mt():
@@ -891,8 +925,15 @@ def bench_config3(args, e):
                 list(pool.map(lambda it: cpu_piece(it[1][0], it[1][1], mk, box, it[0]), enumerate(ranges)))
                 res = {}
                 for tag in ("early", "late"):
+                    def rebase(t, a):  # a piece's indices name piece-local ids
+                        if not pairs:
+                            return t + ((a * K) << shift)
+                        t = t.clone()
+                        t.view(-1, 2)[:, 0] += a * K
+                        return t
+
                     res[tag] = (torch.cat([box[i][tag][0] + a * K for i, (a, b) in enumerate(ranges)]),
-                                torch.cat([box[i][tag][1] + ((a * K) << shift) for i, (a, b) in enumerate(ranges)]))
+                                torch.cat([rebase(box[i][tag][1], a) for i, (a, b) in enumerate(ranges)]))
                 return res, mk
 
             got_mt, mask_mt = cpu_sequence_mt()
@@ -921,6 +962,7 @@ def bench_config3(args, e):
                          f"configs[3]: {world_meshlets} meshlets sharded {world} ways by " + ("contiguous range" if not (shard_desc and shard_desc["shard_block_instances"] > 0) else shard_desc["assignment"]) + (" of ONE scene" if shard_desc else " (an independent scene per rank)") + " (the configs[2] pipeline per rank): rank 0 builds the "
                          "4096^2 pyramid and broadcasts it over RCCL/xGMI, per-rank counters all-gathered every frame, shard-local ids and outputs"),
             "meshlets_per_gpu": n_meshlets, "mesh_instances": M, "meshlets_per_mesh": K, "tris_per_meshlet": args.tris, "verts_per_meshlet": 64,
+            "index_form": ("pairs {u32 id, u32 corner}, 24 B per triangle (wide_triangle_index = 2)" if pairs else "(id << 9) | corner (wide_triangle_index = 1)" if wide else "(id << 8) | corner (visbuffer.slang:9-14)"),
             "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
             "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
             "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
@@ -1228,7 +1270,8 @@ def line_summary(line: dict) -> dict:
             ab = line["assignment_ab"]
             sm["sharding"]["other_assignment"] = {k: ab[k] for k in ("assignment", "value", "ms_per_frame", "per_rank_visible")}
     if "tris124" in line:
-        sm["tris124"] = {"ms_per_frame": g(line, "tris124", "ms_per_frame", nd=4), "frac": g(line, "tris124", "roofline", "frac"), "stage_frac": g(line, "tris124", "stage", "stage_frac"),
+        sm["tris124"] = {"meshlets": g(line, "tris124", "meshlets"), "index": "pairs" if "pairs" in (g(line, "tris124", "index_form") or "") else "wide9",
+                         "ms_per_frame": g(line, "tris124", "ms_per_frame", nd=4), "frac": g(line, "tris124", "roofline", "frac"), "stage_frac": g(line, "tris124", "stage", "stage_frac"),
                          "traffic": g(line, "tris124", "roofline", "traffic"), "bit_match": g(line, "tris124", "bit_match")}
     if "configs1" in line:
         c1 = line["configs1"]
@@ -1301,17 +1344,19 @@ def main():
                                          "per_rank_visible": sh["per_rank_visible"], "per_rank_ms_per_frame": sh["per_rank_ms_per_frame"], "bit_match": t["bit_match"]}
         if e.world == 1 and not args.no_tris124 and args.tris == 64 and not args.meshlets:
             # BASELINE's stated meshlet shape -- 64 vertices / 124 triangles -- does not fit the reference's 24 + 8 bit packed index: the same
-            # frame with the wide index extension ((id << 9) | corner, two 64-lane triangle passes, at most 2^23 ids: 8 M meshlets), a short run
+            # frame at the literal 10 M meshlets with the pair form (wide_triangle_index = 2: {u32 id, u32 corner}, 24 B per emitted triangle, two
+            # 64-lane triangle passes), a short run.  (`--tris 124 --index-form wide` is round 5's (id << 9) | corner form: at most 2^23 ids, 8 M meshlets.)
             import copy
 
             a2 = copy.copy(args)
-            a2.tris, a2.steps, a2.warmup = 124, max(4, args.steps // 4), 1
+            a2.tris, a2.steps, a2.warmup, a2.index_form = 124, max(4, args.steps // 4), 1, "pairs"
             a2.no_scheduling_ab, a2.no_cpu_baseline, a2.cpu_prefix = True, True, min(args.cpu_prefix, 250)
             stage_note("tris124")
             t = bench_config3(a2, e)
-            line["tris124"] = {"workload": "the configs[2] frame with 64 vertices / 124 triangles per meshlet (BASELINE's stated shape): wide_triangle_index, "
-                                           f"{t['config']['meshlets_per_gpu']} meshlets (2^23 ids), 4096^2 HiZ", "value": t["value"], "unit": "meshlets/s",
-                               "ms_per_frame": t["config"]["ms_per_frame"], "frames_timed": t["config"]["frames_timed"], "wide_triangle_index": True,
+            line["tris124"] = {"workload": "the configs[2] frame with 64 vertices / 124 triangles per meshlet (BASELINE's stated shape): wide_triangle_index = 2, "
+                                           f"{{u32 id, u32 corner}} pairs, {t['config']['meshlets_per_gpu']} meshlets, 4096^2 HiZ", "value": t["value"], "unit": "meshlets/s",
+                               "ms_per_frame": t["config"]["ms_per_frame"], "frames_timed": t["config"]["frames_timed"], "index_form": t["config"]["index_form"],
+                               "meshlets": t["config"]["meshlets_per_gpu"],
                                "visible_fraction": t["config"]["visible_fraction"], "triangles_per_visible_meshlet": t["config"]["triangles_per_visible_meshlet"],
                                "bit_match": t["bit_match"], "bit_match_detail": t["bit_match_detail"], "bit_match_sample": t["bit_match_sample"], "counts": t["counts"], "roofline": t["roofline"], "stage": t["stage"],
                                "kernels": {k: v for k, v in t["kernels"].items() if k.startswith("cull_triangles") or k.startswith("_")}}

@@ -107,20 +107,20 @@ def test_two_pass_frame_with_pairs(renderer, oracle_lib):
 
 @pytest.mark.gpu
 def test_pairs_have_no_id_limit_and_bad_values_are_refused(renderer, oracle_lib):
-    """16.9 M meshlet instances -- beyond the 2^24 ids of the reference's packed index and twice the 2^23 of the 23 + 9 bit form -- in ONE call: the
+    """19 M meshlet instances -- beyond the 2^24 ids of the reference's packed index and twice the 2^23 of the 23 + 9 bit form -- in ONE call: the
     tail of the pair list (largest ids) against the checker.  The packed forms refuse that frame; wide_triangle_index = 3 is refused."""
     import oracle
     from oxylus_amd.lib import OxcError
     from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
 
     K = 1000
-    spec = SceneSpec(n_mesh_instances=16900, meshlets_per_mesh=K, share_meshes=2, seed=501, scene_depth=900.0)  # 16 900 000 > 2^24 = 16 777 216
+    spec = SceneSpec(n_mesh_instances=19000, meshlets_per_mesh=K, share_meshes=2, seed=501, scene_depth=900.0)  # 19 000 000 > 2^24 = 16 777 216 (visible ids reach 17.1 M)
     cpu = make_scene(spec, "cpu")
     gpu = cpu.to("cuda")
     N = cpu.n_meshlet_instances
     cam = cpu.cull_camera()
     want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances, nthreads=16)
-    frame = PreparedFrame.create(gpu, max_tris=128, index_words=2)  # 52 GB
+    frame = PreparedFrame.create(gpu, max_tris=128, index_words=2)  # 58 GB
     renderer.prepared_frame = frame
     for unordered in (0, 1):
         ctx = CullGeometryContext(init_cull_meshes=False, cull_flags=L.CULL_TEST_ALL, cull_camera=gpu.cull_camera(), wide_triangle_index=2, unordered_output=unordered)
