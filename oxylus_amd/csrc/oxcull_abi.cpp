@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "oxcull.h"
+#include "oxcull_debug.h"
 #include "oxcull_kernels.hpp"
 #include "oxcull_types.hpp"
 

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/oxcull.h declares (no GPU needed)."""
+"""The C-ABI library loads and exports every symbol include/oxcull.h (the drop-in boundary) and include/oxcull_debug.h (test / harness /
+measurement hooks, not part of the boundary) declare (no GPU needed)."""
 import ctypes
 import os
 import re
@@ -8,14 +9,28 @@ from oxylus_amd import lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "oxcull.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(oxc_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("oxcull.h", "oxcull_debug.h")):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(oxc_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(L.EXPORTS)
+
+
+def test_the_boundary_header_carries_no_debug_hooks():
+    """include/oxcull.h is what an engine binds: the oxc_debug_* / profiling / probe entry points live in oxcull_debug.h, and nothing the
+    reference-named C++ surface (oxylus_amd/host/RendererInstance.hpp) or the integration notes bind comes from there."""
+    boundary = _declared_symbols(("oxcull.h",))
+    debug = _declared_symbols(("oxcull_debug.h",))
+    assert not [n for n in boundary if n.startswith("oxc_debug_") or n.startswith("oxc_profile_") or n == "oxc_stream_read_probe"]
+    assert debug and all(n.startswith("oxc_debug_") or n.startswith("oxc_profile_") or n == "oxc_stream_read_probe" for n in debug)
+    shim = open(os.path.join(ROOT, "oxylus_amd", "host", "RendererInstance.hpp")).read()
+    assert "oxcull_debug.h" not in shim and not [n for n in debug if n in shim]
 
 
 def test_library_exports_every_declared_symbol():
@@ -40,7 +55,7 @@ def test_context_struct_matches_the_header(tmp_path):
     import subprocess
 
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "oxcull.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(oxc_cull_geometry_context), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "oxcull_debug.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(oxc_cull_geometry_context), '
                    'offsetof(oxc_cull_geometry_context, small_triangle_cull), offsetof(oxc_cull_geometry_context, visibility_buffer), sizeof(oxc_kernel_times)); return 0; }\n')
     exe = str(tmp_path / "sz")
     subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
@@ -84,5 +99,5 @@ def test_header_is_plain_c99(tmp_path):
     import subprocess
 
     src = tmp_path / "c99.c"
-    src.write_text('#include "oxcull.h"\nint main(void) { oxc_cull_geometry_context c; oxc_mesh_blob_layout l; (void)c; (void)l; return 0; }\n')
+    src.write_text('#include "oxcull.h"\n#include "oxcull_debug.h"\nint main(void) { oxc_cull_geometry_context c; oxc_mesh_blob_layout l; oxc_kernel_times k; (void)c; (void)l; (void)k; return 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only", str(src)])
