@@ -1045,10 +1045,8 @@ OXC_DEV void meshlets_hiz_body(const MeshletTestArgs& a) {
 // over dirty views; views a whole wave no longer needs are skipped.  Output: ballots, expanded
 // by k_cull_meshlets_emit<false,false> like the plain meshlet stage.
 // ------------------------------------------------------------------------------------------
-#ifndef OXC_HPB_WAVES
-#define OXC_HPB_WAVES 6  // waves per SIMD (80 VGPRs, 7 spilled dwords): 338-341 us per 10 M meshlets x 10 views against 347-353 at 5 and 348 at 4
-#endif
-__global__ __launch_bounds__(256, OXC_HPB_WAVES) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
+constexpr int kHpbWaves = 6;  // waves per SIMD (80 VGPRs, 7 spilled dwords): 338-341 us per 10 M meshlets x 10 views against 347-353 at 5 and 348 at 4
+__global__ __launch_bounds__(256, kHpbWaves) void k_cull_meshlets_hpb_test(HpbTestArgs a) {
   // Round 2: the view loop is the OUTER loop of a wave step.  Round 1 walked one 64-meshlet group at a time and, inside it, one
   // clipmap view at a time, so every (group, view) paid the scalar-load round trips of the view's plane / matrix row on its own --
   // 0.89 ms per 10 M meshlets, latency-bound.  Here a wave holds G groups (all loads batched, as in the plain kernel) and a view's
@@ -1379,10 +1377,7 @@ OXC_DEV void meshlets_emit_body(const MeshletEmitArgs& a) {
 // Cache, whose write-back the NEXT kernels paid (the pyramid build 69 -> 48 us and the triangle tests 90 / 164 -> 67 / 151 us with
 // the lines gone, configs[2] frame).  Whole-line `nt` stores get both.  Same bytes at the same addresses as the per-slot form.
 // ------------------------------------------------------------------------------------------
-#ifndef OXC_EMIT_RUN
-#define OXC_EMIT_RUN 1024
-#endif
-constexpr uint32_t kEmitRun = OXC_EMIT_RUN;  // dwords a wave stages between flushes (>= 384 + 3: one WIDE slot)
+constexpr uint32_t kEmitRun = 1024;  // dwords a wave stages between flushes (>= 384 + 3: one WIDE slot)
 // PAIR (wide_triangle_index = 2, SURVEY A.7's form for shards beyond 2^23 ids): an index is the pair {u32 meshlet_instance_index, u32 corner} -- 8 bytes,
 // six dwords per triangle, no id limit below 2^32.  g0 and the run count in DWORDS either way (the callers double the index offset); the offset is 64-bit
 // in this form: 2^32 - 1 indices are 8.6e9 dwords.
@@ -1489,33 +1484,25 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
 // The two bodies of the triangle stage share the per-chunk pipeline (oxcull_tri_stages.inc / oxcull_tri_slots.inc):
 //   tris_test_body  -- ordered form: pass masks + per-chunk counts to memory, k_cull_triangles_emit follows;
 //   tris_fused_body -- unordered_output: the block also expands what it tested (FUSED above).
-#ifndef OXC_TRI_IDX_AHEAD
-#define OXC_TRI_IDX_AHEAD 2  // measured on config 3 (us per launch): 2/1 -> 123, 3/2 -> 125 (SGPR spills), 6 waves/SIMD with 3/2 or 4/3 -> 139-143; the loop version: 160
-#define OXC_TRI_POS_AHEAD 1
-#endif
-#ifndef OXC_TRI_WIDE_IDX_AHEAD
-#define OXC_TRI_WIDE_IDX_AHEAD OXC_TRI_IDX_AHEAD
-#define OXC_TRI_WIDE_POS_AHEAD OXC_TRI_POS_AHEAD
-#endif
-#ifndef OXC_TRI_LDS_VERTS
+// Pipeline depths of the slot loop, measured on config 3 (us per launch): index loads 2 / position gathers 1 slot ahead -> 123, 3/2 -> 125 (SGPR
+// spills), 6 waves/SIMD with 3/2 or 4/3 -> 139-143; the loop version: 160.  The WIDE instantiations use the same depths.
+constexpr int kTriIdxAhead = 2, kTriPosAhead = 1;
 // The corners of a triangle: nine ds_bpermute (36 B of LDS crossbar traffic per lane and pass) or, with the slot's transformed vertices written to
 // LDS once, three 16-byte reads per pass (64 B).  T = 64 (one pass per slot): the reads lose outright, fused kernels 99 / 209 -> 112 / 266 us.  WIDE
 // (two passes per slot, kernel bound by instruction issue rather than LDS bandwidth): 137 / 265 -> 132.5 / 258 us; 12-byte reads with the z flags
-// kept as a ballot: 136.5 / 262.6.  1 = WIDE only (default), 2 = every instantiation, 0 = ds_bpermute everywhere.
-#define OXC_TRI_LDS_VERTS 1
-#endif
+// kept as a ballot: 136.5 / 262.6.  So: LDS vertices for WIDE only.
 template <bool LATE, bool WIDE, bool SMALL>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
   constexpr int S = 16;  // slots per wave per chunk
-  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;  // position gathers (need the vertex ids) run this many slots ahead of the decision
-  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;  // vertex / micro index loads
+  constexpr int kPosAhead = kTriPosAhead;  // position gathers (need the vertex ids) run this many slots ahead of the decision
+  constexpr int kIdxAhead = kTriIdxAhead;  // vertex / micro index loads
   constexpr int kRecAhead = kIdxAhead + 1;      // scalar: Meshlet record
   constexpr int kRowAhead = kIdxAhead + 2;      // scalar: LOD pointers out of the InstCache row
   typedef const uint32_t __attribute__((address_space(4))) * k32;
   __shared__ uint32_t s_red[4];
-  constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
+  constexpr bool kLdsVerts = WIDE;
   __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];  // per wave: the transformed vertices of the slot in hand (same-wave LDS traffic is in order)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t V = a.tri_cmd[0];
@@ -1572,9 +1559,6 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 // launch of configs[2] is 2 524 spans on 2 048 resident blocks: with whole spans only, 476 blocks run a second span on a nearly empty
 // machine.  Measured on the configs[2] frame (tools/kbench.py, profiles/r05_ab): fused kernels 98.5 / 205.6 -> 97.1 / 200.5 us, frame
 // 511 -> 505 us with the emit launches in front; dynamic at span granularity gave half of it, a whole dynamic round more was worse.
-#ifndef OXC_FUSED_DYNAMIC
-#define OXC_FUSED_DYNAMIC 1  // 0: every span by block index (round 4)
-#endif
 constexpr uint32_t kTriTicketCounters = 16;  // (4 / 16 / 64 counters: the same frame time)
 template <bool LATE, bool WIDE, bool SMALL, bool PAIR = false>
 OXC_DEV void tris_fused_body(const TriTestArgs& a) {
@@ -1582,8 +1566,8 @@ OXC_DEV void tris_fused_body(const TriTestArgs& a) {
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
   constexpr int S = 16;  // slots per wave per chunk
-  constexpr int kPosAhead = WIDE ? OXC_TRI_WIDE_POS_AHEAD : OXC_TRI_POS_AHEAD;
-  constexpr int kIdxAhead = WIDE ? OXC_TRI_WIDE_IDX_AHEAD : OXC_TRI_IDX_AHEAD;
+  constexpr int kPosAhead = kTriPosAhead;
+  constexpr int kIdxAhead = kTriIdxAhead;
   constexpr int kRecAhead = kIdxAhead + 1;
   constexpr int kRowAhead = kIdxAhead + 2;
   typedef const uint32_t __attribute__((address_space(4))) * k32;
@@ -1592,8 +1576,8 @@ OXC_DEV void tris_fused_body(const TriTestArgs& a) {
   constexpr uint32_t kChunksPerSpan = kFSpan / kTriChunk;
   static_assert(kFSpan == 64 || kFSpan == 128 || kFSpan == 256, "one slot per thread of the block at most, whole chunks");
   constexpr uint32_t kCornerBits = WIDE ? 9u : 8u;           // MESHLET_PRIMITIVE_BITS = 8 in the reference (visbuffer.slang:13)
-  constexpr bool kLdsVerts = (OXC_TRI_LDS_VERTS == 2 || (OXC_TRI_LDS_VERTS == 1 && WIDE));
-  constexpr bool kDynamic = OXC_FUSED_DYNAMIC != 0 && kChunksPerSpan > 1u;
+  constexpr bool kLdsVerts = WIDE;
+  constexpr bool kDynamic = kChunksPerSpan > 1u;  // (round 4: every span by block index)
   __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];
   __shared__ uint32_t f_off[kFSpan];
   __shared__ uint64_t f_mask[kFSpan * H];
@@ -1773,9 +1757,6 @@ OXC_DEV float hiz_point_sample(const float* __restrict__ depth, uint32_t dw, uin
   return depth[(size_t)sy * dw + sx];  // (`nt` LOADS here are slower: 80 -> 84 us in round 1, 46 -> 71 us with the nt stores of round 4)
 }
 
-#ifndef OXC_HIZ_NT_STORE
-#define OXC_HIZ_NT_STORE 1
-#endif
 __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
   __shared__ float s_a[16 * 16];
   __shared__ float s_b[8 * 8];
@@ -1795,13 +1776,10 @@ __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
     // `nt`: mip 0 is 3/4 of the pyramid (64 MB at 4096^2) and nothing reads it back soon -- the meshlet tests sample a few texels of
     // it per candidate.  Written with the default policy its lines sat in L2 / the Infinity Cache and their write-back was paid by
     // the kernels that followed (configs[2] frame, us: k_hiz_tile 74.6 -> 62.3, triangle tests 80.7 / 160.2 -> 79.1 / 153.2, frame
-    // 565 -> 544; byte-identical).  OXC_HIZ_NT_STORE: 0 = none, 1 = mip 0, 2 = mips 0 and 1.
+    // 565 -> 544; byte-identical).  Kept: nt for mip 0 only (nt for mip 1 too measured no better).
     {
       typedef float f4v __attribute__((ext_vector_type(4)));
-      if (OXC_HIZ_NT_STORE >= 1)
-        __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(mip0 + (size_t)(y0 + r) * W + x0));
-      else
-        *reinterpret_cast<float4*>(mip0 + (size_t)(y0 + r) * W + x0) = v;
+      __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(mip0 + (size_t)(y0 + r) * W + x0));
     }
   }
   if (a.levels <= 1) return;
@@ -1817,11 +1795,7 @@ __global__ __launch_bounds__(256) void k_hiz_tile(HizArgs a) {
     const uint32_t w1 = W >> 1;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      typedef float f2v __attribute__((ext_vector_type(2)));
-      if (OXC_HIZ_NT_STORE >= 2)
-        __builtin_nontemporal_store(f2v{q[r][0], q[r][1]}, reinterpret_cast<f2v*>(mip1 + (size_t)((y0 >> 1) + r) * w1 + (x0 >> 1)));
-      else
-        *reinterpret_cast<float2*>(mip1 + (size_t)((y0 >> 1) + r) * w1 + (x0 >> 1)) = make_float2(q[r][0], q[r][1]);
+      *reinterpret_cast<float2*>(mip1 + (size_t)((y0 >> 1) + r) * w1 + (x0 >> 1)) = make_float2(q[r][0], q[r][1]);
     }
   }
   if (a.levels <= 2) return;
@@ -1983,13 +1957,7 @@ __global__ __launch_bounds__(1024 / G, (HIZ && (OCCL || LATE)) ? 5 : 1) void k_c
 __global__ __launch_bounds__(64 * kUnordBlockWaves) void k_cull_meshlets_test_unordered(MeshletTestArgs a) { meshlets_plain_body<(int)kGroupsPerWave, true, kUnordBlockWaves>(a); }
 // the two calls of a frame sharing the frustum test (MeshletTestArgs::share)
 template <bool LATE>
-#ifndef OXC_SHARED_LATE_WAVES
-#define OXC_SHARED_LATE_WAVES 5
-#endif
-#ifndef OXC_SHARED_EARLY_WAVES
-#define OXC_SHARED_EARLY_WAVES 5
-#endif
-__global__ __launch_bounds__(1024 / kHizGroupsPerWave, LATE ? OXC_SHARED_LATE_WAVES : OXC_SHARED_EARLY_WAVES) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
+__global__ __launch_bounds__(1024 / kHizGroupsPerWave, 5) void k_cull_meshlets_test_shared(MeshletTestArgs a) {
   // (Round 4 built the form in which a wave takes several consecutive steps and fills its 64-lane occlusion batches ACROSS them -- a tagged
   // per-wave LDS queue, results as cleared bits in per-(step, group) words, steps finished from those words after the last flush; byte-
   // identical on the share / fuzz / full-size tests -- and measured it: 135 / 124 us (2 steps per item, 5 waves per SIMD, 30 VGPRs
@@ -2007,14 +1975,10 @@ template <bool HIZ, bool LATE>
 __global__ __launch_bounds__(256) void k_cull_meshlets_emit(MeshletEmitArgs a) {
   meshlets_emit_body<HIZ, LATE>(a);
 }
-#ifndef OXC_TRI_WAVES
-#define OXC_TRI_WAVES 8
-#endif
-#ifndef OXC_TRI_WIDE_WAVES
-#define OXC_TRI_WIDE_WAVES 4  // (waves per SIMD of the WIDE instantiations: at 6 the 80-VGPR budget spills 25-36 VGPRs to scratch -- 113 / 234 us per launch on the 8 M x 124-triangle frame; 5: 99 / 211; 4: 90 / 185; 3: the same)
-#endif
+constexpr int kTriWaves = 8;
+constexpr int kTriWideWaves = 4;  // (waves per SIMD of the WIDE instantiations: at 6 the 80-VGPR budget spills 25-36 VGPRs to scratch -- 113 / 234 us per launch on the 8 M x 124-triangle frame; 5: 99 / 211; 4: 90 / 185; 3: the same)
 template <bool LATE, bool WIDE, bool SMALL>
-__global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_test(TriTestArgs a) {
+__global__ __launch_bounds__(256, WIDE ? kTriWideWaves : (SMALL ? 6 : kTriWaves)) void k_cull_triangles_test(TriTestArgs a) {
   tris_test_body<LATE, WIDE, SMALL>(a);
 }
 template <bool LATE, bool WIDE>
@@ -2022,12 +1986,12 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit(TriEmitArgs a) {
   tris_emit_body<LATE, WIDE>(a);
 }
 template <bool LATE, bool WIDE, bool SMALL>
-__global__ __launch_bounds__(256, WIDE ? OXC_TRI_WIDE_WAVES : (SMALL ? 6 : OXC_TRI_WAVES)) void k_cull_triangles_fused(TriTestArgs a) {
+__global__ __launch_bounds__(256, WIDE ? kTriWideWaves : (SMALL ? 6 : kTriWaves)) void k_cull_triangles_fused(TriTestArgs a) {
   tris_fused_body<LATE, WIDE, SMALL>(a);
 }
 // wide_triangle_index = 2: the WIDE instantiations writing {id, corner} pairs (kernels of their own name: the profiles key on the names above)
 template <bool LATE, bool SMALL>
-__global__ __launch_bounds__(256, OXC_TRI_WIDE_WAVES) void k_cull_triangles_fused_pairs(TriTestArgs a) {
+__global__ __launch_bounds__(256, kTriWideWaves) void k_cull_triangles_fused_pairs(TriTestArgs a) {
   tris_fused_body<LATE, true, SMALL, true>(a);
 }
 template <bool LATE>
@@ -2195,10 +2159,7 @@ __global__ __launch_bounds__(256) void k_mv_steps(MvArgs a) {
 // transform) is then evaluated once per meshlet and kept as a 64-bit lane mask per 64-meshlet group; otherwise once per view.
 template <bool SAME_POS>
 // (waves per SIMD, same camera position, 10 M meshlets x 16 views: 6 -> 141 us, 7 -> 138, 8 -> 130)
-#ifndef OXC_MV_WAVES
-#define OXC_MV_WAVES 6
-#endif
-__global__ __launch_bounds__(256, SAME_POS ? OXC_MV_WAVES : 4) void k_mv_test(MvArgs a) {
+__global__ __launch_bounds__(256, SAME_POS ? 6 : 4) void k_mv_test(MvArgs a) {
   set_half_denorm_flush();
   constexpr int G = 4;
   const int lane = threadIdx.x & 63;

@@ -87,37 +87,19 @@ enum : uint32_t {
 
 // Work decomposition constants (see DESIGN.md "ordered compaction").
 constexpr uint32_t kGroupsPerWave = 4;       // 64-meshlet groups each wave keeps in flight per block iteration
-#ifndef OXC_PLAIN_G
-#define OXC_PLAIN_G 4
-#endif
-constexpr uint32_t kPlainGroups = OXC_PLAIN_G;  // groups per wave of the plain (non-HiZ) test kernel; block = 16 / kPlainGroups waves
-#ifndef OXC_HIZ_G
-#define OXC_HIZ_G 4
-#endif
-constexpr uint32_t kHizGroupsPerWave = OXC_HIZ_G;  // groups per wave of the HiZ test kernels
-#ifndef OXC_PLAIN_BLOCK_WAVES
-#define OXC_PLAIN_BLOCK_WAVES 4
-#endif
-constexpr uint32_t kPlainBlockWaves = OXC_PLAIN_BLOCK_WAVES;  // the plain test kernel's waves are independent: block size is a scheduling knob
-#ifndef OXC_UNORD_BLOCK_WAVES
-#define OXC_UNORD_BLOCK_WAVES 4
-#endif
+constexpr uint32_t kPlainGroups = 4;  // groups per wave of the plain (non-HiZ) test kernel; block = 16 / kPlainGroups waves
+constexpr uint32_t kHizGroupsPerWave = 4;  // groups per wave of the HiZ test kernels
+constexpr uint32_t kPlainBlockWaves = 4;  // the plain test kernel's waves are independent: block size is a scheduling knob
 // The appending plain test (unordered_output) spends ONE returning atomic on cull_triangles_cmd.x per block iteration: the block size is how
 // many meshlets share an atomic (64 * G per wave).  Measured on configs[1] as one call (1 M meshlets, 977 block atomics at 4 waves):
 // 17.9 us per call at 4 waves, 17.5 at 8, 17.8 at 16 -- the counter is not what the call waits for (its two launches' ramp and drain are).
-constexpr uint32_t kUnordBlockWaves = OXC_UNORD_BLOCK_WAVES;
+constexpr uint32_t kUnordBlockWaves = 4;
 constexpr uint32_t kMeshletChunk = 256 * kGroupsPerWave;  // meshlets per block iteration of the test kernel
 constexpr uint32_t kMeshletSpan = 4096;      // meshlets per block iteration of the emit kernel (8 chunks)
 constexpr uint32_t kTriChunk = 64;           // visible meshlets per block iteration of the triangle test kernel
 constexpr uint32_t kTriSpan = 256;           // visible meshlets per block iteration of the triangle emit kernel
-#ifndef OXC_FUSED_SPAN
-#define OXC_FUSED_SPAN 128  // (configs[2] frame with unordered_output = 1, us: 256 -> 573, 128 -> 562, 64 -> 562)
-#endif
-constexpr uint32_t kFusedTriSpan = OXC_FUSED_SPAN;  // ... and of the fused (unordered_output) kernel: visible meshlets per atomic_add on index_count
-#ifndef OXC_HIZ_LDS_TEXELS
-#define OXC_HIZ_LDS_TEXELS 384
-#endif
-constexpr uint32_t kHizLdsTexels = OXC_HIZ_LDS_TEXELS;      // LDS budget (floats) for the staged top HiZ mips: the 16x16 level and everything above it (round 2: staging the 64x64 level too -- 22 KB per block -- measured 4 % slower: 93 / 121 us against 89 / 116)
+constexpr uint32_t kFusedTriSpan = 128;      // ... and of the fused (unordered_output) kernel: visible meshlets per atomic_add on index_count (configs[2] frame, us: 256 -> 573, 128 -> 562, 64 -> 562)
+constexpr uint32_t kHizLdsTexels = 384;      // LDS budget (floats) for the staged top HiZ mips: the 16x16 level and everything above it (round 2: staging the 64x64 level too -- 22 KB per block -- measured 4 % slower: 93 / 121 us against 89 / 116)
 constexpr uint32_t kSuperStride = 64;         // words between super-chunk accumulators: one per 256 B so their atomics do not serialise on a cache line
 constexpr uint32_t kTicketCounters = 256;    // dynamic work counters of the HiZ meshlet test: counter x hands out the wave steps congruent to x mod 256
 constexpr uint32_t kChunksPerSuper = 64;     // chunk counts are also accumulated per 64 chunks
