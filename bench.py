@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-scheduling-ab", action="store_true", help="config3: skip the short timed runs of the other schedulings (profiling runs: their concurrent kernels would "
                                                                     "be averaged into the per-kernel durations of a kernel trace)")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the short timed run with the other --hiz-exchange form")
+    ap.add_argument("--no-native-comm-ab", action="store_true", help="N > 1: skip the short timed run with the exchanges through the OTHER RCCL path (the C ABI's own entry points "
+                                                                     "when the main line uses torch.distributed, and the reverse)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: build + broadcast the pyramid on the cull stream instead of one frame ahead on a second stream")
     ap.add_argument("--hiz-exchange", default="top", choices=["whole", "top"],
@@ -169,12 +171,39 @@ def setup(args) -> Env:
         e.dist = dist
     e.r = RendererInstance(e.local_rank)
     e.stream = torch.cuda.Stream(device=e.dev)
+    # The product's own RCCL entry points (oxc_comm_*, oxc_exchange_counts, oxc_broadcast_hiz[_levels]): their communicators are set up at every
+    # N > 1 run on real GPUs -- the main line takes them with --native-comm, and otherwise a short nested run (native_comm_ab) does, so that
+    # the first multi-GPU run exercises them either way.  The rendezvous (the 128-byte id) travels through torch.distributed.
     e.native_comm = bool(args.native_comm and e.dist is not None)
-    if e.native_comm:
-        box = [e.r.comm_unique_id() if e.rank == 0 else None]
-        e.dist.broadcast_object_list(box, src=0)
-        e.r.comm_init(box[0], e.rank, e.world)
+    e.native_ready, e.native_error = False, None
+    if e.dist is not None and not e.debug_backend:
+        e.native_ready, e.native_error = native_comm_init(e, e.r)
+        if e.native_comm and not e.native_ready:
+            raise SystemExit(f"bench.py: --native-comm but the communicator could not be set up: {e.native_error}")
+    elif e.dist is not None:
+        e.native_error = f"debug backend {e.debug_backend}: every rank is on the same GPU, RCCL needs one device per rank"
     return e
+
+
+def native_comm_init(e, renderer):
+    """oxc_comm_unique_id on rank 0 -> every rank -> oxc_comm_init; (ok on EVERY rank, first error)."""
+    err = None
+    try:
+        box = [renderer.comm_unique_id() if e.rank == 0 else None]
+    except Exception as ex:  # noqa: BLE001  (librccl could not be loaded, ...)
+        box, err = [None], f"rank 0: {ex}"
+    e.dist.broadcast_object_list(box, src=0)
+    if box[0] is not None:
+        try:
+            renderer.comm_init(box[0], e.rank, e.world)
+        except Exception as ex:  # noqa: BLE001
+            err = f"rank {e.rank}: {ex}"
+    else:
+        err = err or "rank 0 could not create the id"
+    errs = [None] * e.world
+    e.dist.all_gather_object(errs, err)
+    bad = [x for x in errs if x]
+    return (not bad), (bad[0][:200] if bad else None)
 
 
 def barrier(e):
@@ -445,10 +474,10 @@ def bench_config3(args, e):
     use_overlap = [world > 1 and not args.no_overlap]
     overlap = use_overlap[0]
     r_hiz = RendererInstance(e.local_rank)  # its own context: the producer runs beside the cull (one context = one ordered queue)
-    if e.native_comm:  # ... and its own communicator: the broadcast must not queue behind the cull context's calls
-        box = [r_hiz.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        r_hiz.comm_init(box[0], rank, world)
+    native_ready, native_error = e.native_ready, e.native_error
+    if native_ready:  # ... and its own communicator: the broadcast must not queue behind the cull context's calls
+        native_ready, native_error = native_comm_init(e, r_hiz)
+    use_native = [bool(e.native_comm and native_ready)]  # (mutable: native_comm_ab times the other path)
     comm_stream = torch.cuda.Stream(device=dev)
     ev_ready = [torch.cuda.Event() for _ in hiz]
     ev_free = [torch.cuda.Event() for _ in hiz]
@@ -469,8 +498,8 @@ def bench_config3(args, e):
             if st != L.OXC_OK:
                 raise RuntimeError(rr._lib.oxc_last_error(rr._ctx).decode())
         if dist is not None:
-            if e.native_comm:
-                r_hiz.broadcast_hiz(hiz[b], 0, st_, first_level=k_top if top else 0)
+            if use_native[0]:
+                (r_hiz if ahead else r).broadcast_hiz(hiz[b], 0, st_, first_level=k_top if top else 0)
             else:
                 with torch.cuda.stream(st_):
                     dist.broadcast(hiz[b].data[hiz[b].level_offset[k_top] // 4:] if top else hiz[b].data, src=0)
@@ -479,7 +508,7 @@ def bench_config3(args, e):
         # {emitted, early, late, index_count} of this rank's last call -> every rank (north star's all-gather); packed on the
         # device out of the call's counter slot, no host round trip
         check(lib.oxc_pack_counters(ctxp, C.byref(c), C.c_void_p(my_counts.data_ptr()), sp))
-        if e.native_comm:
+        if use_native[0]:
             check(lib.oxc_exchange_counts(ctxp, C.c_void_p(my_counts.data_ptr()), C.c_void_p(gathered.data_ptr()), sp))
         elif e.debug_backend:  # gloo has no device all-gather: stage through the host (debug aid only)
             host = torch.zeros(world * 4, dtype=torch.int32)
@@ -617,11 +646,12 @@ def bench_config3(args, e):
     ramp_clocks(e)
     elapsed = timed_steps(e, run_step, args.steps, args.warmup)
     per_rank_ms_per_frame = [round(t * 1e3 / (args.steps * inner), 6) for t in PER_RANK_SECONDS]
-    per_rank_visible = None
+    per_rank_visible, ranks_seen = None, None
     if world > 1:  # the all-gathered counters of the last frame: {emitted by the late call, early, late, index_count} per rank
         torch.cuda.synchronize()
         gcpu = gathered.cpu().view(world, 4)
         per_rank_visible = [int(gcpu[k, 1] + gcpu[k, 2]) for k in range(world)]
+        ranks_seen = int((gcpu.to(torch.int64).abs().sum(1) > 0).sum().item())  # rows of the gathered counters some rank has filled in
     frames = args.steps * inner
     ms_per_frame = elapsed * 1e3 / frames
     value = world_meshlets * frames / elapsed
@@ -965,7 +995,7 @@ def bench_config3(args, e):
             "index_form": ("pairs {u32 id, u32 corner}, 24 B per triangle (wide_triangle_index = 2)" if pairs else "(id << 9) | corner (wide_triangle_index = 1)" if wide else "(id << 8) | corner (visbuffer.slang:9-14)"),
             "inner_reps": inner, "frames_timed": frames, "ms_per_frame": round(ms_per_frame, 6), "small_triangle_cull": bool(args.small_triangle_cull),
             "visible_fraction": round((v_early + v_late) / n_meshlets, 4), "triangles_per_visible_meshlet": round((t_early + t_late) / max(1, v_early + v_late), 2),
-            "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if e.native_comm else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
+            "sharding": "single GPU" if world == 1 else {"ranks": world, "rccl_ranks": 0 if e.debug_backend else world, "rccl_ranks_seen": 0 if e.debug_backend else ranks_seen, "debug_backend_not_a_measurement": e.debug_backend or None, "backend": "oxc_comm_* (RCCL via the C ABI)" if use_native[0] else (f"torch.distributed {e.debug_backend} (debug)" if e.debug_backend else "torch.distributed nccl (RCCL)"),
                                                          "hiz_exchange": (f"levels >= {k_top} broadcast, lower levels built by every rank from its own depth copy" if xmode["top"] else "whole pyramid broadcast from rank 0"),
                                                          "hiz_broadcast_bytes_per_frame": hiz_wire_bytes, "hiz_one_frame_ahead_on_second_stream": use_overlap[0],
                                                          "counters_all_gather_bytes_per_rank": 16, "per_rank_ms_per_frame": per_rank_ms_per_frame,
@@ -977,6 +1007,54 @@ def bench_config3(args, e):
         "unpinned_gap": unpinned, "counts": counts, "kernels": kernels, "stage": stage, "roofline": roofline, "cpu_baseline": cpu_baseline,
         "scheduling_ab": sched_ab,
     }
+    # ---- N > 1: the same frames with BOTH exchanges through the other RCCL path -- the C ABI's own entry points (oxc_exchange_counts,
+    # oxc_broadcast_hiz[_levels]: SURVEY 8b lists them in the boundary) when the main line ran on torch.distributed, and the reverse with
+    # --native-comm -- a short run, outputs check-summed against the main line.  These entry points had never run with more than one rank
+    # when this was written (one-GPU builder box): every failure is caught and reported, and a hang is cut off by a watchdog that prints the
+    # main line as it stands and ends the process, so the run keeps its headline whatever the exchange does.
+    if world > 1 and not getattr(args, "no_native_comm_ab", False):
+        if not native_ready:
+            line["native_comm_ab"] = {"skipped": native_error or "the communicators could not be set up"}
+        else:
+            import threading
+
+            done = threading.Event()
+
+            def watchdog():
+                if done.wait(float(os.environ.get("OXC_BENCH_NATIVE_AB_TIMEOUT", "120"))):
+                    return
+                if rank == 0:
+                    line["native_comm_ab"] = {"timed_out_s": float(os.environ.get("OXC_BENCH_NATIVE_AB_TIMEOUT", "120")), "note": "the run with the other exchange path did not finish: "
+                                              "the process was ended by the watchdog after printing the main line"}
+                    line["summary"] = line_summary(line)
+                    emit(line)
+                sys.stdout.flush()
+                os._exit(0 if rank == 0 else 3)
+
+            threading.Thread(target=watchdog, daemon=True).start()
+            main_native = use_native[0]
+            res_n = {"path": "torch.distributed nccl (RCCL)" if main_native else "oxc_comm_* (RCCL via the C ABI: oxc_exchange_counts, oxc_broadcast_hiz" + ("_levels)" if xmode["top"] else ")")}
+            try:
+                use_native[0] = not main_native
+                gathered.zero_()
+                el_n = timed_steps(e, run_step, ab_steps, 1)
+                sum_n = outputs_checksum()
+                g2 = gathered.cpu().view(world, 4)
+                res_n.update({"ms_per_frame": round(el_n * 1e3 / (ab_steps * inner), 6), "value": round(world_meshlets * ab_steps * inner / el_n, 1), "frames_timed": ab_steps * inner,
+                              "outputs_match_main_line": sum_n == sum_main, "rccl_ranks_seen": int((g2.to(torch.int64).abs().sum(1) > 0).sum().item()),
+                              "per_rank_visible": [int(g2[k, 1] + g2[k, 2]) for k in range(world)], "main_line_ms_per_frame": round(ms_per_frame, 6)})
+            except Exception as ex:  # noqa: BLE001  (OXC_RCCL_ERROR, ...; the other ranks then sit in a collective until the watchdog ends them)
+                res_n["error"] = str(ex)[:300]
+            use_native[0] = main_native
+            errs = [None] * world
+            dist.all_gather_object(errs, res_n.get("error"))
+            if any(errs):
+                res_n["error"] = next(x for x in errs if x)
+            done.set()
+            line["native_comm_ab"] = res_n
+            with torch.cuda.stream(stream):
+                run_frame()
+            torch.cuda.synchronize()
     # free the 25 GB of this workload before the nested one
     r_hiz.close()
     del scene, frame, depth, hiz, mask0
@@ -1266,6 +1344,10 @@ def line_summary(line: dict) -> dict:
     if isinstance(sh, dict):  # N > 1
         sm["sharding"] = {"assignment": g(sh, "scene", "assignment") or "an independent scene per rank", "per_rank_visible": sh.get("per_rank_visible"),
                           "per_rank_ms_per_frame": sh.get("per_rank_ms_per_frame")}
+        sm["sharding"]["rccl_ranks_seen"] = sh.get("rccl_ranks_seen")
+        if "native_comm_ab" in line:
+            nb = line["native_comm_ab"]
+            sm["native_comm_ab"] = {k: (nb[k][:160] if isinstance(nb[k], str) else nb[k]) for k in ("path", "ms_per_frame", "outputs_match_main_line", "rccl_ranks_seen", "error", "skipped", "timed_out_s") if k in nb}
         if "assignment_ab" in line:
             ab = line["assignment_ab"]
             sm["sharding"]["other_assignment"] = {k: ab[k] for k in ("assignment", "value", "ms_per_frame", "per_rank_visible")}
@@ -1335,7 +1417,7 @@ def main():
             a3 = copy.copy(args)
             a3.shard_block = 0 if args.shard_block > 0 else 64
             a3.steps, a3.warmup = max(2, args.steps // 4), 1
-            a3.no_scheduling_ab, a3.no_cpu_baseline, a3.no_exchange_ab, a3.cpu_prefix = True, True, True, min(args.cpu_prefix, 100)
+            a3.no_scheduling_ab, a3.no_cpu_baseline, a3.no_exchange_ab, a3.no_native_comm_ab, a3.cpu_prefix = True, True, True, True, min(args.cpu_prefix, 100)
             stage_note("assignment_ab")
             t = bench_config3(a3, e)
             if e.rank == 0:
