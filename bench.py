@@ -1370,7 +1370,9 @@ def line_summary(line: dict) -> dict:
         sm["configs0"] = {"entities_per_s": g(line, "configs0", "value"), "cores": g(line, "configs0", "config", "threads"), "one_core": g(line, "configs0", "single_thread_value"),
                           "ms_per_update_one_thread": g(line, "configs0", "ms_per_update_one_thread")}
     if "real_geometry" in line:
-        sm["real_geometry"] = {"ms_per_frame": g(line, "real_geometry", "ms_per_frame", nd=4), "bit_match": g(line, "real_geometry", "bit_match")}
+        sm["real_geometry"] = {"ms_per_frame": g(line, "real_geometry", "ms_per_frame", nd=4), "bit_match": g(line, "real_geometry", "bit_match"),
+                               "visible_fraction": g(line, "real_geometry", "visible_fraction"), "tri_kernel_frac_requested_bytes": g(line, "real_geometry", "roofline", "frac"),
+                               "tri_kernel_us": g(line, "real_geometry", "roofline", "kernel_avg_us"), "traffic": g(line, "real_geometry", "roofline", "traffic")}
     return sm
 
 

@@ -683,6 +683,37 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
     kernels = {k: round(v["total_ms"] / v["launches"] * 1e3, 2) for k, v in prof["kernels"].items()}
     v_e, v_l = snap["early"]["emitted"], snap["late"]["emitted"]
     t_e, t_l = snap["early"]["index_count"] // 3, snap["late"]["index_count"] // 3
+    # ---- the dominant kernel of THIS workload (round-5 review item 7): the triangle kernel, early + late launch averaged, priced as on the main line --
+    # SURVEY 8d's 988 B per visible meshlet (V = 64, T = 64: what the kernel REQUESTS) + 12 B per emitted triangle -- although here almost none of the
+    # read side comes from HBM: the three meshes' geometry (a few MB) lives in L2 / the Infinity Cache, so `achieved` is a rate of REQUESTED bytes,
+    # it can exceed what HBM could deliver, and FETCH_SIZE (counted at the L2 -> fabric boundary) under-reads it.  What bounds the kernel is stated
+    # from the counters of tools/pmc_real_geometry.sh (profiles/r06_real_geometry_pmc.json when committed, else round 3's diagnosis).
+    roofline = None
+    tk = [k for k in ("cull_triangles_test", "cull_triangles_test_late") if k in prof["kernels"]]
+    if len(tk) == 2:
+        us = sum(prof["kernels"][k]["total_ms"] for k in tk) / sum(prof["kernels"][k]["launches"] for k in tk) * 1e3
+        alg_b = ((v_e + v_l) * 988.0 + 12.0 * (t_e + t_l)) / 2.0
+        hbm_b = (12.0 * (t_e + t_l) + (v_e + v_l) * (4.0 + 8.0)) / 2.0  # what MUST cross HBM: the index list written + visible id and MeshletInstance record read
+        achieved = alg_b / (us * 1e-6) / 1e9
+        traffic, src = None, None
+        for tag in ("r06", "r05"):
+            try:
+                with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_real_geometry_pmc.json")) as f:
+                    pm = json.load(f)
+                vals = [cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0) for kk, cs in pm.get("pmc", {}).items() if "k_cull_triangles_fused" in kk and "hbm_read_bytes_corrected" in cs]
+                if vals:
+                    traffic, src = round(sum(vals) / len(vals)), f"profiles/{tag}_real_geometry_pmc.json"
+                    break
+            except (OSError, ValueError):
+                continue
+        roofline = {"bound": "hbm", "kernel": "k_cull_triangles_fused (early + late launch averaged) over INSTANCED geometry", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes_per_launch": round(alg_b), "hbm_bytes_needed_per_launch": round(hbm_b), "kernel_avg_us": round(us, 2),
+                    "us_per_1000_visible_meshlets": round(us * 2.0 / max(1, v_e + v_l) * 1e3, 4),
+                    "note": "requested bytes, not HBM bytes: the geometry is cache-resident (3 meshes), so frac says how the kernel's per-meshlet rate compares with the "
+                            "unique-geometry frame, not how close HBM is to its peak; the HBM side of this kernel is hbm_bytes_needed_per_launch (index list out, ids + MeshletInstance in).  "
+                            "Bound (counters, tools/pmc_real_geometry.sh): VALU issue ~45-55 % busy + the dependent fetch chain per slot (TA waiting on the L1 for the position gather, "
+                            "6-7 lines per meshlet after the vertex remap) -- not memory bandwidth"}
 
     # ---- the checker over a prefix of the same arrays (the scene minus most of its instances): parity + the unpinned gap ----
     bit_match, unpinned = None, None
@@ -747,7 +778,7 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
            "share_pass_tests": True, "unordered_output": unord,
            "value": round(N / (ms_per_frame * 1e-3), 1), "unit": "meshlets/s", "frames_timed": frames,
            "visible_fraction": round((v_e + v_l) / N, 4), "triangles_per_visible_meshlet": round((t_e + t_l) / max(1, v_e + v_l), 2),
-           "counts": {"early": v_e, "late": v_l, "early_triangles": t_e, "late_triangles": t_l}, "kernels_avg_us": kernels, "bit_match": bit_match, "unpinned_gap": unpinned}
+           "counts": {"early": v_e, "late": v_l, "early_triangles": t_e, "late_triangles": t_l}, "kernels_avg_us": kernels, "roofline": roofline, "bit_match": bit_match, "unpinned_gap": unpinned}
     del scene, frame, depth, hiz, mask0
     torch.cuda.empty_cache()
     return res
