@@ -41,18 +41,19 @@ python tools/summarize_profiles.py ${TAG}_config5_pmc --stats $(find gpurun_out/
   --note "bench.py --workload config5 (configs[4]: 10M meshlets x 16 cascade views, explicit MeshletInstance lists written on the side stream); rocprofv3 --kernel-trace --stats + separate --pmc passes; raw CSVs: profiles/raw/${TAG}_config5_*.csv.gz"
 keep_raw config5 gpurun_out/raw/trace_c5 gpurun_out/raw/pmc_c5
 ./tools/profile_trace.sh gpurun_out/raw/trace_t124 --tris 124 --steps 3 --warmup 1 > /dev/null
-# (round 5: the WIDE kernels get their HBM counters too -- FETCH_SIZE / WRITE_SIZE passes only)
+# (round 5: the WIDE kernels get their HBM counters too -- FETCH_SIZE / WRITE_SIZE passes only; round 6: the pair form at 10 M meshlets)
 mkdir -p gpurun_out/raw/pmc_t124
 ( cd /tmp && export TMPDIR=/tmp OXC_BENCH_FULL=/tmp/pmc_bench_full.json && for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed s/_size//); rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/gpurun_out/raw/pmc_t124/$d" -o p -- python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs4 --no-real-geometry --no-tris124 --no-scheduling-ab --no-configs0 --tris 124 --steps 1 --warmup 1 --inner-reps 8 > /dev/null 2> "$ROOT/gpurun_out/raw/pmc_t124/$d.log"; done )
-python tools/summarize_profiles.py ${TAG}_tris124_pmc --stats $(find gpurun_out/raw/trace_t124 -name t_kernel_stats.csv | head -1) --pmc gpurun_out/raw/pmc_t124 \
-  --note "bench.py --tris 124 (8M meshlets x 124 triangles, wide_triangle_index), --steps 3 --warmup 1 (kernel trace) / --steps 1 --warmup 1 --inner-reps 8 (FETCH_SIZE and WRITE_SIZE passes); rocprofv3 --kernel-trace --stats + separate --pmc passes"
-cp gpurun_out/raw/trace_t124/bench.json gpurun_out/profiles_out/${TAG}_tris124_trace_bench.json
-keep_raw tris124 gpurun_out/raw/trace_t124 gpurun_out/raw/pmc_t124
+python tools/summarize_profiles.py ${TAG}_pairs124_pmc --stats $(find gpurun_out/raw/trace_t124 -name t_kernel_stats.csv | head -1) --pmc gpurun_out/raw/pmc_t124 \
+  --note "bench.py --tris 124 (10M meshlets x 124 triangles, wide_triangle_index = 2: {u32 id, u32 corner} pairs, 24 B per emitted triangle), --steps 3 --warmup 1 (kernel trace) / --steps 1 --warmup 1 --inner-reps 8 (FETCH_SIZE and WRITE_SIZE passes); rocprofv3 --kernel-trace --stats + separate --pmc passes"
+cp gpurun_out/raw/trace_t124/bench.json gpurun_out/profiles_out/${TAG}_pairs124_trace_bench.json
+keep_raw pairs124 gpurun_out/raw/trace_t124 gpurun_out/raw/pmc_t124
 ./tools/profile_trace.sh gpurun_out/raw/trace_vsm --workload vsm > /dev/null
 python tools/summarize_profiles.py ${TAG}_vsm_trace --stats $(find gpurun_out/raw/trace_vsm -name t_kernel_stats.csv | head -1) \
   --note "bench.py --workload vsm (10M meshlets x 10 dirty clipmap views, generate_hpb + cull_meshes + cull_meshlets_hpb); rocprofv3 --kernel-trace --stats"
 keep_raw vsm gpurun_out/raw/trace_vsm /nonexistent
 mv profiles/${TAG}_vsm_trace.json gpurun_out/profiles_out/ 2>/dev/null
-mv profiles/${TAG}_config2_pmc.json profiles/${TAG}_config3_pmc.json profiles/${TAG}_config5_pmc.json profiles/${TAG}_config3_ordered_trace.json profiles/${TAG}_tris124_pmc.json gpurun_out/profiles_out/ 2>/dev/null
+mv profiles/${TAG}_config2_pmc.json profiles/${TAG}_config3_pmc.json profiles/${TAG}_config5_pmc.json profiles/${TAG}_config3_ordered_trace.json profiles/${TAG}_pairs124_pmc.json gpurun_out/profiles_out/ 2>/dev/null
+bash tools/pmc_real_geometry.sh ${TAG} > gpurun_out/profiles_out/${TAG}_real_geometry_probe.txt 2>&1
 rm -rf gpurun_out/raw
 ls -la gpurun_out/profiles_out gpurun_out/profiles_out/raw; du -sh gpurun_out/profiles_out
