@@ -1029,7 +1029,9 @@ def bench_config3(args, e):
                     line["summary"] = line_summary(line)
                     emit(line)
                 sys.stdout.flush()
-                os._exit(0 if rank == 0 else 3)
+                if rank != 0:
+                    time.sleep(5.0)  # rank 0 prints first; a launcher that sees a rank die would take the others down
+                os._exit(0)
 
             threading.Thread(target=watchdog, daemon=True).start()
             main_native = use_native[0]
