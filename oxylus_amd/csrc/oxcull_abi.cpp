@@ -407,6 +407,11 @@ static oxc_status check_call(oxc_ctx* ctx, const oxc_prepared_frame* f, const ox
     const oxc_image_array_u8& h = c->hpb_attachment;
     if (!h.dptr || !h.width || !h.height || h.layers < views || h.levels < 1 || h.levels > 13)
       return fail(ctx, OXC_INVALID_ARG, "cull_geometry: use_hpb without a valid hpb_attachment (layers >= clipmaps, 1..13 levels)");
+    for (uint32_t k = 0; k < h.levels; k++) {  // the page test addresses the pyramid with 32-bit byte offsets (test_vsm_page)
+      const uint64_t mw = std::max(1u, h.width >> k), mh = std::max(1u, h.height >> k);
+      if (h.level_offset[k] + (uint64_t)h.layers * mw * mh > 0xFFFFFFFFull)
+        return fail(ctx, OXC_INVALID_ARG, "cull_geometry: hpb_attachment larger than 4 GiB (the reference's is 64 x 64 pages x 10 clipmaps, Shadowmaps.cpp:84-98)");
+    }
   }
   if (!c->init_cull_meshes && (!c->visibility_buffer.dptr || !c->cull_meshlets_cmd_buffer.dptr))
     return fail(ctx, OXC_INVALID_ARG, "cull_geometry: init_cull_meshes=false needs the visibility/cull_meshlets_cmd buffers of the sequence");

@@ -327,23 +327,42 @@ OXC_DEV uint32_t mip_dim(uint32_t d, uint32_t mip) {
 // likewise -- the same floats as the 24 divisions and 48 min / max of the general path (up to the sign of a zero, which neither
 // q * 0.5 + 0.5 nor the depth comparison sees) for 36 instructions.  Lanes whose sums could leave the finite range (any |P0| + |SX| +
 // |SY| + |SZ| above 2^120, or a NaN) send the wave down the general path.  (tests: test_project_aabb_matches_ieee_division_bit_for_bit)
-template <bool TRY_AFFINE = false>
+// NEED_Z = false (test_vsm_page reads only the four uv bounds, cull.slang:137-166): the orthographic branch leaves the z row out -- neither
+// the uv bounds nor the `none` decision depend on it there (every w is 1; a z sum that leaves the finite range changes out[2] / out[5] only,
+// and a NaN / Inf INPUT coordinate reaches the x and y rows as well, 0 * Inf being NaN, so their finiteness test still sends the wave down
+// the general path).  out[2] / out[5] are then unspecified.  Round 6: 13 of the kernel's ~215 VALU instructions per (batch, view).
+// v_min / v_max against 0 as single instructions (fminf / fmaxf put a canonicalising v_max_f32 x, x in front of each: the operands here are
+// finite by the test above them).
+OXC_DEV float min0_finite(float x) {
+  float r;
+  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+OXC_DEV float max0_finite(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+template <bool TRY_AFFINE = false, bool NEED_Z = true>
 OXC_DEV bool project_aabb(const float* mvp, float near_clip, float cx, float cy, float cz, float ex, float ey, float ez, float* out) {
   float SX[4], SY[4], SZ[4], P[8][4];
   float p0x = cx - ex * 0.5f, p0y = cy - ey * 0.5f, p0z = cz - ez * 0.5f;
   if (TRY_AFFINE && asu(OXC_M(mvp, 3, 0)) == 0u && asu(OXC_M(mvp, 3, 1)) == 0u && asu(OXC_M(mvp, 3, 2)) == 0u &&
       asu(OXC_M(mvp, 3, 3)) == 0x3F800000u) {  // (the matrix is wave-uniform in every caller that sets TRY_AFFINE)
-    float lo[3], hi[3];
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f}, P0[3] = {0.f, 0.f, 0.f}, S[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     bool finite = true;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const float sx = OXC_M(mvp, i, 0) * ex, sy = OXC_M(mvp, i, 1) * ey, sz = OXC_M(mvp, i, 2) * ez;
-      const float p0 = ((OXC_M(mvp, i, 0) * p0x + OXC_M(mvp, i, 1) * p0y) + OXC_M(mvp, i, 2) * p0z) + OXC_M(mvp, i, 3);
-      finite = finite && ((__builtin_fabsf(p0) + __builtin_fabsf(sx)) + (__builtin_fabsf(sy) + __builtin_fabsf(sz))) <= 1.329227995784916e36f;
-      lo[i] = ((p0 + fminf(sx, 0.0f)) + fminf(sy, 0.0f)) + fminf(sz, 0.0f);
-      hi[i] = ((p0 + fmaxf(sx, 0.0f)) + fmaxf(sy, 0.0f)) + fmaxf(sz, 0.0f);
+    for (int i = 0; i < (NEED_Z ? 3 : 2); i++) {
+      S[i][0] = OXC_M(mvp, i, 0) * ex, S[i][1] = OXC_M(mvp, i, 1) * ey, S[i][2] = OXC_M(mvp, i, 2) * ez;
+      P0[i] = ((OXC_M(mvp, i, 0) * p0x + OXC_M(mvp, i, 1) * p0y) + OXC_M(mvp, i, 2) * p0z) + OXC_M(mvp, i, 3);
+      finite = finite && ((__builtin_fabsf(P0[i]) + __builtin_fabsf(S[i][0])) + (__builtin_fabsf(S[i][1]) + __builtin_fabsf(S[i][2]))) <= 1.329227995784916e36f;
     }
     if (__builtin_amdgcn_ballot_w64(!finite) == 0) {
+#pragma unroll
+      for (int i = 0; i < (NEED_Z ? 3 : 2); i++) {  // (every operand is finite here)
+        lo[i] = ((P0[i] + min0_finite(S[i][0])) + min0_finite(S[i][1])) + min0_finite(S[i][2]);
+        hi[i] = ((P0[i] + max0_finite(S[i][0])) + max0_finite(S[i][1])) + max0_finite(S[i][2]);
+      }
       if (1.0f < near_clip) return false;  // every w is 1
       out[0] = lo[0] * 0.5f + 0.5f;
       out[1] = lo[1] * 0.5f + 0.5f;
@@ -527,26 +546,25 @@ OXC_DEV uint32_t ceil_log2f_clamped(float x, uint32_t levels) {
   c = min(c, (int32_t)levels - 1);
   return (uint32_t)c;
 }
-OXC_DEV uint32_t hpb_sample(const HpbView& h, const uint32_t* level_off, float u, float v, uint32_t layer, uint32_t mip) {
-  uint32_t mw = mip_dim(h.width, mip), mh = mip_dim(h.height, mip);
-  int32_t x = cvt_i32_sat(floorf(u * (float)mw)), y = cvt_i32_sat(floorf(v * (float)mh));
-  x = min(max(x, 0), (int32_t)mw - 1);
-  y = min(max(y, 0), (int32_t)mh - 1);
-  return h.data[(size_t)level_off[mip] + (size_t)layer * mw * mh + (size_t)y * mw + (size_t)x];
-}
 OXC_DEV float fract_f(float x) { return x - floorf(x); }
 
-// cull.slang:137-166 test_vsm_page (nearest, clamped SampleLevel at an integral mip).
+// cull.slang:137-166 test_vsm_page (nearest, clamped SampleLevel at an integral mip).  The four taps share the level (its extent, its
+// layer's first byte) and pairwise their column / row; a pyramid is at most 4096^2 x 16 layers with its mips = 358 MB, so byte offsets
+// are 32-bit (oxc_cull_geometry checks that) and a tap's address is one 64-bit add (round 6: the 64-bit multiply-adds per tap were a
+// fifth of the kernel's page-test instructions).
 OXC_DEV bool test_vsm_page(const float* a, const HpbView& h, const uint32_t* level_off, uint32_t layer, int32_t pox_i, int32_t poy_i) {
   float sw = (float)h.width, sh = (float)h.height;
   float pox = (float)pox_i / sw, poy = (float)poy_i / sh;
   float box_w = (a[3] - a[0]) * sw, box_h = (a[4] - a[1]) * sh;
   uint32_t mip = ceil_log2f_clamped(fmaxf(box_w, box_h), h.levels);
-  bool tl = hpb_sample(h, level_off, fract_f(a[0] + pox), fract_f(a[1] + poy), layer, mip) != 0u;
-  bool tr = hpb_sample(h, level_off, fract_f(a[3] + pox), fract_f(a[1] + poy), layer, mip) != 0u;
-  bool bl = hpb_sample(h, level_off, fract_f(a[0] + pox), fract_f(a[4] + poy), layer, mip) != 0u;
-  bool br = hpb_sample(h, level_off, fract_f(a[3] + pox), fract_f(a[4] + poy), layer, mip) != 0u;
-  return tl | tr | bl | br;
+  const uint32_t mw = mip_dim(h.width, mip), mh = mip_dim(h.height, mip);
+  const float fw = (float)mw, fh = (float)mh;
+  auto texel = [](float t, float extent_f, uint32_t extent) { return (uint32_t)min(max(cvt_i32_sat(floorf(t * extent_f)), 0), (int32_t)extent - 1); };
+  const uint32_t x0 = texel(fract_f(a[0] + pox), fw, mw), x1 = texel(fract_f(a[3] + pox), fw, mw);
+  const uint32_t y0 = texel(fract_f(a[1] + poy), fh, mh), y1 = texel(fract_f(a[4] + poy), fh, mh);
+  const uint32_t base = level_off[mip] + layer * mw * mh, r0 = base + y0 * mw, r1 = base + y1 * mw;
+  const uint32_t tl = h.data[r0 + x0], tr = h.data[r0 + x1], bl = h.data[r1 + x0], br = h.data[r1 + x1];
+  return (tl | tr | bl | br) != 0u;
 }
 
 // cull_meshlets_hpb.slang:53-54 + cull.slang:177-179: directional cone test.

@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(256, kHpbWaves) void k_cull_meshlets_hpb_test(HpbTe
             OXC_HPB_DECODE(b);
             float sa[6];
             bool pass = true;  // projection crosses the near plane: visible (cull_meshlets_hpb.slang:70-76)
-            if (project_aabb<true>(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa)) pass = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
+            if (project_aabb<true, false>(vmvp, z_near, cxj, cyj, czj, exj, eyj, ezj, sa)) pass = test_vsm_page(sa, hpb, s_level_off, v, pox, poy);
             const bool hit = act && pass;
             if (hit) seen[at] = 1u;
             open_count -= (uint32_t)__popcll((unsigned long long)__builtin_amdgcn_ballot_w64(hit));
