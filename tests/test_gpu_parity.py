@@ -271,6 +271,59 @@ def test_cull_meshlets_hpb_multi_view(renderer, oracle_lib, density, dirty, m, k
         assert want_vis.numel() > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("huge_view", [None, 3], ids=["odd-boxes", "odd-boxes+a-view-scaled-by-2^101"])
+def test_cull_meshlets_hpb_non_finite_boxes_and_huge_matrices(renderer, oracle_lib, huge_view):
+    """The page test of k_cull_meshlets_hpb_test takes project_aabb's orthographic short cut only while nothing can leave the finite range (a per-lane
+    test; round 6 measured hoisting it -- once per candidate + once per view -- and it was no faster: 318.6 against ~309 us).  Boxes whose centre /
+    extent hold Inf or NaN halves, and a view whose matrix is scaled beyond 2^100, must come out as the checker's plain arithmetic has them (the general path)."""
+    import oracle
+    from oxylus_amd.renderer import CullGeometryContext, HpbAttachment, PreparedFrame
+    from oxylus_amd.synth import pack_clipmaps
+
+    spec = SceneSpec(n_mesh_instances=60, meshlets_per_mesh=90, seed=67, scene_depth=150.0)
+    cpu = make_scene(spec, "cpu")
+    g = torch.Generator().manual_seed(7)
+    r = torch.rand(cpu.bounds.shape[0], generator=g)
+    b = cpu.bounds
+    b[r < 0.02, 0] = 0x7C00                                # centre.x = +Inf
+    b[(r >= 0.02) & (r < 0.04), 5] = 0x7E00                # extent.y = NaN
+    b[(r >= 0.04) & (r < 0.06), 6] = 0x7C00                # extent.z = +Inf
+    b[(r >= 0.06) & (r < 0.08), 2] = torch.tensor(-1024, dtype=torch.int16)  # centre.z = 0xFC00 = -Inf
+    gpu = cpu.to("cuda")
+    light, mats, clip, zn, hpb = _vsm_inputs(67, 0.2)
+    offs = clip.view(torch.int32).view(10, 19)[:, 16:18].numpy().copy()
+    if huge_view is not None:  # (rows x and y scaled: an orthographic matrix stays one, its frustum is what it is; the point is the magnitude)
+        mats = np.array(mats, dtype=np.float32).copy()
+        mats[huge_view, 0::4] *= np.float32(2.0 ** 101)
+        mats[huge_view, 1::4] *= np.float32(2.0 ** 101)
+        clip = pack_clipmaps(mats, offs, zn)
+    dirty_t = torch.ones(10, dtype=torch.int32)
+
+    def camera(scene):
+        cam = scene.cull_camera()
+        for i in range(16):
+            cam.projection_view[i] = float(mats[9][i])
+        for i in range(3):
+            cam.position[i] = float(-light[i])
+        cam.near_clip = zn
+        return cam
+
+    cam = camera(cpu)
+    mli, _ = oracle.cull_meshes(cpu, cam, L.CULL_TEST_FRUSTUM)
+    h = oracle.make_hpb(hpb.data, 64, 64, 10, 7, hpb.level_offset)
+    want_vis = oracle.cull_meshlets_hpb(cpu, cam, mli, clip, dirty_t, h)
+    frame = PreparedFrame.create(gpu, expand=False)
+    renderer.prepared_frame = frame
+    ctx = CullGeometryContext(use_hpb=True, init_cull_meshes=True, cull_flags=L.CULL_TEST_FRUSTUM, cull_camera=camera(gpu), hpb_attachment=HpbAttachment(hpb.data.cuda(), 64, 64, 10, 7, hpb.level_offset),
+                              vsm_clipmaps_buffer=clip.cuda(), vsm_clipmap_dirty_flags_buffer=dirty_t.cuda(), vsm_clipmap_count=10, stages=L.STAGE_MESHES | L.STAGE_MESHLETS)
+    renderer.cull_geometry(ctx)
+    c = renderer.read_counters(ctx)
+    got_vis = frame.visible_meshlet_instances_indices_buffer[: c.cull_triangles_cmd_x].cpu()
+    assert torch.equal(got_vis, want_vis)
+    assert 0 < want_vis.numel() < mli.shape[0]
+
+
 def test_use_hpb_argument_validation(renderer):
     from oxylus_amd.renderer import CullGeometryContext, PreparedFrame
 
