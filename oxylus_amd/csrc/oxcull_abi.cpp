@@ -93,6 +93,7 @@ struct oxc_ctx {
   hipEvent_t fork_event = nullptr;
   hipStream_t mv_side = nullptr;
   hipEvent_t mv_fork = nullptr, mv_join = nullptr;  // multi-view batch: the MeshletInstance expansion on `side` beside the meshlet stage
+  uint32_t mv_expand_after = 1;                      // 1: the side-stream expansion starts behind the meshlet stage's set-up launches (beside the test + emit); 0: behind the scan (round 5)
   uint32_t mv_expand_async = 4;                      // blocks per CU the side-stream expansion takes; oxc_debug_set_tuning(OXC_TUNE_MV_EXPAND_ASYNC, 0): in order on the caller's stream (A/B aid)
   struct TriPending {
     hipEvent_t done = nullptr;
@@ -968,7 +969,32 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t max_grid = ctx->num_cus * 8;
   const bool do_meshes = ci[0].do_meshes, do_meshlets = ci[0].do_meshlets, do_tris = ci[0].do_tris;
-  bool mv_expand_async = false;
+  bool mv_expand_async = false, mv_expand_deferred = false;
+  // The MeshletInstance expansion of a batched call: in order on `s`, or (multi-view, nothing of the call reads the records) on the context's
+  // lowest-priority side stream, forked from `s` where this is called and joined at the end of the call.
+  auto launch_mv_expand = [&](uint32_t count_, uint32_t g_expand_, uint32_t cap_, bool on_side) -> oxc_status {
+    hipStream_t es = s;
+    if (on_side) {
+      if (!ctx->mv_side) {  // its own stream, at the lowest priority: the store stream yields wave slots to the meshlet stage's launches
+        int lo = 0, hi = 0;
+        OXC_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        OXC_HIP(ctx, hipStreamCreateWithPriority(&ctx->mv_side, hipStreamNonBlocking, lo));
+      }
+      if (!ctx->mv_fork) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->mv_fork, hipEventDisableTiming));
+      if (!ctx->mv_join) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->mv_join, hipEventDisableTiming));
+      OXC_HIP(ctx, hipEventRecord(ctx->mv_fork, s));
+      OXC_HIP(ctx, hipStreamWaitEvent(ctx->mv_side, ctx->mv_fork, 0));
+      es = ctx->mv_side;
+    }
+    {
+      KernelTimer t(ctx, OXC_K_MESHES_EXPAND, es);
+      // (beside the meshlet stage the expansion takes mv_expand_async blocks per CU, not every wave slot: the small set-up launches queue behind it otherwise)
+      const uint32_t ecap = on_side ? std::max(1u, ctx->num_cus * ctx->mv_expand_async / count_) : cap_;
+      launch_expand_batch(ctx->batch_dev, count_, std::min(g_expand_, ecap), es);
+    }
+    if (on_side) OXC_HIP(ctx, hipEventRecord(ctx->mv_join, es));
+    return OXC_OK;
+  };
   BatchCore cores[kMaxBatch];
   std::memset(cores, 0, sizeof cores);
   uint32_t g_prep = 1, g_expand = 1, g_test = 1, g_emit = 1, g_ttest = 1, g_temit = 1;
@@ -1070,26 +1096,11 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       // latency-bound set-up launches and the VALU-bound test of the meshlet stage, and is joined at the end of the call (fork / join by
       // events, capturable like async_triangles).  A triangle stage in the call reads the records: in order then.
       mv_expand_async = multiview && do_meshlets && !do_tris && ctx->mv_expand_async != 0;
-      hipStream_t es = s;
-      if (mv_expand_async) {
-        if (!ctx->mv_side) {  // its own stream, at the lowest priority: the store stream yields wave slots to the meshlet stage's launches
-          int lo = 0, hi = 0;
-          OXC_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-          OXC_HIP(ctx, hipStreamCreateWithPriority(&ctx->mv_side, hipStreamNonBlocking, lo));
-        }
-        if (!ctx->mv_fork) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->mv_fork, hipEventDisableTiming));
-        if (!ctx->mv_join) OXC_HIP(ctx, hipEventCreateWithFlags(&ctx->mv_join, hipEventDisableTiming));
-        OXC_HIP(ctx, hipEventRecord(ctx->mv_fork, s));
-        OXC_HIP(ctx, hipStreamWaitEvent(ctx->mv_side, ctx->mv_fork, 0));
-        es = ctx->mv_side;
+      mv_expand_deferred = mv_expand_async && ctx->mv_expand_after != 0;
+      if (!mv_expand_deferred) {
+        oxc_status est = launch_mv_expand(count, g_expand, cap, mv_expand_async);
+        if (est != OXC_OK) return est;
       }
-      {
-        KernelTimer t(ctx, OXC_K_MESHES_EXPAND, es);
-        // (beside the meshlet stage the expansion takes mv_expand_async blocks per CU, not every wave slot: the small set-up launches queue behind it otherwise)
-        const uint32_t ecap = mv_expand_async ? std::max(1u, ctx->num_cus * ctx->mv_expand_async / count) : cap;
-        launch_expand_batch(ctx->batch_dev, count, std::min(g_expand, ecap), es);
-      }
-      if (mv_expand_async) OXC_HIP(ctx, hipEventRecord(ctx->mv_join, es));
     }
   }
   if (do_meshlets && multiview) {
@@ -1172,6 +1183,13 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     {
       KernelTimer t(ctx, OXC_K_MULTIVIEW_SETUP, s);
       launch_mv_setup(ma, blob, std::max(1u, std::min(cdiv(Mv, 16u), max_grid)), s);  // 16 lanes per mesh instance
+    }
+    // Round 6: the record expansion (466 MB of stores per 16 views of a 10 M-meshlet scene) is forked HERE, behind the three small set-up launches,
+    // and runs beside the VALU-bound test and the emit.  Forked behind the scan (round 5) it ran beside the set-up launches, which are chains of
+    // dependent loads and took 78 us next to the store stream against 33 us alone (profiles/r06_config5_pmc.json: k_mv_group 43, k_mv_scan 19, k_mv_steps 16).
+    if (mv_expand_deferred) {
+      oxc_status est = launch_mv_expand(count, g_expand, cap, true);
+      if (est != OXC_OK) return est;
     }
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
@@ -1751,6 +1769,7 @@ oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
       ctx->tri_blocks_per_cu = value;
       return OXC_OK;
     case OXC_TUNE_MV_EXPAND_ASYNC: ctx->mv_expand_async = value; return OXC_OK;
+    case OXC_TUNE_MV_EXPAND_AFTER_SETUP: ctx->mv_expand_after = value; return OXC_OK;
     case OXC_TUNE_RASTER_BIG_CAPACITY:
       if (ctx->raster_scratch) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the raster scratch is allocated by the first oxc_draw_visbuffer; set its capacity before");
       ctx->raster_capacity_request = value;
