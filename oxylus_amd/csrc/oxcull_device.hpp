@@ -537,14 +537,12 @@ struct HpbView {
 
 // ceil(log2(x)) of a float from its bits (exact), clamped to [0, levels-1]; x <= 0 / NaN -> 0.
 OXC_DEV uint32_t ceil_log2f_clamped(float x, uint32_t levels) {
-  if (!(x > 0.0f)) return 0u;
-  uint32_t b = asu(x);
-  uint32_t be = (b >> 23) & 0xFFu;
-  if (be == 0u) return 0u;
-  int32_t c = (int32_t)be - 127 + ((b & 0x7FFFFFu) ? 1 : 0);
-  c = max(c, 0);
-  c = min(c, (int32_t)levels - 1);
-  return (uint32_t)c;
+  // straight-line (round 6: the two early returns were exec-masked branches in the VSM page test): a denormal's exponent field is 0, so its
+  // c is negative and the lower clamp gives the 0 the early return gave; x <= 0 and NaN are the one select at the end
+  const uint32_t b = asu(x);
+  int32_t c = (int32_t)((b >> 23) & 0xFFu) - 127 + ((b & 0x7FFFFFu) ? 1 : 0);
+  c = min(max(c, 0), (int32_t)levels - 1);
+  return (x > 0.0f) ? (uint32_t)c : 0u;
 }
 OXC_DEV float fract_f(float x) { return x - floorf(x); }
 
