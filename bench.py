@@ -1342,6 +1342,13 @@ def line_summary(line: dict) -> dict:
 
     sm = {"ms_per_frame": g(line, "config", "ms_per_frame", nd=4), "stage_frac": g(line, "stage", "stage_frac"), "stage_frac_needed_bytes": g(line, "stage", "stage_frac_needed_bytes"),
           "roofline_frac": g(line, "roofline", "frac"), "bit_match": line.get("bit_match"), "hiz_bit_match": line.get("hiz_bit_match")}
+    # what no oracle can pin (the reference is compiled fast-math): decisions that differ between the canonical checker and its fast-math-envelope build,
+    # on the synthetic soup (whose backface determinants sit close to the 1e-4 threshold: a pessimistic proxy) and on the clusteriser-built real meshes
+    def gap(u):
+        return None if not isinstance(u, dict) else {"meshlets": u.get("visible_meshlets_differ"), "mask_bits": u.get("mask_bits_differ"), "triangles": u.get("triangles_differ"),
+                                                     "of_triangles": u.get("triangles_emitted")}
+    if line.get("unpinned_gap") or g(line, "real_geometry", "unpinned_gap"):
+        sm["unpinned_gap"] = {"synthetic": gap(line.get("unpinned_gap")), "real_geometry": gap(g(line, "real_geometry", "unpinned_gap"))}
     kn = line.get("kernels") or {}
     sm["kernel_us"] = {k: round(v["avg_us"], 1) for k, v in kn.items() if isinstance(v, dict) and "avg_us" in v}
     if "hiz" in kn:
