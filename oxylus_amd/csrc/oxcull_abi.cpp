@@ -93,6 +93,7 @@ struct oxc_ctx {
   hipEvent_t fork_event = nullptr;
   hipStream_t mv_side = nullptr;
   hipEvent_t mv_fork = nullptr, mv_join = nullptr;  // multi-view batch: the MeshletInstance expansion on `side` beside the meshlet stage
+  uint32_t tri_loads = 0;                            // OXC_TUNE_TRI_LOADS: 0 = by the scene (shared geometry -> plain loads), 1 = always `nt`, 2 = always plain
   uint32_t mv_expand_after = 1;                      // 1: the side-stream expansion starts behind the meshlet stage's set-up launches (beside the test + emit); 0: behind the scan (round 5)
   uint32_t mv_expand_async = 4;                      // blocks per CU the side-stream expansion takes; oxc_debug_set_tuning(OXC_TUNE_MV_EXPAND_ASYNC, 0): in order on the caller's stream (A/B aid)
   struct TriPending {
@@ -861,11 +862,16 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     tt.out = static_cast<uint32_t*>(f->reordered_indices_buffer.dptr);
     tt.ticket = t_supers;  // (zeroed by this call's prepare kernel; the fused form has no other use for the accumulators)
     tt.ticket_count = std::max(pa.n_supers_tris, 1u);
+    // Geometry shared between instances (the engine's case: a few Mesh records, many MeshInstances) is read with plain loads -- the next visible
+    // meshlet of another instance finds the lines in L2; unique geometry is streamed once with `nt` loads (oxcull_kernels.hip, OXC_TRI_LOAD_*).
+    // "Shared" = at least four mesh instances per Mesh record of the caller's meshes_buffer.
+    const uint64_t mesh_records = f->meshes_buffer.bytes / sizeof(GpuMesh);
+    const bool cached_loads = ctx->tri_loads == 2u || (ctx->tri_loads == 0u && mesh_records != 0u && (uint64_t)M >= 4u * mesh_records);
     if (unord_tris) {  // one launch: test + expansion per work item (a span of kFusedTriSpan visible meshlets, or a chunk of it)
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
       // (the default cap is "one resident round": of the instantiation that runs, which the launcher knows; a cap set by hand stands)
       const bool default_cap = !(async && ctx->async_tri_per_cu) && ctx->tri_blocks_per_cu == kTriangleBlocksPerCU;
-      launch_tris_fused(tt, late, c->wide_triangle_index, c->small_triangle_cull != 0, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap),
+      launch_tris_fused(tt, late, c->wide_triangle_index, c->small_triangle_cull != 0, cached_loads, std::min(cdiv(std::max(N, 1u), kFusedTriSpan), tri_grid_cap),
                         default_cap ? ctx->num_cus : 0u, ts);
     } else {
     {
@@ -873,7 +879,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
       // (the ordered test kernel walks 64-meshlet chunks with a grid stride: with the default cap it takes four resident rounds of blocks and
       //  lets the dispatcher balance them -- late launch 149.6 -> 140.3 us on the configs[2] frame; a cap set by hand stands)
       const bool default_cap = !(async && ctx->async_tri_per_cu) && ctx->tri_blocks_per_cu == kTriangleBlocksPerCU;
-      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, std::min(t_chunks, (default_cap && !c->wide_triangle_index) ? ctx->num_cus * 32u : tri_grid_cap), ts);  // (WIDE, 4 waves per SIMD: 8 per CU measured better than 32)
+      launch_tris_test(tt, late, c->wide_triangle_index != 0, c->small_triangle_cull != 0, cached_loads, std::min(t_chunks, (default_cap && !c->wide_triangle_index) ? ctx->num_cus * 32u : tri_grid_cap), ts);  // (WIDE, 4 waves per SIMD: 8 per CU measured better than 32)
     }
     TriEmitArgs te;
     te.tri_masks = ctx->lane[0].tri_masks;
@@ -1770,6 +1776,10 @@ oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
       return OXC_OK;
     case OXC_TUNE_MV_EXPAND_ASYNC: ctx->mv_expand_async = value; return OXC_OK;
     case OXC_TUNE_MV_EXPAND_AFTER_SETUP: ctx->mv_expand_after = value; return OXC_OK;
+    case OXC_TUNE_TRI_LOADS:
+      if (value > 2u) return fail(ctx, OXC_INVALID_ARG, "set_tuning: OXC_TUNE_TRI_LOADS is 0 (by the scene), 1 (nt) or 2 (plain)");
+      ctx->tri_loads = value;
+      return OXC_OK;
     case OXC_TUNE_RASTER_BIG_CAPACITY:
       if (ctx->raster_scratch) return fail(ctx, OXC_INVALID_ARG, "set_tuning: the raster scratch is allocated by the first oxc_draw_visbuffer; set its capacity before");
       ctx->raster_capacity_request = value;

@@ -1471,8 +1471,13 @@ OXC_DEV void expand_slots_wide(const uint64_t* masks, const uint32_t* ids, int f
 //  * the 16 pass masks are collected in lanes 0..15 (v_writelane) and stored once.
 // vertex ids, micro indices and positions of a visible meshlet are read once per call: `nt` loads
 // (measured on config 3: 140 -> 121 us per launch on the same box, whole frame +5 %)
-#define OXC_TRI_LOAD_U32 load_stream_u32
-#define OXC_TRI_LOAD_U2 load_stream_u2
+// ... unless the geometry is SHARED between instances (CACHED instantiations, round 6): the engine's case -- a few meshes drawn many times
+// (AssetManager_GLTF.cpp builds one blob per mesh, Scene.cpp:1248-1260 instances them).  There the `nt` hint keeps lines out of the caches that
+// the next visible meshlet of another instance would have hit: the real-mesh frame (3 meshes, 8 700 instances) 0.729 -> 0.632 ms, fused
+// kernels 164.5 / 360.6 -> 132.5 / 292.8 us with plain loads; on unique geometry plain loads cost what is quoted above.  The host picks
+// (oxc_cull_geometry: mesh instances per Mesh record), oxc_debug_set_tuning(OXC_TUNE_TRI_LOADS) overrides.
+#define OXC_TRI_LOAD_U32(base, index) (CACHED ? load_global_u32((base), (index)) : load_stream_u32((base), (index)))
+#define OXC_TRI_LOAD_U2(base, index) (CACHED ? load_global_u2((base), (index)) : load_stream_u2((base), (index)))
 // SMALL (extension, include/oxcull.h small_triangle_cull): after the two reference tests, drop a triangle whose
 // screen-space bounding box covers no pixel centre.  The screen position is computed once per vertex (lane = vertex,
 // two IEEE divisions) and fetched per corner like the clip coordinates; with SMALL off none of it is compiled in.
@@ -1491,7 +1496,7 @@ constexpr int kTriIdxAhead = 2, kTriPosAhead = 1;
 // LDS once, three 16-byte reads per pass (64 B).  T = 64 (one pass per slot): the reads lose outright, fused kernels 99 / 209 -> 112 / 266 us.  WIDE
 // (two passes per slot, kernel bound by instruction issue rather than LDS bandwidth): 137 / 265 -> 132.5 / 258 us; 12-byte reads with the z flags
 // kept as a ballot: 136.5 / 262.6.  So: LDS vertices for WIDE only.
-template <bool LATE, bool WIDE, bool SMALL>
+template <bool LATE, bool WIDE, bool SMALL, bool CACHED = false>
 OXC_DEV void tris_test_body(const TriTestArgs& a) {
   set_half_denorm_flush();
   constexpr int H = WIDE ? 2 : 1;
@@ -1560,7 +1565,7 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
 // machine.  Measured on the configs[2] frame (tools/kbench.py, profiles/r05_ab): fused kernels 98.5 / 205.6 -> 97.1 / 200.5 us, frame
 // 511 -> 505 us with the emit launches in front; dynamic at span granularity gave half of it, a whole dynamic round more was worse.
 constexpr uint32_t kTriTicketCounters = 16;  // (4 / 16 / 64 counters: the same frame time)
-template <bool LATE, bool WIDE, bool SMALL, bool PAIR = false>
+template <bool LATE, bool WIDE, bool SMALL, bool PAIR = false, bool CACHED = false>
 OXC_DEV void tris_fused_body(const TriTestArgs& a) {
   static_assert(!PAIR || WIDE, "the pair form is the form of the 128-triangle meshlets");
   set_half_denorm_flush();
@@ -1997,6 +2002,15 @@ __global__ __launch_bounds__(256, kTriWideWaves) void k_cull_triangles_fused_pai
 template <bool LATE>
 __global__ __launch_bounds__(256) void k_cull_triangles_emit_pairs(TriEmitArgs a) {
   tris_emit_body<LATE, true, true>(a);
+}
+// shared (instanced) geometry: plain loads instead of `nt` for vertex ids, micro indices and positions (OXC_TRI_LOAD_*); INDEX = wide_triangle_index
+template <bool LATE, int INDEX>
+__global__ __launch_bounds__(256, INDEX ? kTriWideWaves : kTriWaves) void k_cull_triangles_fused_cached(TriTestArgs a) {
+  tris_fused_body<LATE, INDEX != 0, false, INDEX == 2, true>(a);
+}
+template <bool LATE, bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? kTriWideWaves : kTriWaves) void k_cull_triangles_test_cached(TriTestArgs a) {
+  tris_test_body<LATE, WIDE, false, true>(a);
 }
 
 // Batched prepare: gets every element's core by value (kernarg), rebuilds the per-stage argument blocks of its
@@ -2479,8 +2493,19 @@ void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_
   else
     hipLaunchKernelGGL((k_cull_meshlets_emit<true, false>), g, b, 0, s, a);
 }
-void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s) {
+void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, bool cached, uint32_t grid, hipStream_t s) {
   dim3 g(grid), b(256);
+  if (cached && !small_triangle_cull) {  // shared geometry (the small-triangle instantiations keep the streaming loads)
+    if (late && wide)
+      hipLaunchKernelGGL((k_cull_triangles_test_cached<true, true>), g, b, 0, s, a);
+    else if (late)
+      hipLaunchKernelGGL((k_cull_triangles_test_cached<true, false>), g, b, 0, s, a);
+    else if (wide)
+      hipLaunchKernelGGL((k_cull_triangles_test_cached<false, true>), g, b, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_cull_triangles_test_cached<false, false>), g, b, 0, s, a);
+    return;
+  }
   const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
   switch (v) {
     case 0: hipLaunchKernelGGL((k_cull_triangles_test<false, false, false>), g, b, 0, s, a); break;
@@ -2496,7 +2521,7 @@ void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_tri
 // resident_cus != 0: the grid is also capped at the blocks of THIS instantiation that are resident at once on that many CUs (occupancy
 // query).  The fused kernel hands out its work by rounds of the grid (tris_fused_body): a grid of two resident rounds -- the WIDE
 // instantiations run 4 waves per SIMD, the generic cap was 8 blocks per CU -- cost the 8 M x 124-triangle frame 33 us (0.562 -> 0.529 ms).
-void launch_tris_fused(const TriTestArgs& a, bool late, uint32_t wide, bool small_triangle_cull, uint32_t grid, uint32_t resident_cus, hipStream_t s) {
+void launch_tris_fused(const TriTestArgs& a, bool late, uint32_t wide, bool small_triangle_cull, bool cached, uint32_t grid, uint32_t resident_cus, hipStream_t s) {
   dim3 b(256);
   const int v = (late ? 4 : 0) | (wide ? 2 : 0) | (small_triangle_cull ? 1 : 0);
 #define OXC_FUSED_LAUNCH(K_)                                                                                       \
@@ -2509,6 +2534,17 @@ void launch_tris_fused(const TriTestArgs& a, bool late, uint32_t wide, bool smal
   case i:                                                                                                          \
     OXC_FUSED_LAUNCH((k_cull_triangles_fused<L_, W_, S_>))                                                         \
     break;
+  if (cached && !small_triangle_cull) {  // shared geometry: plain loads
+    switch ((late ? 4 : 0) | (int)std::min(wide, 2u)) {
+      case 0: OXC_FUSED_LAUNCH((k_cull_triangles_fused_cached<false, 0>)) break;
+      case 1: OXC_FUSED_LAUNCH((k_cull_triangles_fused_cached<false, 1>)) break;
+      case 2: OXC_FUSED_LAUNCH((k_cull_triangles_fused_cached<false, 2>)) break;
+      case 4: OXC_FUSED_LAUNCH((k_cull_triangles_fused_cached<true, 0>)) break;
+      case 5: OXC_FUSED_LAUNCH((k_cull_triangles_fused_cached<true, 1>)) break;
+      default: OXC_FUSED_LAUNCH((k_cull_triangles_fused_cached<true, 2>)) break;
+    }
+    return;
+  }
   if (wide == 2u) {  // {id, corner} pairs
     switch (v & 5) {
       case 0: OXC_FUSED_LAUNCH((k_cull_triangles_fused_pairs<false, false>)) break;

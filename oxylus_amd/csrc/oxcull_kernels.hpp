@@ -369,10 +369,10 @@ void launch_expand(const uint32_t* counts, const uint32_t* offsets, uint32_t n, 
 // a.out != null: the unordered (appending) instantiation of the same kernel; no emit launch follows
 void launch_meshlets_test(const MeshletTestArgs& a, bool hiz, bool occl, bool late, uint32_t grid, uint32_t num_cus, uint32_t grid_limit, hipStream_t s);
 void launch_meshlets_emit(const MeshletEmitArgs& a, bool hiz, bool late, uint32_t grid, hipStream_t s);
-void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, uint32_t grid, hipStream_t s);
+void launch_tris_test(const TriTestArgs& a, bool late, bool wide, bool small_triangle_cull, bool cached_loads, uint32_t grid, hipStream_t s);  // cached_loads: shared (instanced) geometry -- plain loads instead of `nt`
 void launch_tris_emit(const TriEmitArgs& a, bool late, uint32_t wide, uint32_t grid, hipStream_t s);  // wide: oxc_cull_geometry_context::wide_triangle_index (0, 1, 2 = pairs)
 // unordered_output: test + expansion in one launch (a.draw_cmd / a.out set); grid in kFusedTriSpan-meshlet spans
-void launch_tris_fused(const TriTestArgs& a, bool late, uint32_t wide, bool small_triangle_cull, uint32_t grid, uint32_t resident_cus, hipStream_t s);
+void launch_tris_fused(const TriTestArgs& a, bool late, uint32_t wide, bool small_triangle_cull, bool cached_loads, uint32_t grid, uint32_t resident_cus, hipStream_t s);
 void launch_hiz(const HizArgs& a, uint32_t num_cus, hipStream_t s);
 // batched (grid.y = batch element); `dev` is the device copy written by launch_prepare_batch
 void launch_prepare_batch(const BatchBlob& blob, BatchElem* dev, uint32_t grid, hipStream_t s);

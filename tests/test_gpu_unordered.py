@@ -13,7 +13,7 @@ from oxylus_amd import lib as L
 from oxylus_amd.renderer import CullGeometryContext, ImageAttachment, MainGeometryContext, PreparedFrame
 from oxylus_amd.synth import SceneSpec, make_depth, make_scene
 
-from util import assert_same, assert_triangles_adjacent, gpu_frame, oracle_frame, oracle_hiz, sorted_lists
+from util import assert_same, assert_triangles_adjacent, gpu_frame, oracle_frame, oracle_hiz, pairs_as_u64, sorted_lists
 
 pytestmark = pytest.mark.gpu
 
@@ -213,3 +213,33 @@ def test_bad_value_is_refused(renderer):
     with pytest.raises(L.OxcError) as ei:
         renderer.cull_geometry(ctx)
     assert ei.value.status == L.OXC_INVALID_ARG
+
+
+@pytest.mark.parametrize("wide", [0, 1, 2], ids=["packed", "wide9", "pairs"])
+def test_triangle_load_policy_changes_no_byte(oracle_lib, wide):
+    """Round 6: geometry shared between instances is read with plain loads, unique geometry with `nt` loads (OXC_TUNE_TRI_LOADS: 0 = by the scene, 1 = nt,
+    2 = plain).  A cache policy: every list of the ordered and of the fused form must come out the same under both, on a scene of unique meshes and on
+    an instanced one (share_meshes: 3 meshes, 40 instances -- which the default picks plain loads for)."""
+    import oracle
+    from oxylus_amd.renderer import RendererInstance
+
+    r = RendererInstance(0)
+    try:
+        for share in (0, 3):
+            spec = SceneSpec(n_mesh_instances=40, meshlets_per_mesh=120, with_geometry=True, seed=71 + share, tris_per_meshlet=124 if wide else 64, share_meshes=share)
+            cpu = make_scene(spec, "cpu")
+            gpu = cpu.to("cuda")
+            cam = cpu.cull_camera()
+            want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances)
+            want_idx = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, 0, want_vis.numel(), wide=wide).numpy()
+            assert want_idx.size > 2000
+            key = (lambda a: pairs_as_u64(a)) if wide == 2 else (lambda a: a.view(np.uint32))
+            for policy in (0, 1, 2):
+                r.debug_set_tuning(L.TUNE_TRI_LOADS, policy)
+                got = gpu_frame(r, gpu, unordered_output=0, wide_triangle_index=wide, max_tris=128 if wide else 64)
+                assert np.array_equal(got["visible"], want_vis.numpy()) and np.array_equal(got["indices"], want_idx), (share, policy)
+                gotu = gpu_frame(r, gpu, unordered_output=1, wide_triangle_index=wide, max_tris=128 if wide else 64)
+                assert np.array_equal(np.sort(key(gotu["indices"])), np.sort(key(want_idx))), (share, policy)
+    finally:
+        r.debug_set_tuning(L.TUNE_TRI_LOADS, 0)
+        r.close()
