@@ -702,20 +702,22 @@ def bench_real_geometry(args, r, dev, stream, rank=0):
             try:
                 with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_real_geometry_pmc.json")) as f:
                     pm = json.load(f)
-                vals = [cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0) for kk, cs in pm.get("pmc", {}).items() if "k_cull_triangles_fused" in kk and "hbm_read_bytes_corrected" in cs]
+                vals = [cs["hbm_read_bytes_corrected"] + cs.get("hbm_write_bytes", 0) for kk, cs in pm.get("pmc", {}).items()
+                        if "k_cull_triangles_fused_cached" in kk and "hbm_read_bytes_corrected" in cs]
                 if vals:
                     traffic, src = round(sum(vals) / len(vals)), f"profiles/{tag}_real_geometry_pmc.json"
                     break
             except (OSError, ValueError):
                 continue
-        roofline = {"bound": "hbm", "kernel": "k_cull_triangles_fused (early + late launch averaged) over INSTANCED geometry", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        roofline = {"bound": "hbm", "kernel": "k_cull_triangles_fused_cached (early + late launch averaged; plain loads: the geometry is shared between instances)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
                     "algorithmic_bytes_per_launch": round(alg_b), "hbm_bytes_needed_per_launch": round(hbm_b), "kernel_avg_us": round(us, 2),
                     "us_per_1000_visible_meshlets": round(us * 2.0 / max(1, v_e + v_l) * 1e3, 4),
                     "note": "requested bytes, not HBM bytes: the geometry is cache-resident (3 meshes), so frac says how the kernel's per-meshlet rate compares with the "
                             "unique-geometry frame, not how close HBM is to its peak; the HBM side of this kernel is hbm_bytes_needed_per_launch (index list out, ids + MeshletInstance in).  "
-                            "Bound (counters, tools/pmc_real_geometry.sh): VALU issue ~45-55 % busy + the dependent fetch chain per slot (TA waiting on the L1 for the position gather, "
-                            "6-7 lines per meshlet after the vertex remap) -- not memory bandwidth"}
+                            "Since round 6 the host picks PLAIN loads for geometry shared between instances (k_cull_triangles_fused_cached): with the `nt` loads of the unique-geometry frame "
+                            "the L1 waited on L2 misses 61 % of the time (TCP_PENDING_STALL_CYCLES) and the frame took 0.73 instead of 0.63 ms.  What is left (counters, tools/pmc_real_geometry.sh): "
+                            "VALU issue ~70 % busy + the dependent fetch chain per slot -- not memory bandwidth"}
 
     # ---- the checker over a prefix of the same arrays (the scene minus most of its instances): parity + the unpinned gap ----
     bit_match, unpinned = None, None
