@@ -74,7 +74,6 @@ uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
 enum { OXC_TUNE_ASYNC_MTEST_BLOCKS_PER_CU = 0, OXC_TUNE_ASYNC_TRI_BLOCKS_PER_CU = 1, OXC_TUNE_RASTER_BIG_CAPACITY = 2,
        OXC_TUNE_TRI_BLOCKS_PER_CU = 3 /* grid cap of the triangle kernels in blocks per CU (default 8 = one resident round) */,
        OXC_TUNE_TRI_LOADS = 7 /* triangle kernels' loads of vertex ids / micro indices / positions: 0 (default) = by the scene -- plain loads when the geometry is shared (>= 4 mesh instances per Mesh record), `nt` when it is unique; 1 = always `nt`; 2 = always plain.  Same outputs either way */,
-       OXC_TUNE_MV_EXPAND_AFTER_SETUP = 6 /* multi-view batch: 1 (default) = the side-stream expansion starts behind the meshlet stage's set-up launches, 0 = behind the scan (round 5's order) */,
        OXC_TUNE_MV_EXPAND_ASYNC = 5 /* multi-view batch: blocks per CU of the MeshletInstance expansion on the context's own low-priority stream beside the meshlet stage (default 4); 0: in order on the caller's stream */ };
 oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value);
 

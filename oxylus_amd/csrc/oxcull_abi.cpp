@@ -94,7 +94,6 @@ struct oxc_ctx {
   hipStream_t mv_side = nullptr;
   hipEvent_t mv_fork = nullptr, mv_join = nullptr;  // multi-view batch: the MeshletInstance expansion on `side` beside the meshlet stage
   uint32_t tri_loads = 0;                            // OXC_TUNE_TRI_LOADS: 0 = by the scene (shared geometry -> plain loads), 1 = always `nt`, 2 = always plain
-  uint32_t mv_expand_after = 1;                      // 1: the side-stream expansion starts behind the meshlet stage's set-up launches (beside the test + emit); 0: behind the scan (round 5)
   uint32_t mv_expand_async = 4;                      // blocks per CU the side-stream expansion takes; oxc_debug_set_tuning(OXC_TUNE_MV_EXPAND_ASYNC, 0): in order on the caller's stream (A/B aid)
   struct TriPending {
     hipEvent_t done = nullptr;
@@ -975,7 +974,7 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t max_grid = ctx->num_cus * 8;
   const bool do_meshes = ci[0].do_meshes, do_meshlets = ci[0].do_meshlets, do_tris = ci[0].do_tris;
-  bool mv_expand_async = false, mv_expand_deferred = false;
+  bool mv_expand_async = false;
   // The MeshletInstance expansion of a batched call: in order on `s`, or (multi-view, nothing of the call reads the records) on the context's
   // lowest-priority side stream, forked from `s` where this is called and joined at the end of the call.
   auto launch_mv_expand = [&](uint32_t count_, uint32_t g_expand_, uint32_t cap_, bool on_side) -> oxc_status {
@@ -1102,11 +1101,11 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
       // latency-bound set-up launches and the VALU-bound test of the meshlet stage, and is joined at the end of the call (fork / join by
       // events, capturable like async_triangles).  A triangle stage in the call reads the records: in order then.
       mv_expand_async = multiview && do_meshlets && !do_tris && ctx->mv_expand_async != 0;
-      mv_expand_deferred = mv_expand_async && ctx->mv_expand_after != 0;
-      if (!mv_expand_deferred) {
-        oxc_status est = launch_mv_expand(count, g_expand, cap, mv_expand_async);
-        if (est != OXC_OK) return est;
-      }
+      // (Round 6 measured the fork behind the meshlet stage's three set-up launches instead -- they are chains of dependent loads and take 78 us next to
+      //  the store stream against 33 us alone -- : 0.2600 against 0.2615 ms per 16 views on one box, 0.2616 against 0.2568 on another; the test and the
+      //  emit then share the machine with the whole store stream.  The fork stays here.)
+      oxc_status est = launch_mv_expand(count, g_expand, cap, mv_expand_async);
+      if (est != OXC_OK) return est;
     }
   }
   if (do_meshlets && multiview) {
@@ -1189,13 +1188,6 @@ oxc_status oxc_cull_geometry_batch(oxc_ctx* ctx, uint32_t count, const oxc_prepa
     {
       KernelTimer t(ctx, OXC_K_MULTIVIEW_SETUP, s);
       launch_mv_setup(ma, blob, std::max(1u, std::min(cdiv(Mv, 16u), max_grid)), s);  // 16 lanes per mesh instance
-    }
-    // Round 6: the record expansion (466 MB of stores per 16 views of a 10 M-meshlet scene) is forked HERE, behind the three small set-up launches,
-    // and runs beside the VALU-bound test and the emit.  Forked behind the scan (round 5) it ran beside the set-up launches, which are chains of
-    // dependent loads and took 78 us next to the store stream against 33 us alone (profiles/r06_config5_pmc.json: k_mv_group 43, k_mv_scan 19, k_mv_steps 16).
-    if (mv_expand_deferred) {
-      oxc_status est = launch_mv_expand(count, g_expand, cap, true);
-      if (est != OXC_OK) return est;
     }
     {
       KernelTimer t(ctx, OXC_K_MESHLETS_TEST, s);
@@ -1775,7 +1767,6 @@ oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
       ctx->tri_blocks_per_cu = value;
       return OXC_OK;
     case OXC_TUNE_MV_EXPAND_ASYNC: ctx->mv_expand_async = value; return OXC_OK;
-    case OXC_TUNE_MV_EXPAND_AFTER_SETUP: ctx->mv_expand_after = value; return OXC_OK;
     case OXC_TUNE_TRI_LOADS:
       if (value > 2u) return fail(ctx, OXC_INVALID_ARG, "set_tuning: OXC_TUNE_TRI_LOADS is 0 (by the scene), 1 (nt) or 2 (plain)");
       ctx->tri_loads = value;

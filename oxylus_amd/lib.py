@@ -27,7 +27,7 @@ STAGE_MESHLETS = 2
 STAGE_TRIANGLES = 4
 STAGE_ALL = 7
 
-TUNE_ASYNC_MTEST_BLOCKS_PER_CU, TUNE_ASYNC_TRI_BLOCKS_PER_CU, TUNE_RASTER_BIG_CAPACITY, TUNE_TRI_BLOCKS_PER_CU, TUNE_MV_EXPAND_ASYNC, TUNE_MV_EXPAND_AFTER_SETUP, TUNE_TRI_LOADS = 0, 1, 2, 3, 5, 6, 7  # oxc_debug_set_tuning knobs
+TUNE_ASYNC_MTEST_BLOCKS_PER_CU, TUNE_ASYNC_TRI_BLOCKS_PER_CU, TUNE_RASTER_BIG_CAPACITY, TUNE_TRI_BLOCKS_PER_CU, TUNE_MV_EXPAND_ASYNC, TUNE_TRI_LOADS = 0, 1, 2, 3, 5, 7  # oxc_debug_set_tuning knobs
 
 
 class Buffer(C.Structure):

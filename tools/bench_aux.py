@@ -340,8 +340,6 @@ def bench_config5(args, r, dev, stream, rank, world, dist, nested=False):
     implicit_main = bool(getattr(args, "implicit_lists", False))
     if os.environ.get("OXC_BENCH_MV_EXPAND_ASYNC"):  # A/B aid: 0 = the explicit records written in order on the caller's stream (round 4's form), n = blocks per CU of the side-stream expansion
         r.debug_set_tuning(L.TUNE_MV_EXPAND_ASYNC, int(os.environ["OXC_BENCH_MV_EXPAND_ASYNC"]))
-    if os.environ.get("OXC_BENCH_MV_EXPAND_AFTER_SETUP"):  # A/B aid: 0 = round 5's fork point (behind the scan)
-        r.debug_set_tuning(L.TUNE_MV_EXPAND_AFTER_SETUP, int(os.environ["OXC_BENCH_MV_EXPAND_AFTER_SETUP"]))
     groups = make_groups(implicit_main)
 
     def check(st):
