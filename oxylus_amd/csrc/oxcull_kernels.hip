@@ -1509,7 +1509,10 @@ OXC_DEV void tris_test_body(const TriTestArgs& a) {
   __shared__ uint32_t s_red[4];
   constexpr bool kLdsVerts = WIDE;
   __shared__ uint4 s_vert[kLdsVerts ? 4 : 1][kLdsVerts ? 64 : 1];  // per wave: the transformed vertices of the slot in hand (same-wave LDS traffic is in order)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave as a SCALAR in the CACHED instantiations: the compiler cannot see that threadIdx.x >> 6 is the same in all 64 lanes, and everything derived from it -- a
+  //  slot's index, "is this slot inside the list" -- is computed per lane, ~6 VALU instructions per slot.  Round 6, measured: on shared geometry, where the kernel
+  //  is 90 % VALU-busy, 131.7 / 293.7 -> 126.4 / 286.1 us; on unique geometry the extra scalar registers cost more than the instructions gave, 198.4 -> 201.4 us)
+  const int lane = threadIdx.x & 63, wave = CACHED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
   const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;
@@ -1590,7 +1593,10 @@ OXC_DEV void tris_fused_body(const TriTestArgs& a) {
   __shared__ __attribute__((aligned(16))) uint32_t f_run[4 * (kEmitRun + 8u)];
   __shared__ uint32_t f_base;
   __shared__ uint32_t f_next;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave as a SCALAR in the CACHED instantiations: the compiler cannot see that threadIdx.x >> 6 is the same in all 64 lanes, and everything derived from it -- a
+  //  slot's index, "is this slot inside the list" -- is computed per lane, ~6 VALU instructions per slot.  Round 6, measured: on shared geometry, where the kernel
+  //  is 90 % VALU-busy, 131.7 / 293.7 -> 126.4 / 286.1 us; on unique geometry the extra scalar registers cost more than the instructions gave, 198.4 -> 201.4 us)
+  const int lane = threadIdx.x & 63, wave = CACHED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
   const uint32_t V = a.tri_cmd[0];
   const uint32_t first = LATE ? a.vis[1] : 0u;  // cull_triangles.slang:34-37
   const uint32_t nchunks = (V + kTriChunk - 1) / kTriChunk;  // 64-slot chunks of the list (a chunk's slots beyond V re-do the last slot and leave empty masks)
@@ -2005,6 +2011,7 @@ __global__ __launch_bounds__(256) void k_cull_triangles_emit_pairs(TriEmitArgs a
 }
 // shared (instanced) geometry: plain loads instead of `nt` for vertex ids, micro indices and positions (OXC_TRI_LOAD_*); INDEX = wide_triangle_index
 template <bool LATE, int INDEX>
+// (waves per SIMD of the T = 64 instantiation on the real-mesh frame: 8 -> 0.620 ms, 7 -> 0.628 although its 94 SGPRs spill nothing, 6 -> 0.79)
 __global__ __launch_bounds__(256, INDEX ? kTriWideWaves : kTriWaves) void k_cull_triangles_fused_cached(TriTestArgs a) {
   tris_fused_body<LATE, INDEX != 0, false, INDEX == 2, true>(a);
 }
