@@ -63,3 +63,46 @@ def test_random_frame_matches_checker(renderer, oracle_lib, seed):
         shared = gpu_frame(renderer, gpu, cull_flags=flags, use_hiz=True, hiz=att, mask=mask.clone(), two_pass=two, share_pass_tests=True)
         assert_same(want, shared, keys)
     assert_same(want, got, keys)
+
+
+def _tri_case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    wide = int(rng.choice([0, 1, 2, 2]))
+    tris = int(rng.choice([17, 64, 64])) if wide == 0 else int(rng.choice([64, 100, 124, 128]))
+    k = int(rng.choice([5, 63, 64, 65, 130, 257]))
+    m = int(rng.choice([1, 7, 40, 90]))
+    share = int(rng.choice([0, 0, 2, 5]))
+    spec = SceneSpec(n_mesh_instances=m, meshlets_per_mesh=k, seed=7000 + seed, ragged=bool(rng.integers(2)), scene_depth=float(rng.choice([15.0, 60.0])),
+                     tris_per_meshlet=tris, verts_per_meshlet=int(rng.choice([64, 64, 33])), share_meshes=min(share, m))
+    return spec, wide, int(rng.integers(2)), int(rng.choice([0, 1, 2])), bool(rng.integers(4) == 0)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_triangle_stage_forms_match_checker(oracle_lib, seed):
+    """Round 6: the index forms (packed 24 + 8, 23 + 9, {id, corner} pairs), the two list layouts (ordered / unordered_output = 1), the two load
+    policies of the triangle kernels (nt / plain; 0 = by the scene) and the small-triangle cull, drawn at random over scenes of unique and of
+    shared meshes; every list against the checker (unordered lists as sorted sets)."""
+    import oracle
+    from oxylus_amd.renderer import RendererInstance
+    from util import pairs_as_u64
+
+    spec, wide, unordered, policy, small = _tri_case(seed)
+    cpu = make_scene(spec, "cpu")
+    gpu = cpu.to("cuda")
+    cam = cpu.cull_camera()
+    want_vis = oracle.cull_meshlets(cpu, cam, cpu.meshlet_instances)
+    want_idx = oracle.cull_triangles(cpu, cam, cpu.meshlet_instances, want_vis, 0, want_vis.numel(), wide=wide, small_triangle_cull=small).numpy()
+    r = RendererInstance(0)
+    try:
+        r.debug_set_tuning(L.TUNE_TRI_LOADS, policy)
+        got = gpu_frame(r, gpu, unordered_output=unordered, wide_triangle_index=wide, small_triangle_cull=small, max_tris=128 if wide else 64)
+    finally:
+        r.debug_set_tuning(L.TUNE_TRI_LOADS, 0)
+        r.close()
+    key = (lambda a: pairs_as_u64(a)) if wide == 2 else (lambda a: a.view(np.uint32))
+    if unordered:
+        assert np.array_equal(np.sort(got["visible"]), want_vis.numpy())
+        assert np.array_equal(np.sort(key(got["indices"])), np.sort(key(want_idx)))
+    else:
+        assert np.array_equal(got["visible"], want_vis.numpy())
+        assert np.array_equal(got["indices"], want_idx)
