@@ -65,6 +65,9 @@ oxc_status oxc_debug_read_u32(oxc_ctx* ctx, const void* dptr, uint32_t n, uint32
  * also published its results, 2: late call that reused them, 3: late call that reused them and launched no prepare kernel (the early
  * call had done that work too: it was in order on one stream and directly in front of it). */
 uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx);
+/* Test hook: which loads the triangle kernels of the context's last oxc_cull_geometry call used for vertex ids / micro indices / positions -- 0: the call
+ * ran no triangle stage, 1: `nt` (geometry read once), 2: plain (geometry shared between instances: >= 4 mesh instances per Mesh record, or OXC_TUNE_TRI_LOADS). */
+uint32_t oxc_debug_tri_loads_mode(const oxc_ctx* ctx);
 
 /* Harness hook: sizing / scheduling knobs of a context that the measurements and the tests move (the library itself reads no environment
  * variable).  OXC_TUNE_ASYNC_*: resident blocks per CU the persistent kernels of the meshlet / triangle stage take while async_triangles

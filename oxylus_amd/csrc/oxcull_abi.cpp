@@ -127,6 +127,7 @@ struct oxc_ctx {
   };
   SharedTests shared;
   uint32_t last_share_mode = 0;  // oxc_debug_shared_tests_mode
+  uint32_t last_tri_loads = 0;   // oxc_debug_tri_loads_mode: 0 = the last call ran no triangle stage, 1 = nt loads, 2 = plain loads
   uint64_t call_seq = 0;  // lane-0 oxc_cull_geometry calls so far: parity selects cache / t_supers
   // resident blocks per CU of the persistent kernels while the two stages share the machine (0 = no limit); oxc_debug_set_tuning
   // overrides the defaults (tuning aid of tools/kbench.py)
@@ -559,6 +560,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
   if (st != OXC_OK) return st;
   OXC_ORDER(ctx, hip_stream);
   ctx->last_share_mode = 0;
+  ctx->last_tri_loads = 0;
   if (do_meshes) ctx->shared.valid = false;  // (share_pass_tests: the MeshletInstance list is rebuilt; a flagged early call marks its results valid below)
 
   // ---- async_triangles bookkeeping (include/oxcull.h).  Calls alternate between two sets of instance rows / triangle-count
@@ -866,6 +868,7 @@ oxc_status oxc_cull_geometry(oxc_ctx* ctx, const oxc_prepared_frame* f, oxc_cull
     // "Shared" = at least four mesh instances per Mesh record of the caller's meshes_buffer.
     const uint64_t mesh_records = f->meshes_buffer.bytes / sizeof(GpuMesh);
     const bool cached_loads = ctx->tri_loads == 2u || (ctx->tri_loads == 0u && mesh_records != 0u && (uint64_t)M >= 4u * mesh_records);
+    ctx->last_tri_loads = (cached_loads && !c->small_triangle_cull) ? 2u : 1u;
     if (unord_tris) {  // one launch: test + expansion per work item (a span of kFusedTriSpan visible meshlets, or a chunk of it)
       KernelTimer t(ctx, late ? OXC_K_TRIANGLES_TEST_LATE : OXC_K_TRIANGLES_TEST, ts);
       // (the default cap is "one resident round": of the instantiation that runs, which the launcher knows; a cap set by hand stands)
@@ -1756,6 +1759,7 @@ oxc_status oxc_debug_project_aabb(oxc_ctx* ctx, const float* mvp16_host, float n
 }
 
 uint32_t oxc_debug_shared_tests_mode(const oxc_ctx* ctx) { return ctx ? ctx->last_share_mode : 0u; }
+uint32_t oxc_debug_tri_loads_mode(const oxc_ctx* ctx) { return ctx ? ctx->last_tri_loads : 0u; }
 
 oxc_status oxc_debug_set_tuning(oxc_ctx* ctx, uint32_t knob, uint32_t value) {
   if (!ctx) return OXC_INVALID_ARG;

@@ -275,6 +275,7 @@ EXPORTS = [
     "oxc_broadcast_hiz_levels",
     "oxc_debug_read_u32",
     "oxc_debug_shared_tests_mode",
+    "oxc_debug_tri_loads_mode",
     "oxc_debug_set_tuning",
     "oxc_debug_count_occlusion_candidates",
     "oxc_debug_project_aabb",
@@ -341,6 +342,8 @@ def load(path: str = None) -> C.CDLL:
     lib.oxc_debug_read_u32.argtypes = [vp, vp, C.c_uint32, vp, vp]
     lib.oxc_debug_shared_tests_mode.argtypes = [vp]
     lib.oxc_debug_shared_tests_mode.restype = C.c_uint32
+    lib.oxc_debug_tri_loads_mode.argtypes = [vp]
+    lib.oxc_debug_tri_loads_mode.restype = C.c_uint32
     lib.oxc_debug_raster_stats.argtypes = [vp, vp, vp]
     lib.oxc_debug_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.oxc_debug_count_occlusion_candidates.argtypes = [vp, vp]

@@ -398,6 +398,10 @@ class RendererInstance:
         3 late call that reused and needed no prepare kernel."""
         return int(self._lib.oxc_debug_shared_tests_mode(self._ctx))
 
+    def debug_tri_loads_mode(self) -> int:
+        """1 = the last call's triangle kernels used nt loads, 2 = plain loads (shared geometry), 0 = no triangle stage ran."""
+        return int(self._lib.oxc_debug_tri_loads_mode(self._ctx))
+
     def debug_project_aabb(self, mvp16, near_clip: float, boxes6: torch.Tensor) -> torch.Tensor:
         """boxes6 f32 [n, 6] = {center.xyz, extent.xyz} -> f32 [n, 7] = {min.u, min.v, min.z, max.u, max.v, max.z, valid}."""
         n = boxes6.shape[0]

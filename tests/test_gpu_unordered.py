@@ -238,6 +238,8 @@ def test_triangle_load_policy_changes_no_byte(oracle_lib, wide):
                 r.debug_set_tuning(L.TUNE_TRI_LOADS, policy)
                 got = gpu_frame(r, gpu, unordered_output=0, wide_triangle_index=wide, max_tris=128 if wide else 64)
                 assert np.array_equal(got["visible"], want_vis.numpy()) and np.array_equal(got["indices"], want_idx), (share, policy)
+                # the host's own choice: 40 instances of 3 meshes are shared geometry (plain loads), 40 instances of 40 meshes are not
+                assert r.debug_tri_loads_mode() == ((2 if share else 1) if policy == 0 else policy)
                 gotu = gpu_frame(r, gpu, unordered_output=1, wide_triangle_index=wide, max_tris=128 if wide else 64)
                 assert np.array_equal(np.sort(key(gotu["indices"])), np.sort(key(want_idx))), (share, policy)
     finally:
