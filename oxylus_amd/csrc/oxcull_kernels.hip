@@ -2342,15 +2342,21 @@ __global__ __launch_bounds__(256, SAME_POS ? 6 : 4) void k_mv_test(MvArgs a) {
 __global__ __launch_bounds__(256) void k_mv_emit(MvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const MvView& w = a.dev[blockIdx.y];
+  // (the view's pointers as values: read through the reference, `w.out` was re-loaded from the view table -- a scalar load and its wait -- in front of every
+  //  store of the expansion loop below, since the compiler cannot know that the stores leave the table alone; round 6)
+  uint32_t* const out = w.out;
+  const uint64_t* const wbits = w.bits;
+  const uint32_t *const widbase = w.idbase, *const wsupers = w.supers, *const wcounts = w.counts;
+  uint32_t* const wtri_cmd = w.tri_cmd;
   const uint32_t nchunks = gptr(w.scan_total)[0];
   const uint32_t nwords = nchunks * 4u;
   const uint32_t nspans = (nchunks + 15u) / 16u;
-  if (nspans == 0u && blockIdx.x == 0 && threadIdx.x == 0) gptr(w.tri_cmd)[0] = 0u;
+  if (nspans == 0u && blockIdx.x == 0 && threadIdx.x == 0) gptr(wtri_cmd)[0] = 0u;
   for (uint32_t span = blockIdx.x * 4u + (uint32_t)wave; span < nspans; span += gridDim.x * 4u) {
     const uint32_t wd = span * 64u + (uint32_t)lane;
     const uint32_t wc = min(wd, nwords - 1u);
-    uint64_t bits = gptr(w.bits)[wc];
-    const uint32_t idb = gptr(w.idbase)[wc >> 2] + (wc & 3u) * 64u;
+    uint64_t bits = gptr(wbits)[wc];
+    const uint32_t idb = gptr(widbase)[wc >> 2] + (wc & 3u) * 64u;
     // exclusive base of the span: all supers before its super + the chunk counts inside it
     const uint32_t c0 = span * 16u, sup = c0 / kChunksPerSuper;
     uint32_t acc = 0;
@@ -2359,20 +2365,19 @@ __global__ __launch_bounds__(256) void k_mv_emit(MvArgs a) {
     for (uint32_t i0 = (uint32_t)lane; i0 < sup; i0 += 512u) {
       uint32_t part[8];
 #pragma unroll
-      for (uint32_t u = 0; u < 8u; u++) part[u] = gptr(w.supers)[min(i0 + 64u * u, sup - 1u) * kSuperStride];
+      for (uint32_t u = 0; u < 8u; u++) part[u] = gptr(wsupers)[min(i0 + 64u * u, sup - 1u) * kSuperStride];
 #pragma unroll
       for (uint32_t u = 0; u < 8u; u++) acc += i0 + 64u * u < sup ? part[u] : 0u;
     }
     const uint32_t j = sup * kChunksPerSuper + (uint32_t)lane;
-    if (j < c0) acc += gptr(w.counts)[j];
+    if (j < c0) acc += gptr(wcounts)[j];
     const uint32_t base = wave_sum(acc);
     if (wd >= nwords) bits = 0ull;
     const uint32_t cnt = (uint32_t)__popcll((unsigned long long)bits);
     const uint32_t incl = wave_incl_scan(cnt, lane);
     const uint32_t off = base + incl - cnt;
-    if (lane == 63 && span == nspans - 1u) gptr(w.tri_cmd)[0] = base + incl;  // cull_triangles_cmd.x
+    if (lane == 63 && span == nspans - 1u) gptr(wtri_cmd)[0] = base + incl;  // cull_triangles_cmd.x
     const uint32_t blo = (uint32_t)bits, bhi = (uint32_t)(bits >> 32);
-    const uint64_t below = (1ull << lane) - 1ull;
     // (Staging the span's ids in an LDS run and writing 16-byte stores, as expand_slots_wide does for the index list: 44 -> 115 us with either store
     // policy -- the second pass over the 64 words and the LDS hand-offs cost more than the 64 short stores.)
 #pragma unroll 4
@@ -2380,7 +2385,8 @@ __global__ __launch_bounds__(256) void k_mv_emit(MvArgs a) {
       const uint64_t bk = (uint64_t)readlane_u(blo, k) | ((uint64_t)readlane_u(bhi, k) << 32);
       if (bk == 0ull) continue;  // wave-uniform
       const uint32_t ok = readlane_u(off, k), ik = readlane_u(idb, k);
-      if ((bk >> lane) & 1ull) gptr(w.out)[ok + (uint32_t)__popcll((unsigned long long)(bk & below))] = ik + (uint32_t)lane;
+      // (a lane's rank among the word's set bits: v_mbcnt with the word as its scalar mask operand)
+      if ((bk >> lane) & 1ull) gptr(out)[ok + __builtin_amdgcn_mbcnt_hi((uint32_t)(bk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bk, 0u))] = ik + (uint32_t)lane;
     }
   }
 }
